@@ -1,0 +1,85 @@
+"""ctypes binding of libamq_hip.so (C ABI: include/amq_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call
+fails, an exception is raised.  PyTorch is used only for device memory and the
+current HIP stream.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamq_hip.so")
+
+AMQ_OK = 0
+MODE_HQQ, MODE_FMA = 0, 1
+PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
+MAX_SEGMENTS = 4
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+
+class Segment(ctypes.Structure):
+    """mirror of `amq_segment` (include/amq_hip.h)"""
+    _fields_ = [("qweight_native", _vp), ("meta_native", _vp), ("bias", _vp), ("residual", _vp),
+                ("y", _vp), ("N", _i), ("bits", _i), ("mode", _i), ("y_stride", _i)]
+
+
+# name -> (restype, argtypes); must list every symbol include/amq_hip.h declares
+SIGNATURES = {
+    "amq_version": (_i, []),
+    "amq_last_error": (ctypes.c_char_p, []),
+    "amq_query": (_i, [_i, ctypes.POINTER(_i), _i]),
+    "amq_native_qweight_bytes": (_sz, [_i, _i, _i]),
+    "amq_native_meta_bytes": (_sz, [_i, _i, _i]),
+    "amq_repack_from_hqq": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "amq_repack_from_gptq": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "amq_repack_from_awq": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "amq_dequantize_f16": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "amq_dequantize_hqq_f16": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "amq_gemv_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "amq_gemm_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "amq_linear_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+class AmqError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libamq_hip.so once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmqError(
+            f"{LIB_PATH} not found: the HIP extension is not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C amq_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != AMQ_OK:
+        msg = load().amq_last_error().decode("utf-8", "replace")
+        raise AmqError(f"libamq_hip error {rc}: {msg}")
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())

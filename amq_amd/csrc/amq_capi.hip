@@ -1,0 +1,155 @@
+// amq_capi.hip -- extern "C" boundary of libamq_hip.so (see include/amq_hip.h).
+// Argument validation + dispatch only; no allocation, no synchronisation.
+#include "../../include/amq_hip.h"
+#include "amq_common.cuh"
+#include "amq_kernels.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return AMQ_OK;
+    return fail(AMQ_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+int check_shape(int bits, int N, int K, int group) {
+    if (bits != 2 && bits != 3 && bits != 4) return fail(AMQ_EINVAL, "bits must be 2, 3 or 4 (got %d)", bits);
+    if (group != 128) return fail(AMQ_ESHAPE, "group size must be 128 (got %d)", group);
+    if (N <= 0 || K <= 0 || (N % 16) != 0 || (K % 128) != 0)
+        return fail(AMQ_ESHAPE, "need N %% 16 == 0 and K %% 128 == 0 (got N=%d K=%d)", N, K);
+    return AMQ_OK;
+}
+
+int check_mode(int mode) {
+    if (mode != AMQ_MODE_HQQ && mode != AMQ_MODE_FMA) return fail(AMQ_EINVAL, "unknown dequant mode %d", mode);
+    return AMQ_OK;
+}
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+}  // namespace
+
+extern "C" {
+
+int amq_version(void) { return AMQ_VERSION; }
+const char* amq_last_error(void) { return g_err; }
+
+int amq_query(int K, int* out, int cap) {
+    int vals[4];
+    int maxm = 0;
+    for (int m = 1; m <= 64; ++m)
+        if (amq::gemv_lds_bytes(m, K) <= LDS_LIMIT) maxm = m;
+    vals[0] = maxm;                 // largest M amq_gemv_f16 accepts for this K
+    vals[1] = (int)LDS_LIMIT;
+    vals[2] = amq::TILE_N;
+    vals[3] = amq::TILE_K;
+    int n = cap < 4 ? cap : 4;
+    for (int i = 0; i < n; ++i) out[i] = vals[i];
+    return n;
+}
+
+size_t amq_native_qweight_bytes(int bits, int N, int K) { return amq::native_qweight_bytes(bits, N, K); }
+size_t amq_native_meta_bytes(int N, int K, int group) { (void)group; return amq::native_meta_bytes(N, K); }
+
+int amq_repack_from_hqq(int bits, const void* W_q, const void* scale, const void* zero, int N, int K, int group,
+                        void* qn, void* mn, void* stream) {
+    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (!W_q || !scale || !zero || !qn || !mn) return fail(AMQ_EINVAL, "null pointer");
+    return check_hip(amq::launch_repack(amq::FMT_HQQ, bits, W_q, scale, zero, N, K, qn, mn, (hipStream_t)stream), "repack_from_hqq");
+}
+
+int amq_repack_from_gptq(int bits, const void* qweight, const void* scales, const void* zeros, int N, int K, int group,
+                         void* qn, void* mn, void* stream) {
+    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (!qweight || !scales || !zeros || !qn || !mn) return fail(AMQ_EINVAL, "null pointer");
+    return check_hip(amq::launch_repack(amq::FMT_GPTQ, bits, qweight, scales, zeros, N, K, qn, mn, (hipStream_t)stream), "repack_from_gptq");
+}
+
+int amq_repack_from_awq(const void* qweight, const void* scales, const void* scaled_zeros, int N, int K, int group,
+                        void* qn, void* mn, void* stream) {
+    if (int rc = check_shape(4, N, K, group)) return rc;
+    if (!qweight || !scales || !scaled_zeros || !qn || !mn) return fail(AMQ_EINVAL, "null pointer");
+    return check_hip(amq::launch_repack(amq::FMT_AWQ, 4, qweight, scales, scaled_zeros, N, K, qn, mn, (hipStream_t)stream), "repack_from_awq");
+}
+
+int amq_dequantize_f16(int bits, int mode, const void* qn, const void* mn, int N, int K, int group, void* W, void* stream) {
+    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (int rc = check_mode(mode)) return rc;
+    if (!qn || !mn || !W) return fail(AMQ_EINVAL, "null pointer");
+    return check_hip(amq::launch_dequantize(bits, mode, qn, mn, N, K, W, (hipStream_t)stream), "dequantize");
+}
+
+int amq_dequantize_hqq_f16(int bits, const void* W_q, const void* scale, const void* zero, int N, int K, int group,
+                           void* W, void* stream) {
+    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (!W_q || !scale || !zero || !W) return fail(AMQ_EINVAL, "null pointer");
+    return check_hip(amq::launch_dequantize_hqq(bits, W_q, scale, zero, N, K, W, (hipStream_t)stream), "dequantize_hqq");
+}
+
+int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const void* x2, const void* gamma,
+                         float eps, int prologue, int M, int K, int group, int x_stride, void* stream) {
+    if (!segs || nseg < 1 || nseg > AMQ_MAX_SEGMENTS) return fail(AMQ_EINVAL, "nseg must be 1..%d (got %d)", AMQ_MAX_SEGMENTS, nseg);
+    if (!x) return fail(AMQ_EINVAL, "null x");
+    if (prologue < AMQ_PRO_NONE || prologue > AMQ_PRO_SILU_MUL) return fail(AMQ_EINVAL, "unknown prologue %d", prologue);
+    if (prologue == AMQ_PRO_RMSNORM && !gamma) return fail(AMQ_EINVAL, "RMSNorm prologue needs gamma");
+    if (prologue == AMQ_PRO_SILU_MUL && !x2) return fail(AMQ_EINVAL, "SiLU*mul prologue needs x2");
+    if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
+    if (amq::gemv_lds_bytes(M, K) > LDS_LIMIT)
+        return fail(AMQ_ESHAPE, "M=%d rows of K=%d do not fit LDS for the GEMV path; use amq_gemm_f16", M, K);
+    amq::GemvArgs a{};
+    int wg = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const amq_segment& s = segs[i];
+        if (int rc = check_shape(s.bits, s.N, K, group)) return rc;
+        if (int rc = check_mode(s.mode)) return rc;
+        if (!s.qweight_native || !s.meta_native || !s.y) return fail(AMQ_EINVAL, "segment %d: null pointer", i);
+        amq::GemvSeg& d = a.seg[i];
+        d.qweight = s.qweight_native; d.meta = s.meta_native; d.bias = s.bias; d.residual = s.residual; d.y = s.y;
+        d.N = s.N; d.bits = s.bits; d.mode = s.mode; d.wg_begin = wg;
+        d.y_stride = s.y_stride ? s.y_stride : s.N;
+        wg += s.N / 16;
+    }
+    a.nseg = nseg; a.M = M; a.K = K; a.x_stride = x_stride ? x_stride : K;
+    a.x = x; a.x2 = x2; a.gamma = gamma; a.eps = eps; a.prologue = prologue;
+    return check_hip(amq::launch_gemv(a, wg, (hipStream_t)stream), "gemv");
+}
+
+int amq_gemv_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
+                 int M, int N, int K, int group, int x_stride, int y_stride, void* stream) {
+    amq_segment s{};
+    s.qweight_native = qn; s.meta_native = mn; s.bias = bias; s.residual = nullptr; s.y = y;
+    s.N = N; s.bits = bits; s.mode = mode; s.y_stride = y_stride;
+    return amq_gemv_grouped_f16(&s, 1, x, nullptr, nullptr, 0.f, AMQ_PRO_NONE, M, K, group, x_stride, stream);
+}
+
+int amq_gemm_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
+                 int M, int N, int K, int group, int x_stride, int y_stride, void* stream) {
+    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (int rc = check_mode(mode)) return rc;
+    if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
+    amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N};
+    return check_hip(amq::launch_gemm(a, (hipStream_t)stream), "gemm");
+}
+
+int amq_linear_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
+                   int M, int N, int K, int group, void* stream) {
+    // few rows: weight-streaming GEMV family; otherwise the tiled MFMA GEMM
+    if (M <= 8 && amq::gemv_lds_bytes(M, K) <= LDS_LIMIT)
+        return amq_gemv_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
+    return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+// amq_gemm.hip -- y[M,N] = x[M,K] . W^T for many rows (prefill / batched), gfx950.
+//
+// Replaces the reference's tensor-core paths
+//   gemm_w4a16_T1 / gemm_w4a16_T2 (amq/kernel/ft/quantization_new/gemm/gemm_cuda.cu:290-586, 746-927)
+//   and GPTQLinear.forward's torch unpack + matmul branch for M >= 128
+//   (hqq/backends/autogptq.py:245-283)
+// for 2/3/4-bit alike, over the native AMQ-T16 layout.
+//
+// Structure: workgroup tile BM x 128 (BM = 128 or 64), BK = 128 (one quant group), 4 waves side by
+// side along N (wave tile BM x 32).  x tiles are double-buffered through LDS
+// (register-staged: issue-early / write-late); the packed W tile never
+// touches LDS -- each lane's 16/12/8-byte payload unpacks (v_and_or +
+// v_pk_*_f16) directly into the B operand of v_mfma_f32_16x16x32_f16 and is
+// reused across all BM/16 row blocks, so the unpack VALU work is amortised BM/16x.
+// fp32 accumulate; split-K is not used (K/128 steps stay inside one workgroup,
+// results are deterministic).
+#include "amq_common.cuh"
+#include "amq_kernels.h"
+
+namespace amq {
+
+constexpr int GM_BN = 128;
+constexpr int GM_THREADS = 256;
+constexpr int GM_LDA = 128 + 8;     // halves per staged x row (272 B: conflict-free ds_read_b128)
+
+template <int BITS, int MODE, int BM>
+__global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
+    constexpr int MBLK = BM / 16;              // 16-row blocks per wave tile
+    constexpr int ACH = BM * 16 / GM_THREADS;  // 16-byte chunks of the x tile per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* const abase = (_Float16*)smem;
+    auto abuf = [&](int i) { return abase + (i & 1) * (BM * GM_LDA); };
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, o = lane >> 4;
+    const int G = a.K >> 7;
+    const int ntn = (a.N + GM_BN - 1) / GM_BN;
+    // consecutive workgroups walk M for a fixed N panel: the packed W panel
+    // (tiny) stays in L2 while x tiles stream
+    const int bn = (int)blockIdx.x % ntn, bm = (int)blockIdx.x / ntn;
+    const int m0 = bm * BM, n0 = bn * GM_BN + wave * 32;
+
+    const _Float16* x = (const _Float16*)a.x;
+    const uint32_t* qw = (const uint32_t*)a.qweight;
+    const h2* mt = (const h2*)a.meta;
+
+    f4 acc[MBLK][2];
+#pragma unroll
+    for (int i = 0; i < MBLK; ++i) { acc[i][0] = (f4){0, 0, 0, 0}; acc[i][1] = (f4){0, 0, 0, 0}; }
+
+    h8 areg[ACH];
+    LanePayload<BITS> pay[2];
+    h2 meta[2];
+    auto load_a = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) {
+            const int c = threadIdx.x + GM_THREADS * j;
+            const int row = c >> 4, col = (c & 15) * 8;
+            const int m = m0 + row;
+            areg[j] = (m < a.M) ? *(const h8*)(x + (size_t)m * a.x_stride + kt * 128 + col) : (h8)(_Float16)0;
+        }
+    };
+    auto store_a = [&](_Float16* buf) {
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) {
+            const int c = threadIdx.x + GM_THREADS * j;
+            const int row = c >> 4, col = (c & 15) * 8;
+            *(h8*)(buf + row * GM_LDA + col) = areg[j];
+        }
+    };
+    auto load_b = [&](int kt) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            // clamp column blocks past N (ragged N % 128): computed, never stored
+            const int nblk = min((n0 >> 4) + nb, (a.N >> 4) - 1);
+            const size_t tile = (size_t)nblk * G + kt;
+            // plain (cached) loads: the W panel is re-read by every M block
+            const uint32_t* p = qw + tile * 64 * BITS + lane * BITS;
+#pragma unroll
+            for (int d = 0; d < BITS; ++d) pay[nb].w[d] = p[d];
+            meta[nb] = mt[tile * 16 + r];
+        }
+    };
+
+    load_a(0);
+    load_b(0);
+    store_a(abuf(0));
+    __syncthreads();
+
+    for (int kt = 0; kt < G; ++kt) {
+        const _Float16* ab = abuf(kt);
+        h2 wv[2][16];
+        dequant_lane<BITS, MODE>(pay[0].w, meta[0], wv[0]);
+        dequant_lane<BITS, MODE>(pay[1].w, meta[1], wv[1]);
+        if (kt + 1 < G) { load_a(kt + 1); load_b(kt + 1); }      // issue early
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            h8 b0, b1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                b0[2 * p] = wv[0][4 * t + p].x; b0[2 * p + 1] = wv[0][4 * t + p].y;
+                b1[2 * p] = wv[1][4 * t + p].x; b1[2 * p + 1] = wv[1][4 * t + p].y;
+            }
+#pragma unroll
+            for (int mb = 0; mb < MBLK; ++mb) {
+                const h8 av = *(const h8*)(ab + (mb * 16 + r) * GM_LDA + 32 * t + 8 * o);
+                acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b0, acc[mb][0], 0, 0, 0);
+                acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b1, acc[mb][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < G) store_a(abuf(kt + 1));              // write late
+        __syncthreads();
+    }
+
+    // epilogue: acc[mb][nb][i] = D[m = mb*16 + 4*o + i][n = nb*16 + r]
+    const _Float16* bias = (const _Float16*)a.bias;
+    _Float16* y = (_Float16*)a.y;
+#pragma unroll
+    for (int mb = 0; mb < MBLK; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + mb * 16 + 4 * o + i;
+                const int n = n0 + nb * 16 + r;
+                if (m < a.M && n < a.N) {
+                    _Float16 v = (_Float16)acc[mb][nb][i];
+                    if (bias) v = v + bias[n];
+                    y[(size_t)m * a.y_stride + n] = v;
+                }
+            }
+}
+
+template <int BITS, int MODE>
+static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
+    const int ntn = (a.N + GM_BN - 1) / GM_BN;
+    if (a.M > 64) {
+        const int ntm = (a.M + 127) / 128;
+        const size_t lds = 2 * 128 * GM_LDA * 2;
+        auto k = gemm_kernel<BITS, MODE, 128>;
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(GM_THREADS), lds, st, a);
+    } else {
+        const int ntm = (a.M + 63) / 64;
+        const size_t lds = 2 * 64 * GM_LDA * 2;
+        hipLaunchKernelGGL((gemm_kernel<BITS, MODE, 64>), dim3(ntm * ntn), dim3(GM_THREADS), lds, st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t st) {
+    if (a.mode == MODE_HQQ) {
+        if (a.bits == 4) return gemm_launch_bm<4, MODE_HQQ>(a, st);
+        if (a.bits == 3) return gemm_launch_bm<3, MODE_HQQ>(a, st);
+        return gemm_launch_bm<2, MODE_HQQ>(a, st);
+    }
+    if (a.bits == 4) return gemm_launch_bm<4, MODE_FMA>(a, st);
+    if (a.bits == 3) return gemm_launch_bm<3, MODE_FMA>(a, st);
+    return gemm_launch_bm<2, MODE_FMA>(a, st);
+}
+
+}  // namespace amq

@@ -1,0 +1,60 @@
+// amq_kernels.h -- internal launcher interfaces between the .hip translation
+// units and the C-ABI layer (amq_capi.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace amq {
+
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILU_MUL = 2 };
+enum { FMT_HQQ = 0, FMT_GPTQ = 1, FMT_AWQ = 2 };
+constexpr int GEMV_MAX_SEG = 4;
+
+struct GemvSeg {
+    const void* qweight;   // native AMQ-T16 payload
+    const void* meta;      // native (scale, zero|c) half2
+    const void* bias;      // fp16 [N] or null
+    const void* residual;  // fp16 [M, y_stride] or null: y = residual + (xW^T + bias)
+    void* y;               // fp16 [M, y_stride]
+    int N;
+    int bits;              // 2 | 3 | 4
+    int mode;              // MODE_HQQ | MODE_FMA
+    int wg_begin;          // first workgroup of this segment
+    int y_stride;          // elements between output rows
+    int _pad;
+};
+
+struct GemvArgs {
+    GemvSeg seg[GEMV_MAX_SEG];
+    int nseg;
+    int M, K;
+    int x_stride;          // elements between x rows
+    const void* x;         // fp16 [M, x_stride]   (PRO_SILU_MUL: gate)
+    const void* x2;        // PRO_SILU_MUL: up
+    const void* gamma;     // PRO_RMSNORM: fp16 [K]
+    float eps;
+    int prologue;
+};
+
+size_t gemv_lds_bytes(int M, int K);
+hipError_t launch_gemv(const GemvArgs& a, int total_wg, hipStream_t st);
+
+// y[M,N] = x[M,K] . W^T for any M (MFMA, LDS-staged x tiles)
+struct GemmArgs {
+    const void* x; const void* qweight; const void* meta; const void* bias; void* y;
+    int M, N, K, bits, mode, x_stride, y_stride;
+};
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t st);
+
+// reference formats -> native
+hipError_t launch_repack(int fmt, int bits, const void* qsrc, const void* s_src, const void* z_src,
+                         int N, int K, void* q_native, void* meta_native, hipStream_t st);
+// native -> fp16 W[N,K]
+hipError_t launch_dequantize(int bits, int mode, const void* q_native, const void* meta_native,
+                             int N, int K, void* w_out, hipStream_t st);
+// HQQ Format A -> fp16 W[N,K] directly (ATEN-style standalone dequant, f-4)
+hipError_t launch_dequantize_hqq(int bits, const void* wq, const void* scale, const void* zero,
+                                 int N, int K, void* w_out, hipStream_t st);
+
+}  // namespace amq

@@ -1,0 +1,205 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point).
+
+All tensors must live on a HIP device; inputs are validated on the host before
+a kernel is launched (shape/dtype/contiguity), because an out-of-bounds access
+in a hand-written kernel can take the GPU down.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MODE_HQQ, MODE_FMA, PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL, Segment  # noqa: F401
+
+GROUP = 128
+
+
+def _need(t, dtype, name, numel=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a tensor on the GPU")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name}: expected {numel} elements, got {t.numel()}")
+
+
+def native_sizes(bits, N, K):
+    lib = _lib.load()
+    return int(lib.amq_native_qweight_bytes(bits, N, K)), int(lib.amq_native_meta_bytes(N, K, GROUP))
+
+
+def alloc_native(bits, N, K, device):
+    qb, mb = native_sizes(bits, N, K)
+    return (torch.empty(qb // 4, dtype=torch.int32, device=device),
+            torch.empty(mb // 2, dtype=torch.float16, device=device))
+
+
+def _check_shape(bits, N, K):
+    if bits not in (2, 3, 4):
+        raise ValueError(f"bits must be 2, 3 or 4 (got {bits})")
+    if N % 16 or K % 128 or N <= 0 or K <= 0:
+        raise ValueError(f"need N % 16 == 0 and K % 128 == 0 (got N={N}, K={K})")
+
+
+def repack_from_hqq(W_q, scale, zero, bits, N, K):
+    """HQQLinear.W_q + meta['scale'|'zero'] -> (qweight_native, meta_native), MODE_HQQ."""
+    _check_shape(bits, N, K)
+    lib = _lib.load()
+    R = N * K // GROUP
+    if bits == 3:
+        _need(W_q, torch.int32, "W_q", ((R + 9) // 10) * GROUP)
+    else:
+        _need(W_q, torch.uint8, "W_q", R * GROUP * bits // 8)
+    _need(scale, torch.float16, "scale", R)
+    _need(zero, torch.float16, "zero", R)
+    qn, mn = alloc_native(bits, N, K, W_q.device)
+    _lib.check(lib.amq_repack_from_hqq(bits, _lib.ptr(W_q), _lib.ptr(scale), _lib.ptr(zero), N, K, GROUP,
+                                       _lib.ptr(qn), _lib.ptr(mn), _lib.current_stream()))
+    return qn, mn
+
+
+def repack_from_gptq(qweight, scales, zeros, bits, N, K):
+    """GPTQLinear buffers -> native, MODE_FMA."""
+    _check_shape(bits, N, K)
+    lib = _lib.load()
+    _need(qweight, torch.int32, "qweight", K // 32 * bits * N)
+    _need(scales, torch.float32, "scales", K // GROUP * N)
+    _need(zeros, torch.float32, "zeros", K // GROUP * N)
+    qn, mn = alloc_native(bits, N, K, qweight.device)
+    _lib.check(lib.amq_repack_from_gptq(bits, _lib.ptr(qweight), _lib.ptr(scales), _lib.ptr(zeros), N, K, GROUP,
+                                        _lib.ptr(qn), _lib.ptr(mn), _lib.current_stream()))
+    return qn, mn
+
+
+def repack_from_awq(qweight, scales, scaled_zeros, N, K):
+    """FT_QuantLinear buffers (4 bit) -> native, MODE_FMA."""
+    _check_shape(4, N, K)
+    if N % 4 or K % 64:
+        raise ValueError("AWQ pack needs N % 4 == 0 and K % 64 == 0")
+    lib = _lib.load()
+    _need(qweight, torch.int16, "qweight", N // 4 * K)
+    _need(scales, torch.float16, "scales", K // GROUP * N)
+    _need(scaled_zeros, torch.float16, "scaled_zeros", K // GROUP * N)
+    qn, mn = alloc_native(4, N, K, qweight.device)
+    _lib.check(lib.amq_repack_from_awq(_lib.ptr(qweight), _lib.ptr(scales), _lib.ptr(scaled_zeros), N, K, GROUP,
+                                       _lib.ptr(qn), _lib.ptr(mn), _lib.current_stream()))
+    return qn, mn
+
+
+def _check_native(qn, mn, bits, N, K):
+    qb, mb = native_sizes(bits, N, K)
+    _need(qn, torch.int32, "qweight_native", qb // 4)
+    _need(mn, torch.float16, "meta_native", mb // 2)
+
+
+def dequantize(qn, mn, bits, mode, N, K):
+    _check_shape(bits, N, K)
+    _check_native(qn, mn, bits, N, K)
+    out = torch.empty(N, K, dtype=torch.float16, device=qn.device)
+    _lib.check(_lib.load().amq_dequantize_f16(bits, mode, _lib.ptr(qn), _lib.ptr(mn), N, K, GROUP,
+                                              _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+def dequantize_hqq(W_q, scale, zero, bits, N, K):
+    _check_shape(bits, N, K)
+    R = N * K // GROUP
+    if bits == 3:
+        _need(W_q, torch.int32, "W_q", ((R + 9) // 10) * GROUP)
+    else:
+        _need(W_q, torch.uint8, "W_q", R * GROUP * bits // 8)
+    _need(scale, torch.float16, "scale", R)
+    _need(zero, torch.float16, "zero", R)
+    out = torch.empty(N, K, dtype=torch.float16, device=W_q.device)
+    _lib.check(_lib.load().amq_dequantize_hqq_f16(bits, _lib.ptr(W_q), _lib.ptr(scale), _lib.ptr(zero), N, K, GROUP,
+                                                  _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+def _prep_x(x, K):
+    if x.dtype != torch.float16:
+        raise ValueError(f"x: expected float16, got {x.dtype}")
+    if x.shape[-1] != K:
+        raise ValueError(f"x: last dim {x.shape[-1]} != K={K}")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    return x2
+
+
+def gemv(x, qn, mn, bits, mode, N, K, bias=None, out=None):
+    """y = x . W^T for few rows (weight-streaming kernels)."""
+    _check_shape(bits, N, K)
+    _check_native(qn, mn, bits, N, K)
+    x2 = _prep_x(x, K)
+    M = x2.shape[0]
+    if bias is not None:
+        _need(bias, torch.float16, "bias", N)
+    y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=x.device)
+    _need(y, torch.float16, "y", M * N)
+    _lib.check(_lib.load().amq_gemv_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
+                                        _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.current_stream()))
+    return y.reshape(*x.shape[:-1], N)
+
+
+def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None):
+    """y = x . W^T for any number of rows (MFMA tiles)."""
+    _check_shape(bits, N, K)
+    _check_native(qn, mn, bits, N, K)
+    x2 = _prep_x(x, K)
+    M = x2.shape[0]
+    if bias is not None:
+        _need(bias, torch.float16, "bias", N)
+    y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=x.device)
+    _need(y, torch.float16, "y", M * N)
+    _lib.check(_lib.load().amq_gemm_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
+                                        _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.current_stream()))
+    return y.reshape(*x.shape[:-1], N)
+
+
+def linear(x, qn, mn, bits, mode, N, K, bias=None):
+    """Reference-style dispatch: few rows -> gemv family, otherwise gemm."""
+    _check_shape(bits, N, K)
+    _check_native(qn, mn, bits, N, K)
+    x2 = _prep_x(x, K)
+    M = x2.shape[0]
+    if bias is not None:
+        _need(bias, torch.float16, "bias", N)
+    y = torch.empty(M, N, dtype=torch.float16, device=x.device)
+    if M == 0:
+        return y.reshape(*x.shape[:-1], N)
+    _lib.check(_lib.load().amq_linear_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
+                                          _lib.ptr(y), M, N, K, GROUP, _lib.current_stream()))
+    return y.reshape(*x.shape[:-1], N)
+
+
+def gemv_grouped(x, segments, K, prologue=PRO_NONE, x2=None, gamma=None, eps=0.0):
+    """One launch for several linears sharing x.
+
+    segments: list of dicts {qn, mn, bits, mode, N, y, bias=None, residual=None}
+    (y / residual: fp16 [M, N] contiguous)."""
+    xx = _prep_x(x, K)
+    M = xx.shape[0]
+    if not 1 <= len(segments) <= _lib.MAX_SEGMENTS:
+        raise ValueError(f"1..{_lib.MAX_SEGMENTS} segments")
+    arr = (Segment * len(segments))()
+    for i, s in enumerate(segments):
+        _check_shape(s["bits"], s["N"], K)
+        _check_native(s["qn"], s["mn"], s["bits"], s["N"], K)
+        _need(s["y"], torch.float16, "y", M * s["N"])
+        if s.get("bias") is not None:
+            _need(s["bias"], torch.float16, "bias", s["N"])
+        if s.get("residual") is not None:
+            _need(s["residual"], torch.float16, "residual", M * s["N"])
+        arr[i] = Segment(_lib.ptr(s["qn"]), _lib.ptr(s["mn"]), _lib.ptr(s.get("bias")), _lib.ptr(s.get("residual")),
+                         _lib.ptr(s["y"]), s["N"], s["bits"], s["mode"], 0)
+    if prologue == PRO_RMSNORM:
+        _need(gamma, torch.float16, "gamma", K)
+    if prologue == PRO_SILU_MUL:
+        x2 = _prep_x(x2, K)
+        if x2.shape[0] != M:
+            raise ValueError("x2 rows != x rows")
+    _lib.check(_lib.load().amq_gemv_grouped_f16(arr, len(segments), _lib.ptr(xx), _lib.ptr(x2), _lib.ptr(gamma),
+                                                ctypes.c_float(eps), prologue, M, K, GROUP, 0, _lib.current_stream()))

@@ -1,0 +1,126 @@
+/* amq_hip.h -- C ABI of libamq_hip.so: the MI355X (gfx950) replacement for the
+ * native kernels on AMQ's mixed-precision inference hot path.
+ *
+ * What it replaces (reference paths relative to the dlwns147/amq checkout):
+ *   pybind module `auto_gptq`          amq/kernel/AutoGPTQ/auto_gptq_kernel.cu:471-475
+ *       vecquant{2,3,4}matmul_faster_old(vec, mat, mul, scales, zeros, groupsize, vec_height)
+ *   pybind module `faster_transformer` amq/kernel/ft/FT.cpp:9-19
+ *       gemv_4bit(x, kernel, scales, scaled_zeros, m, n, k, group_size)   gemv_cuda.cu:358-525
+ *       gemm_4bit(x, kernel, scales, scaled_zeros)                        gemm_cuda.cu:929-1033
+ *   host packers  GPTQLinear.pack (hqq/backends/autogptq.py:111-156),
+ *                 pack_intweight  (hqq/backends/ft.py:15-55)
+ *   dequantize    Quantizer.dequantize (hqq/core/quantize.py:184-199)
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t
+ *     passed as void* (NULL = default stream).  All work is stream-ordered and
+ *     asynchronous; nothing allocates, synchronises or touches global state,
+ *     so every call may be captured into a hipGraph.
+ *   - every pointer is a DEVICE pointer owned by the caller unless noted.
+ *   - return value: AMQ_OK (0) or a negative AMQ_E* code; amq_last_error()
+ *     returns a thread-local message for the most recent failure.
+ *   - fp16 activations / outputs, fp32 accumulation; weights 2, 3 or 4 bit,
+ *     group size 128 along K (the only configuration AMQ produces:
+ *     amq/amq_quantization_proxy.py:22,36), N % 16 == 0, K % 128 == 0.
+ *   - "native" buffers are in the AMQ-T16 layout (amq_common.cuh);
+ *     sizes from amq_native_*_bytes(); produced by the amq_repack_from_* calls.
+ */
+#ifndef AMQ_HIP_H
+#define AMQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMQ_VERSION 100            /* 0.1.0 */
+
+#define AMQ_OK            0
+#define AMQ_EINVAL       -1        /* bad argument (null pointer, bits, mode ...) */
+#define AMQ_ESHAPE       -2        /* unsupported shape (N % 16, K % 128, group != 128, M out of range) */
+#define AMQ_ELAUNCH      -3        /* HIP launch failed (message carries hipGetErrorString) */
+#define AMQ_EUNSUPPORTED -4        /* valid request this build does not implement */
+
+/* dequantisation arithmetic carried by a native buffer's meta */
+#define AMQ_MODE_HQQ 0             /* meta = (scale, zero):  w = fp16(fp16(q - zero) * scale)   quantize.py:198 */
+#define AMQ_MODE_FMA 1             /* meta = (scale, c):     w = fp16(fma(q, scale, c))          auto_gptq_kernel.cu:206, gemv_cuda.cu:151 */
+
+/* fused x transforms of amq_gemv_grouped_f16 */
+#define AMQ_PRO_NONE     0
+#define AMQ_PRO_RMSNORM  1         /* x <- gamma * fp16(x * rsqrt(mean(x^2) + eps))   (LlamaRMSNorm; FT generalT5LayerNorm, layernorm.cu:25-51) */
+#define AMQ_PRO_SILU_MUL 2         /* x <- fp16(silu(x)) * x2                           (LlamaMLP act_fn(gate) * up) */
+
+#define AMQ_MAX_SEGMENTS 4
+
+int amq_version(void);
+const char* amq_last_error(void);
+
+/* capabilities: writes up to `cap` ints {max_gemv_rows_for_K, lds_bytes, ...}; returns the count */
+int amq_query(int K, int* out, int cap);
+
+/* ---- native buffer sizes ------------------------------------------------ */
+size_t amq_native_qweight_bytes(int bits, int N, int K);
+size_t amq_native_meta_bytes(int N, int K, int group);
+
+/* ---- load-time repack: reference formats -> native ---------------------- */
+/* Format A: HQQLinear.W_q (uint8 for 4/2 bit, int32 for 3 bit) + meta['scale'], meta['zero'] fp16 [N*K/group]
+ * (hqq/core/bitpack.py:24-110, quantize.py:106-111).  Result carries AMQ_MODE_HQQ. */
+int amq_repack_from_hqq(int bits, const void* W_q, const void* scale, const void* zero,
+                        int N, int K, int group, void* qweight_native, void* meta_native, void* stream);
+/* Format B: GPTQLinear buffers qweight int32 [K/32*bits, N], scales fp32 [K/group, N], zeros fp32 [K/group, N]
+ * (hqq/backends/autogptq.py:55-75).  Result carries AMQ_MODE_FMA (c = -zeros). */
+int amq_repack_from_gptq(int bits, const void* qweight, const void* scales, const void* zeros,
+                         int N, int K, int group, void* qweight_native, void* meta_native, void* stream);
+/* Format C: FT_QuantLinear buffers qweight int16 [N/4, K], scales fp16 [K/group, N], scaled_zeros fp16
+ * (hqq/backends/ft.py:57-126), 4 bit only.  Result carries AMQ_MODE_FMA (c = scaled_zeros). */
+int amq_repack_from_awq(const void* qweight, const void* scales, const void* scaled_zeros,
+                        int N, int K, int group, void* qweight_native, void* meta_native, void* stream);
+
+/* ---- dequantize ---------------------------------------------------------- */
+/* native -> W[N,K] fp16 (row-major, nn.Linear orientation) */
+int amq_dequantize_f16(int bits, int mode, const void* qweight_native, const void* meta_native,
+                       int N, int K, int group, void* W_out, void* stream);
+/* Format A -> W[N,K] fp16: Quantizer.dequantize (quantize.py:184-199) as one kernel */
+int amq_dequantize_hqq_f16(int bits, const void* W_q, const void* scale, const void* zero,
+                           int N, int K, int group, void* W_out, void* stream);
+
+/* ---- the hot path: y[M,N] = x[M,K] . W^T (+ bias) ------------------------ */
+/* few rows (decode).  M == 1: dot-product + wavefront reduction; 2 <= M: register-operand MFMA.
+ * M is limited by LDS (M * (K + 8) * 2 + 32 KiB <= 160 KiB), AMQ_ESHAPE beyond -- use amq_gemm_f16.
+ * x_stride / y_stride in elements (0 = dense). */
+int amq_gemv_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
+                 const void* bias, void* y, int M, int N, int K, int group,
+                 int x_stride, int y_stride, void* stream);
+/* any M (prefill / batched): LDS-staged x tiles, MFMA 16x16x32 f16 */
+int amq_gemm_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
+                 const void* bias, void* y, int M, int N, int K, int group,
+                 int x_stride, int y_stride, void* stream);
+/* dispatch the way the reference modules do (rows < threshold -> gemv, else gemm;
+ * GPTQLinear.forward autogptq.py:163, FT_QuantLinear.forward_normal ft.py:128-145) */
+int amq_linear_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
+                   const void* bias, void* y, int M, int N, int K, int group, void* stream);
+
+/* several linears that consume the same x (q/k/v, gate/up), each with its own bit-width,
+ * in ONE launch; optional fused prologue on x and residual add on y. */
+typedef struct amq_segment {
+    const void* qweight_native;
+    const void* meta_native;
+    const void* bias;       /* fp16 [N] or NULL */
+    const void* residual;   /* fp16 [M, y_stride] or NULL: y = residual + (x W^T + bias) */
+    void* y;                /* fp16 [M, y_stride] */
+    int N;
+    int bits;
+    int mode;
+    int y_stride;           /* 0 = N */
+} amq_segment;
+
+int amq_gemv_grouped_f16(const amq_segment* segments /* host */, int nseg,
+                         const void* x, const void* x2, const void* gamma, float eps, int prologue,
+                         int M, int K, int group, int x_stride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMQ_HIP_H */

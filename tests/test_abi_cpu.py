@@ -1,0 +1,57 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/amq_hip.h
+declares; argument validation works without a GPU (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from amq_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "amq_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(amq_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in amq_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes SIGNATURES out of sync with amq_hip.h"
+
+
+def test_version_sizes_and_validation():
+    lib = _lib.load()
+    assert lib.amq_version() == 100
+    # native sizes: N*K*bits/8 payload, 4 B of (scale, zero) per (row, group)
+    for bits in (2, 3, 4):
+        assert lib.amq_native_qweight_bytes(bits, 4096, 4096) == 4096 * 4096 * bits // 8
+    assert lib.amq_native_meta_bytes(4096, 4096, 128) == 4096 * 4096 // 128 * 4
+    # validation happens before any HIP call
+    one = ctypes.c_void_p(16)
+    rc = lib.amq_gemv_f16(5, 0, one, one, one, None, one, 1, 4096, 4096, 128, 0, 0, None)
+    assert rc == -1 and b"bits" in lib.amq_last_error()
+    rc = lib.amq_gemv_f16(4, 0, one, one, one, None, one, 1, 4096, 4100, 128, 0, 0, None)
+    assert rc == -2
+    rc = lib.amq_gemv_f16(4, 0, one, one, one, None, one, 1, 4096, 4096, 64, 0, 0, None)
+    assert rc == -2 and b"group" in lib.amq_last_error()
+    rc = lib.amq_gemv_f16(4, 0, one, one, one, None, one, 40, 4096, 4096, 128, 0, 0, None)
+    assert rc == -2 and b"amq_gemm_f16" in lib.amq_last_error()
+    rc = lib.amq_gemm_f16(4, 7, one, one, one, None, one, 40, 4096, 4096, 128, 0, 0, None)
+    assert rc == -1
+    out = (ctypes.c_int * 4)()
+    assert lib.amq_query(4096, out, 4) == 4 and out[0] >= 8 and out[2] == 16 and out[3] == 128
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.AmqError, match="no CPU fallback"):
+        _lib.load()

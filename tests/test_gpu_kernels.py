@@ -1,0 +1,240 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle.
+
+Bar: bit-exact for integer work and for the dequantized fp16 weights;
+matmul outputs within 1e-3 relative (fp16) of the reference CPU path
+nn.Linear-on-dequantized-weights (BASELINE.json north_star)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hqq_ref, gptq_ref, awq_ref, linear_ref
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(glob.glob(os.path.join(GOLDEN, "hqq_b*.npz")))
+RTOL = 1e-3
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _load(path):
+    d = np.load(path)
+    return {k: d[k] for k in d.files}
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+
+
+def _assert_close(y, y_ref, what=""):
+    """|y - ref| <= 1e-3*|ref| + 1e-3*rms(ref): fp16-relative with a floor for
+    outputs that cancel to ~0 (one fp16 ulp of a typical output)."""
+    y = np.asarray(y, np.float32)
+    y_ref = np.asarray(y_ref, np.float32)
+    floor = RTOL * float(np.sqrt(np.mean(y_ref.astype(np.float64) ** 2)))
+    err = np.abs(y - y_ref)
+    bad = err > RTOL * np.abs(y_ref) + floor
+    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} out of tolerance, max err {err.max()}"
+
+
+def _native_from_golden(g):
+    from amq_amd import ops
+    bits, (n, k) = int(g["nbits"]), tuple(int(v) for v in g["shape"])
+    qn, mn = ops.repack_from_hqq(_t(g["W_q"]), _t(g["scale"].reshape(-1)), _t(g["zero"].reshape(-1)), bits, n, k)
+    return bits, n, k, qn, mn
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c) for c in CASES])
+def test_repack_dequant_bit_exact_golden(path):
+    """native repack + in-register unpack + (q - z) * s reproduces the
+    reference's HQQLinear.dequantize() bit for bit."""
+    from amq_amd import ops
+    g = _load(path)
+    bits, n, k, qn, mn = _native_from_golden(g)
+    w = ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy()
+    assert np.array_equal(w.view(np.uint16), g["W_deq"].view(np.uint16))
+    w2 = ops.dequantize_hqq(_t(g["W_q"]), _t(g["scale"].reshape(-1)), _t(g["zero"].reshape(-1)), bits, n, k).cpu().numpy()
+    assert np.array_equal(w2.view(np.uint16), g["W_deq"].view(np.uint16))
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c) for c in CASES])
+def test_forward_matches_reference_golden(path):
+    """y for the reference's own captured x (3 rows) and for 1 row, vs the
+    captured torch CPU result."""
+    from amq_amd import ops
+    g = _load(path)
+    bits, n, k, qn, mn = _native_from_golden(g)
+    bias = _t(g["bias"]) if "bias" in g else None
+    y3 = ops.gemv(_t(g["x"]), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias).cpu().numpy()
+    _assert_close(y3, g["y_ref"], "gemv M=3")
+    y1 = ops.gemv(_t(g["x"][:1]), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias).cpu().numpy()
+    _assert_close(y1, g["y_ref"][:1], "gemv M=1")
+    ym = ops.gemm(_t(g["x"]), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias).cpu().numpy()
+    _assert_close(ym, g["y_ref"], "gemm M=3")
+    # M=128 rows: the GPTQLinear fallback capture uses the same integers; compare to the oracle on W_deq
+    xg = g["gptq_x"]
+    yg = ops.gemm(_t(xg), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias).cpu().numpy()
+    _assert_close(yg, linear_ref.linear_f16(xg, g["W_deq"], g.get("bias")), "gemm M=128")
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c) for c in CASES])
+def test_gptq_and_awq_import_golden(path):
+    """Format B / C buffers captured from the reference -> native (MODE_FMA):
+    integers identical, weights equal the reference kernels' fma dequant."""
+    from amq_amd import ops
+    g = _load(path)
+    bits, (n, k) = int(g["nbits"]), tuple(int(v) for v in g["shape"])
+    qn, mn = ops.repack_from_gptq(_t(g["gptq_qweight"]), _t(g["gptq_scales"]), _t(g["gptq_zeros"]), bits, n, k)
+    w = ops.dequantize(qn, mn, bits, ops.MODE_FMA, n, k).cpu().numpy()
+    w_ref = gptq_ref.dequant_kernel(g["gptq_qweight"], g["gptq_scales"], g["gptq_zeros"], bits)
+    assert np.array_equal(w.view(np.uint16), w_ref.view(np.uint16))
+    # same payload as the HQQ import (the packed integers are the same integers)
+    _, _, _, qn_h, _ = _native_from_golden(g)
+    assert torch.equal(qn, qn_h)
+    y = ops.gemm(_t(g["gptq_x"]), qn, mn, bits, ops.MODE_FMA, n, k).cpu().numpy()
+    _assert_close(y, g["gptq_y"], "gptq-format forward vs GPTQLinear.forward capture")
+    if bits == 4:
+        qa, ma = ops.repack_from_awq(_t(g["awq_qweight"]), _t(g["awq_scales"]), _t(g["awq_scaled_zeros"]), n, k)
+        assert torch.equal(qa, qn_h)
+        wa = ops.dequantize(qa, ma, 4, ops.MODE_FMA, n, k).cpu().numpy()
+        wa_ref = awq_ref.dequant_kernel(g["awq_qweight"], g["awq_scales"], g["awq_scaled_zeros"])
+        assert np.array_equal(wa.view(np.uint16), wa_ref.view(np.uint16))
+
+
+def _random_case(bits, n, k, seed, bias=False):
+    from amq_amd.hqq_format import random_hqq
+    from amq_amd import ops
+    h = random_hqq(n, k, bits, seed=seed, bias=bias)
+    hd = h.to(_dev())
+    qn, mn = ops.repack_from_hqq(hd.W_q, hd.scale.reshape(-1), hd.zero.reshape(-1), bits, n, k)
+    w_ref = hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (n, k))
+    return h, qn, mn, w_ref
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k", [(16, 128), (48, 384), (256, 1024), (1024, 4096), (4096, 11008)])
+def test_random_dequant_bit_exact(bits, n, k):
+    from amq_amd import ops
+    h, qn, mn, w_ref = _random_case(bits, n, k, seed=100 + bits)
+    w = ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy()
+    assert np.array_equal(w.view(np.uint16), w_ref.view(np.uint16))
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_integer_roundtrip_all_codes(bits):
+    """scale = 1, zero = 0 makes dequantize return the integers themselves:
+    checks every code value through repack + unpack, bit-exact."""
+    from amq_amd import ops
+    from amq_amd.hqq_format import HQQWeights, pack_rows
+    n, k = 64, 512
+    r = n * k // 128
+    q = (torch.arange(r * 128, dtype=torch.int64) * 2654435761 % (2 ** bits)).reshape(r, 128).to(torch.int32)
+    h = HQQWeights(pack_rows(q, bits), torch.ones(r, 1, dtype=torch.float16), torch.zeros(r, 1, dtype=torch.float16), bits, (n, k)).to(_dev())
+    qn, mn = ops.repack_from_hqq(h.W_q, h.scale.reshape(-1), h.zero.reshape(-1), bits, n, k)
+    w = ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).cpu()
+    assert torch.equal(w.to(torch.int32), q.reshape(n, k))
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k,m", [(16, 128, 1), (256, 1024, 1), (4096, 4096, 1), (1024, 8192, 1), (4096, 11008, 1),
+                                    (11008, 4096, 1), (256, 1024, 2), (4096, 4096, 4), (4096, 4096, 7), (512, 2048, 8)])
+def test_gemv_random(bits, n, k, m):
+    from amq_amd import ops
+    h, qn, mn, w_ref = _random_case(bits, n, k, seed=7 * bits + m, bias=(m == 4))
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(n + k + m)).to(torch.float16)
+    bias = None if h.bias is None else h.bias.to(_dev())
+    y = ops.gemv(x.to(_dev()), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias).cpu().numpy()
+    y_ref = linear_ref.linear_f16(x.numpy(), w_ref, None if h.bias is None else h.bias.numpy())
+    _assert_close(y, y_ref, f"gemv {bits}b {n}x{k} M={m}")
+    # and against an fp64-accumulated product of the same fp16 weights: the
+    # kernel's own error (fp32 accumulate + one fp16 rounding) stays at fp16 rounding level
+    if h.bias is None:
+        y64 = linear_ref.matmul_f64(x.numpy(), w_ref.T)
+        scale = np.sqrt(np.mean(y64 ** 2))
+        assert np.max(np.abs(y.astype(np.float64) - y64) - 2.0 ** -10 * np.abs(y64)) <= 2e-3 * scale * 2.0 ** -3
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k,m", [(128, 256, 9), (256, 1024, 64), (384, 512, 65), (1024, 4096, 128), (1024, 4096, 300), (176, 384, 130)])
+def test_gemm_random(bits, n, k, m):
+    from amq_amd import ops
+    h, qn, mn, w_ref = _random_case(bits, n, k, seed=31 * bits + m, bias=(m == 64))
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(n + k + m)).to(torch.float16)
+    bias = None if h.bias is None else h.bias.to(_dev())
+    y = ops.gemm(x.to(_dev()), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias).cpu().numpy()
+    y_ref = linear_ref.linear_f16(x.numpy(), w_ref, None if h.bias is None else h.bias.numpy())
+    _assert_close(y, y_ref, f"gemm {bits}b {n}x{k} M={m}")
+    # reference-style dispatch goes through the same kernels
+    y2 = ops.linear(x.to(_dev()).reshape(1, m, k), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias)
+    assert y2.shape == (1, m, n)
+    assert np.array_equal(y2.reshape(m, n).cpu().numpy().view(np.uint16), y.view(np.uint16))
+
+
+def test_gemv_is_deterministic():
+    from amq_amd import ops
+    h, qn, mn, _ = _random_case(3, 4096, 4096, seed=5)
+    x = torch.randn(1, 4096).to(torch.float16).to(_dev())
+    y0 = ops.gemv(x, qn, mn, 3, ops.MODE_HQQ, 4096, 4096)
+    for _ in range(5):
+        assert torch.equal(ops.gemv(x, qn, mn, 3, ops.MODE_HQQ, 4096, 4096), y0)
+
+
+def _rmsnorm_ref(x, gamma, eps):
+    xf = x.float()
+    h = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(torch.float16)
+    return gamma * h
+
+
+@pytest.mark.parametrize("m", [1, 3])
+def test_grouped_mixed_bits_with_prologues(m):
+    """q/k/v-style launch: three segments of different bit-widths sharing a
+    RMSNorm'ed x; then a SiLU*mul prologue with residual epilogue."""
+    from amq_amd import ops
+    k = 1024
+    specs = [(4, 512), (2, 256), (3, 384)]
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(m, k, generator=gen).to(torch.float16)
+    gamma = (1.0 + 0.1 * torch.randn(k, generator=gen)).to(torch.float16)
+    eps = 1e-5
+    xn = _rmsnorm_ref(x, gamma, eps)
+    segs, refs = [], []
+    for i, (bits, n) in enumerate(specs):
+        h, qn, mn, w_ref = _random_case(bits, n, k, seed=50 + i)
+        y = torch.empty(m, n, dtype=torch.float16, device=_dev())
+        segs.append(dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_HQQ, N=n, y=y))
+        refs.append(linear_ref.linear_f16(xn.numpy(), w_ref))
+    ops.gemv_grouped(x.to(_dev()), segs, k, prologue=ops.PRO_RMSNORM, gamma=gamma.to(_dev()), eps=eps)
+    for s, r in zip(segs, refs):
+        _assert_close(s["y"].cpu().numpy(), r, "grouped rmsnorm")
+    # down_proj-style: x = silu(gate) * up ; y = residual + x W^T
+    gate = torch.randn(m, k, generator=gen).to(torch.float16)
+    up = torch.randn(m, k, generator=gen).to(torch.float16)
+    act = torch.nn.functional.silu(gate.float()).to(torch.float16) * up
+    h, qn, mn, w_ref = _random_case(3, 256, k, seed=77)
+    res = torch.randn(m, 256, generator=gen).to(torch.float16)
+    y = torch.empty(m, 256, dtype=torch.float16, device=_dev())
+    ops.gemv_grouped(gate.to(_dev()), [dict(qn=qn, mn=mn, bits=3, mode=ops.MODE_HQQ, N=256, y=y, residual=res.to(_dev()))],
+                     k, prologue=ops.PRO_SILU_MUL, x2=up.to(_dev()))
+    ref = (res.numpy() + linear_ref.linear_f16(act.numpy(), w_ref)).astype(np.float16)
+    _assert_close(y.cpu().numpy(), ref, "silu*mul + residual")
+
+
+def test_error_paths_raise():
+    from amq_amd import ops, _lib
+    h, qn, mn, _ = _random_case(4, 64, 256, seed=1)
+    x = torch.randn(1, 256).to(torch.float16).to(_dev())
+    with pytest.raises(ValueError):
+        ops.gemv(x.float(), qn, mn, 4, ops.MODE_HQQ, 64, 256)          # wrong dtype
+    with pytest.raises(ValueError):
+        ops.gemv(x, qn[:-1], mn, 4, ops.MODE_HQQ, 64, 256)             # short buffer
+    with pytest.raises(ValueError):
+        ops.gemv(x, qn, mn, 5, ops.MODE_HQQ, 64, 256)                  # bits
+    with pytest.raises(_lib.AmqError):
+        ops.gemv(torch.randn(60, 256).half().to(_dev()), qn, mn, 4, 9, 64, 256)   # bad mode reaches the C ABI

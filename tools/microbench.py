@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-layer microbenchmark of the weight-streaming kernels (GPU only).
+
+Rotates over enough distinct weight buffers (>= 512 MiB) that neither L2 nor
+the 256 MiB Infinity Cache can serve the stream; times with HIP events on the
+launch stream.  Prints one JSON line per case: achieved algorithmic GB/s
+(BASELINE.md section 3 byte count) and us per call."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from amq_amd import ops  # noqa: E402
+from amq_amd.hqq_format import random_hqq  # noqa: E402
+
+
+def layer_bytes(n, k, bits, m=1):
+    return n * k * bits // 8 + 4 * n * k // 128 + 2 * m * k + 2 * m * n
+
+
+def bench_case(n, k, bits, m, iters, fn_name="gemv"):
+    dev = torch.device("cuda:0")
+    h = random_hqq(n, k, bits, seed=1).to(dev)
+    qn0, mn0 = ops.repack_from_hqq(h.W_q, h.scale.reshape(-1), h.zero.reshape(-1), bits, n, k)
+    per = qn0.numel() * 4 + mn0.numel() * 2
+    copies = max(2, min(64, (768 << 20) // per + 1))
+    bufs = [(qn0.clone(), mn0.clone()) for _ in range(copies)]
+    x = torch.randn(m, k, device=dev).half()
+    y = torch.empty(m, n, device=dev, dtype=torch.float16)
+    fn = getattr(ops, fn_name)
+    for i in range(copies):
+        fn(x, bufs[i][0], bufs[i][1], bits, ops.MODE_HQQ, n, k, out=y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        q, mt = bufs[i % copies]
+        fn(x, q, mt, bits, ops.MODE_HQQ, n, k, out=y)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    b = layer_bytes(n, k, bits, m)
+    return {"kernel": fn_name, "N": n, "K": k, "bits": bits, "M": m, "us": round(us, 3),
+            "GBps": round(b / us / 1e3, 1), "bytes": b, "copies": copies}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=400)
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    shapes = [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096)]
+    if args.quick:
+        shapes = shapes[:2]
+    for n, k in shapes:
+        for bits in (4, 3, 2):
+            print(json.dumps(bench_case(n, k, bits, 1, args.iters)), flush=True)
+    for m in (2, 4, 8):
+        print(json.dumps(bench_case(4096, 4096, 4, m, args.iters)), flush=True)
+    for m in (64, 512, 4096):
+        for bits in (4, 3, 2):
+            r = bench_case(5120, 5120, bits, m, max(20, args.iters // 10), "gemm")
+            r["TFLOPs"] = round(2.0 * m * 5120 * 5120 / r["us"] / 1e6, 1)
+            print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
