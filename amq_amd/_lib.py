@@ -8,12 +8,15 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libamq_hip.so")
+# AMQ_LIB_TAG selects an A/B build variant (libamq_hip_<tag>.so, `make variant`); default: the product build
+_TAG = os.environ.get("AMQ_LIB_TAG", "")
+LIB_PATH = os.path.join(_HERE, f"libamq_hip_{_TAG}.so" if _TAG else "libamq_hip.so")
 
 AMQ_OK = 0
 MODE_HQQ, MODE_FMA = 0, 1
 PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
+OPT_GEMV_DOT, OPT_GEMV_WAVES = 1, 2
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
@@ -28,6 +31,7 @@ class Segment(ctypes.Structure):
 SIGNATURES = {
     "amq_version": (_i, []),
     "amq_last_error": (ctypes.c_char_p, []),
+    "amq_set_option": (_i, [_i, _i]),
     "amq_query": (_i, [_i, ctypes.POINTER(_i), _i]),
     "amq_native_qweight_bytes": (_sz, [_i, _i, _i]),
     "amq_native_meta_bytes": (_sz, [_i, _i, _i]),
@@ -59,6 +63,10 @@ def load():
             f"{LIB_PATH} not found: the HIP extension is not built. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C amq_amd/csrc`). "
             "There is no CPU fallback.")
+    # torch bundles its own libamdhip64.so.7; load it FIRST so that this
+    # library binds to the same HIP runtime instance (two runtimes in one
+    # process do not share a device context -> "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

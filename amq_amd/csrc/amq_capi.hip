@@ -38,6 +38,8 @@ int check_mode(int mode) {
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
+int g_opt_dot = 0;
+int g_opt_waves = 0;
 
 }  // namespace
 
@@ -46,10 +48,20 @@ extern "C" {
 int amq_version(void) { return AMQ_VERSION; }
 const char* amq_last_error(void) { return g_err; }
 
+int amq_set_option(int option, int value) {
+    if (option == AMQ_OPT_GEMV_DOT) { g_opt_dot = value ? 1 : 0; return AMQ_OK; }
+    if (option == AMQ_OPT_GEMV_WAVES) {
+        if (value != 0 && value != 4 && value != 8 && value != 16) return fail(AMQ_EINVAL, "waves must be 0, 4, 8 or 16");
+        g_opt_waves = value;
+        return AMQ_OK;
+    }
+    return fail(AMQ_EINVAL, "unknown option %d", option);
+}
+
 int amq_query(int K, int* out, int cap) {
     int vals[4];
     int maxm = 0;
-    for (int m = 1; m <= 64; ++m)
+    for (int m = 1; m <= amq::GEMV_MAX_M; ++m)
         if (amq::gemv_lds_bytes(m, K) <= LDS_LIMIT) maxm = m;
     vals[0] = maxm;                 // largest M amq_gemv_f16 accepts for this K
     vals[1] = (int)LDS_LIMIT;
@@ -106,7 +118,7 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     if (prologue == AMQ_PRO_RMSNORM && !gamma) return fail(AMQ_EINVAL, "RMSNorm prologue needs gamma");
     if (prologue == AMQ_PRO_SILU_MUL && !x2) return fail(AMQ_EINVAL, "SiLU*mul prologue needs x2");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
-    if (amq::gemv_lds_bytes(M, K) > LDS_LIMIT)
+    if (M > amq::GEMV_MAX_M || amq::gemv_lds_bytes(M, K) > LDS_LIMIT)
         return fail(AMQ_ESHAPE, "M=%d rows of K=%d do not fit LDS for the GEMV path; use amq_gemm_f16", M, K);
     amq::GemvArgs a{};
     int wg = 0;
@@ -123,6 +135,8 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     }
     a.nseg = nseg; a.M = M; a.K = K; a.x_stride = x_stride ? x_stride : K;
     a.x = x; a.x2 = x2; a.gamma = gamma; a.eps = eps; a.prologue = prologue;
+    a.flags = g_opt_dot ? amq::GEMV_FLAG_DOT : 0;
+    a.force_waves = g_opt_waves;
     return check_hip(amq::launch_gemv(a, wg, (hipStream_t)stream), "gemv");
 }
 
@@ -147,7 +161,7 @@ int amq_gemm_f16(int bits, int mode, const void* x, const void* qn, const void* 
 int amq_linear_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
                    int M, int N, int K, int group, void* stream) {
     // few rows: weight-streaming GEMV family; otherwise the tiled MFMA GEMM
-    if (M <= 8 && amq::gemv_lds_bytes(M, K) <= LDS_LIMIT)
+    if (M <= 8 && amq::gemv_lds_bytes(M, K) <= 64 * 1024)
         return amq_gemv_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
     return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
 }

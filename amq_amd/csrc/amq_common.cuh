@@ -127,6 +127,108 @@ __device__ __forceinline__ void dequant_lane(const uint32_t* w, h2 meta, h2* out
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fast-path unpack ("scaled-subnormal" form) used inside the matmul kernels.
+//
+// Measured on gfx950 (tools/ubench/valu_rate.hip): every VOP3/VOP3P op
+// (v_pk_*_f16, v_and_or_b32, v_perm_b32, v_dot2*) issues at 4 cycles per wave,
+// plain VOP2 (v_and_b32, v_lshrrev_b32) at 2.  The magic-number unpack above
+// costs and+or+sub+sub+mul = 18 cycles / pair; at 2-4 bits per weight that is
+// MORE VALU time than the HBM time of the weights.  This form needs
+// shift+and+fma+mul = 12:
+//
+//   t = u << / >> c       bring the pair's field to the TOP of the fp16
+//                         mantissa (bit SH of each half)
+//   (t & mask)            exponent bits are zero, so the half IS the
+//                         subnormal  q * 2^(SH-24)
+//   d = fma(sub, 2^B, -z * 2^E)   =  RN16((q - z) * 2^E),   E = SH + B - 24
+//   w = d * (s * 2^-E)            =  RN16(RN16(q - z) * s)
+//
+// Scaling by a power of two commutes with fp16 rounding, so w is bit-identical
+// to the reference's two-rounding dequant (quantize.py:198) as long as
+// z * 2^E and (q - z) * 2^E are normal fp16 numbers: E = -3 / -2 / -5 for
+// 4 / 3 / 2 bit, i.e. for |z|, |q - z| >= 2^-11 / 2^-12 / 2^-9; below that the
+// value involved is < 1e-3 of a quantization step and may differ by
+// <= 2^-24 * 2^-E (tests bound it).  Requires |s| * 2^-E < 65504.
+// MODE_FMA: w = fma(sub * 2^B, s * 2^-E, c)   (q * 2^E is exact).
+template <int BITS> struct SdCfg;
+template <> struct SdCfg<4> { static constexpr int E = -3; };
+template <> struct SdCfg<3> { static constexpr int E = -2; };
+template <> struct SdCfg<2> { static constexpr int E = -5; };
+
+struct SdMeta { h2 zc, sc; };
+
+template <int BITS, int MODE>
+__device__ __forceinline__ SdMeta sd_meta(h2 meta) {
+    constexpr int E = SdCfg<BITS>::E;
+    SdMeta m;
+    m.sc = bcast(meta.x) * bcast((_Float16)(float)(1 << (-E)));
+    if (MODE == MODE_HQQ) m.zc = bcast(meta.y) * bcast((_Float16)(-1.0f / (float)(1 << (-E))));
+    else m.zc = bcast(meta.y);
+    return m;
+}
+
+// t: word already shifted so that the pair's field starts at bit SH of each half
+template <int BITS, int MODE, int SH>
+__device__ __forceinline__ h2 sd_pair(uint32_t t, const SdMeta& m) {
+    constexpr uint32_t fm = (1u << BITS) - 1u;
+    constexpr uint32_t msk = (fm << SH) | ((fm << SH) << 16);
+    constexpr int B = SdCfg<BITS>::E + 24 - SH;                  // multiplier exponent, <= 15
+    static_assert(B <= 15 && B >= 0 && SH + BITS <= 10, "field must sit in the mantissa");
+    const h2 sub = as_h2(t & msk);                               // q * 2^(SH-24), exact subnormal
+    const _Float16 mul = (_Float16)(float)(1 << B);
+    if (MODE == MODE_HQQ) {
+        h2 d = __builtin_elementwise_fma(sub, bcast(mul), m.zc); // RN16((q - z) * 2^E)
+        return d * m.sc;
+    } else {
+        h2 qs = sub * bcast(mul);                                // q * 2^E, exact
+        return __builtin_elementwise_fma(qs, m.sc, m.zc);
+    }
+}
+
+template <int BITS, int MODE>
+__device__ __forceinline__ void dequant_lane_sd(const uint32_t* w, h2 meta, h2* out) {
+    const SdMeta m = sd_meta<BITS, MODE>(meta);
+    if (BITS == 4) {            // fields at bits 0,4,8,12 of each half -> bits 6..9
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t u = w[t];
+            out[4 * t + 0] = sd_pair<4, MODE, 6>(u << 6, m);
+            out[4 * t + 1] = sd_pair<4, MODE, 6>(u << 2, m);
+            out[4 * t + 2] = sd_pair<4, MODE, 6>(u >> 2, m);
+            out[4 * t + 3] = sd_pair<4, MODE, 6>(u >> 6, m);
+        }
+    } else if (BITS == 2) {     // fields at bits 2i: three shifted copies put all of them at 4, 6 or 8
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const uint32_t u = w[d];
+            const uint32_t a = u << 4, b = u >> 2, c = u >> 8;
+            out[8 * d + 0] = sd_pair<2, MODE, 4>(a, m);
+            out[8 * d + 1] = sd_pair<2, MODE, 6>(a, m);
+            out[8 * d + 2] = sd_pair<2, MODE, 8>(a, m);
+            out[8 * d + 3] = sd_pair<2, MODE, 4>(b, m);
+            out[8 * d + 4] = sd_pair<2, MODE, 6>(b, m);
+            out[8 * d + 5] = sd_pair<2, MODE, 8>(b, m);
+            out[8 * d + 6] = sd_pair<2, MODE, 4>(c, m);
+            out[8 * d + 7] = sd_pair<2, MODE, 6>(c, m);
+        }
+    } else {                    // fields at bits 3i -> bits 7..9
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t u = w[d];
+            out[5 * d + 0] = sd_pair<3, MODE, 7>(u << 7, m);
+            out[5 * d + 1] = sd_pair<3, MODE, 7>(u << 4, m);
+            out[5 * d + 2] = sd_pair<3, MODE, 7>(u << 1, m);
+            out[5 * d + 3] = sd_pair<3, MODE, 7>(u >> 2, m);
+            out[5 * d + 4] = sd_pair<3, MODE, 7>(u >> 5, m);
+        }
+        // pair 15: value bit b of the (low, high) weight = bit (15, 31) of dword b -> bits 7+b
+        const uint32_t e = ((w[0] >> 8) & 0x00800080u) | ((w[1] >> 7) & 0x01000100u) |
+                           ((w[2] >> 6) & 0x02000200u);
+        out[15] = sd_pair<3, MODE, 7>(e, m);
+    }
+}
+
 // Integer-only view of the same map (used by the repack / reference-format
 // kernels): where does weight (t, j) of a lane live?
 __host__ __device__ __forceinline__ void native_slot(int bits, int t, int j, int* dword, int* shift) {
@@ -149,20 +251,29 @@ __host__ __device__ __forceinline__ size_t native_meta_bytes(int N, int K) {
 template <int BITS>
 struct LanePayload { uint32_t w[BITS]; };
 
+#ifndef AMQ_NT
+#define AMQ_NT 1
+#endif
+#if AMQ_NT
+#define AMQ_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define AMQ_STREAM_LOAD(p) (*(p))
+#endif
+
 template <int BITS>
 __device__ __forceinline__ LanePayload<BITS> load_payload(const uint32_t* tile_base, int lane) {
     LanePayload<BITS> r;
     if (BITS == 4) {
-        u4 v = __builtin_nontemporal_load((const u4*)tile_base + lane);
+        u4 v = AMQ_STREAM_LOAD((const u4*)tile_base + lane);
         r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
     } else if (BITS == 2) {
-        u2 v = __builtin_nontemporal_load((const u2*)tile_base + lane);
+        u2 v = AMQ_STREAM_LOAD((const u2*)tile_base + lane);
         r.w[0] = v.x; r.w[1] = v.y;
     } else {
         const uint32_t* p = tile_base + 3 * lane;
-        r.w[0] = __builtin_nontemporal_load(p);
-        r.w[1] = __builtin_nontemporal_load(p + 1);
-        r.w[2] = __builtin_nontemporal_load(p + 2);
+        r.w[0] = AMQ_STREAM_LOAD(p);
+        r.w[1] = AMQ_STREAM_LOAD(p + 1);
+        r.w[2] = AMQ_STREAM_LOAD(p + 2);
     }
     return r;
 }

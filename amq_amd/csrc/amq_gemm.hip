@@ -90,8 +90,8 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     for (int kt = 0; kt < G; ++kt) {
         const _Float16* ab = abuf(kt);
         h2 wv[2][16];
-        dequant_lane<BITS, MODE>(pay[0].w, meta[0], wv[0]);
-        dequant_lane<BITS, MODE>(pay[1].w, meta[1], wv[1]);
+        dequant_lane_sd<BITS, MODE>(pay[0].w, meta[0], wv[0]);
+        dequant_lane_sd<BITS, MODE>(pay[1].w, meta[1], wv[1]);
         if (kt + 1 < G) { load_a(kt + 1); load_b(kt + 1); }      // issue early
 #pragma unroll
         for (int t = 0; t < 4; ++t) {

@@ -5,19 +5,24 @@
 //   gemv_kernel<2,Batch,256,128>          (amq/kernel/ft/quantization_new/gemv/gemv_cuda.cu:73-204)
 // with one kernel family over the native AMQ-T16 layout (amq_common.cuh).
 //
-// Structure (HBM-bound: every byte of W is read exactly once, nothing else matters):
+// Structure (HBM-bound by design: every byte of W is read exactly once):
 //   * one workgroup = 16 output rows x all of K; its weight bytes are one
-//     contiguous range.  NW waves split the K/128 tiles round-robin.
-//   * each wave issues its first U tile loads (16 B/lane, non-temporal)
-//     BEFORE x is staged, so the HBM round trip overlaps the prologue.
+//     contiguous range.  NW waves (4 / 8 / 16, picked from the grid size) take
+//     the K/128 tiles round-robin.
+//   * each wave keeps U tile loads (16/12/8 B per lane, non-temporal) in flight
+//     in a rolling register ring: a slot is re-issued as soon as it has been
+//     consumed, and the first U leave BEFORE x is staged, so the HBM round trip
+//     overlaps the prologue.
 //   * x (optionally RMSNorm'ed or SiLU(gate)*up) is staged once in LDS as fp16;
 //     lanes read their 8-wide k-octets with ds_read_b128 (4 addresses per
 //     instruction, broadcast over 16 lanes -> conflict free).
-//   * M == 1: unpack (v_and_or + v_pk_*_f16) -> v_dot2c_f32_f16 into fp32,
-//     2-step wavefront reduction over the 4 k-octet lane groups, fixed-order
-//     cross-wave sum through LDS (deterministic, no atomics).
-//   * 2 <= M <= 64: the unpacked fp16x8 register block IS the MFMA B operand;
-//     v_mfma_f32_16x16x32_f16 against x rows read from LDS.  W never touches LDS.
+//   * the unpacked fp16x8 register block IS the MFMA B operand (layout chosen
+//     for that): v_mfma_f32_16x16x32_f16 against the x rows; W never touches
+//     LDS, the k-octet reduction happens inside the matrix core, and M = 1..16
+//     costs the same VALU work.  (M == 1 can alternatively run the
+//     v_dot2c_f32_f16 + wavefront-shuffle reduction body: GEMV_FLAG_DOT; it is
+//     slower on gfx950 because dot2c is a 4-cycle VOP3 issue -- DESIGN.md.)
+//   * fixed-order cross-wave sum through LDS: deterministic, no atomics.
 //   * several linears that share x (q/k/v, gate/up) with different bit-widths
 //     run as segments of ONE launch (wave-uniform switch on bits).
 #include "amq_common.cuh"
@@ -25,8 +30,6 @@
 
 namespace amq {
 
-constexpr int GEMV_NW = 8;           // waves per workgroup
-constexpr int GEMV_THREADS = GEMV_NW * 64;
 constexpr int GEMV_U = 4;            // tiles in flight per wave
 constexpr int XPAD = 8;              // halves of padding per staged x row (16 B)
 
@@ -40,8 +43,9 @@ __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + __expf(-g)
 
 // ---------------------------------------------------------------- staging
 // Writes the (transformed) activations into LDS as fp16 [M][xs].
-template <int PRO>
+template <int PRO, int NW>
 __device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* red, int xs) {
+    constexpr int THREADS = NW * 64;
     const int tid = threadIdx.x;
     const int K = a.K;
     const int chunks = K >> 3;      // 8 halves per chunk
@@ -49,12 +53,12 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* 
         const _Float16* xrow = (const _Float16*)a.x + (size_t)m * a.x_stride;
         _Float16* lrow = xl + (size_t)m * xs;
         if (PRO == PRO_NONE) {
-            for (int c = tid; c < chunks; c += GEMV_THREADS)
+            for (int c = tid; c < chunks; c += THREADS)
                 *(h8*)(lrow + 8 * c) = *(const h8*)(xrow + 8 * c);
         } else if (PRO == PRO_SILU_MUL) {
             // x = fp16(fp16(silu(gate)) * up)  -- HF LlamaMLP: act_fn(gate) * up
             const _Float16* urow = (const _Float16*)a.x2 + (size_t)m * a.x_stride;
-            for (int c = tid; c < chunks; c += GEMV_THREADS) {
+            for (int c = tid; c < chunks; c += THREADS) {
                 h8 g = *(const h8*)(xrow + 8 * c);
                 h8 u = *(const h8*)(urow + 8 * c);
                 h8 r;
@@ -67,7 +71,7 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* 
             }
         } else {  // PRO_RMSNORM
             float ss = 0.f;
-            for (int c = tid; c < chunks; c += GEMV_THREADS) {
+            for (int c = tid; c < chunks; c += THREADS) {
                 h8 v = *(const h8*)(xrow + 8 * c);
                 *(h8*)(lrow + 8 * c) = v;
 #pragma unroll
@@ -79,10 +83,10 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* 
             __syncthreads();
             float tot = 0.f;
 #pragma unroll
-            for (int w = 0; w < GEMV_NW; ++w) tot += red[w];
+            for (int w = 0; w < NW; ++w) tot += red[w];
             const float rstd = rsqrtf(tot / (float)K + a.eps);
             // HF LlamaRMSNorm: weight * (x.float() * rstd).to(fp16)
-            for (int c = tid; c < chunks; c += GEMV_THREADS) {
+            for (int c = tid; c < chunks; c += THREADS) {
                 h8 v = *(h8*)(lrow + 8 * c);
                 h8 gm = *(const h8*)((const _Float16*)a.gamma + 8 * c);
                 h8 r;
@@ -106,86 +110,97 @@ __device__ __forceinline__ void store_out(const GemvSeg& s, int m, int n, float 
 }
 
 // ---------------------------------------------------------------- body
-template <int BITS, int MODE, int PRO, bool MFMA>
+template <int BITS, int MODE, int PRO, int NW, bool DOT>
 __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, int rt,
                                           _Float16* xl, float* red, int xs) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = a.K >> 7;
     const int r = lane & 15, o = lane >> 4;
     const uint32_t* qw = (const uint32_t*)s.qweight + (size_t)rt * G * (64 * BITS);
     const h2* mt = (const h2*)s.meta + (size_t)rt * G * 16 + r;
+    const int nt = (G - wave + NW - 1) / NW;          // tiles owned by this wave: g = wave + i*NW
 
     LanePayload<BITS> pay[GEMV_U];
     h2 meta[GEMV_U];
-    auto issue = [&](int g0) {
+#define AMQ_ISSUE(slot, i)                                                                       \
+    do {                                                                                         \
+        const int g_ = wave + (i) * NW;                                                          \
+        pay[slot] = load_payload<BITS>(qw + (size_t)g_ * (64 * BITS), lane);                      \
+        meta[slot] = as_h2(AMQ_STREAM_LOAD((const uint32_t*)(mt + (size_t)g_ * 16)));            \
+    } while (0)
+
 #pragma unroll
-        for (int u = 0; u < GEMV_U; ++u) {
-            const int g = g0 + u * GEMV_NW;
-            if (g < G) {
-                pay[u] = load_payload<BITS>(qw + (size_t)g * (64 * BITS), lane);
-                meta[u] = as_h2(__builtin_nontemporal_load((const uint32_t*)(mt + (size_t)g * 16)));
-            }
-        }
-    };
-    issue(wave);                    // HBM requests leave before the prologue
-    stage_x<PRO>(a, xl, red, xs);
+    for (int u = 0; u < GEMV_U; ++u)
+        if (u < nt) AMQ_ISSUE(u, u);                  // HBM requests leave before the prologue
+
+    stage_x<PRO, NW>(a, xl, red, xs);
     __syncthreads();
 
-    constexpr int MB = MFMA ? 4 : 1;           // 16-row m-blocks (MFMA) / scalar acc
     float acc1[4] = {0.f, 0.f, 0.f, 0.f};
-    f4 accm[MB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i) accm[i] = (f4){0.f, 0.f, 0.f, 0.f};
-    const int mblocks = (a.M + 15) >> 4;
+    f4 accm = (f4){0.f, 0.f, 0.f, 0.f};
+    int mrow = r < a.M ? r : a.M - 1;                 // A rows >= M: any finite data, result unused
+    const _Float16* xrow = xl + (size_t)mrow * xs + 8 * o;
 
-    for (int g0 = wave; g0 < G; g0 += GEMV_NW * GEMV_U) {
-        LanePayload<BITS> cur[GEMV_U];
-        h2 cmeta[GEMV_U];
-#pragma unroll
-        for (int u = 0; u < GEMV_U; ++u) { cur[u] = pay[u]; cmeta[u] = meta[u]; }
-        if (g0 + GEMV_NW * GEMV_U < G) issue(g0 + GEMV_NW * GEMV_U);   // prefetch next batch
+    // consume one tile out of ring slot `slot`
+#define AMQ_COMPUTE(slot, i)                                                                     \
+    do {                                                                                         \
+        h2 wv[16];                                                                               \
+        dequant_lane_sd<BITS, MODE>(pay[slot].w, meta[slot], wv);                                \
+        const int kbase = (wave + (i) * NW) << 7;                                                \
+        if (DOT) {                                                                               \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                      \
+                const h8 xv = *(const h8*)(xl + kbase + 8 * o + 32 * t);                         \
+                _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                  \
+                    h2 xp = {xv[2 * p], xv[2 * p + 1]};                                          \
+                    acc1[t] = __builtin_amdgcn_fdot2(wv[4 * t + p], xp, acc1[t], false);         \
+                }                                                                                \
+            }                                                                                    \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                      \
+                h8 b;                                                                            \
+                _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                  \
+                    b[2 * p] = wv[4 * t + p].x; b[2 * p + 1] = wv[4 * t + p].y;                  \
+                }                                                                                \
+                const h8 av = *(const h8*)(xrow + kbase + 32 * t);                               \
+                accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, accm, 0, 0, 0);             \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+
+    // Software pipeline over this wave's tiles.  A slot is refilled only after
+    // its tile has been fully consumed (sched_barrier keeps the compiler from
+    // hoisting the load into temporaries + a vmcnt(0)/v_mov rotation, which is
+    // what a naive ring compiles to); the main loop refills unconditionally so
+    // the waits stay counted (vmcnt((U-1)*loads)), the tail drains.
+    int i = 0;
+    for (; i + 2 * GEMV_U <= nt; i += GEMV_U) {
 #pragma unroll
         for (int u = 0; u < GEMV_U; ++u) {
-            const int g = g0 + u * GEMV_NW;
-            if (g < G) {
-                h2 wv[16];
-                dequant_lane<BITS, MODE>(cur[u].w, cmeta[u], wv);
-                const int kbase = (g << 7) + 8 * o;
-                if (!MFMA) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const h8 xv = *(const h8*)(xl + kbase + 32 * t);
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) {
-                            h2 xp = {xv[2 * p], xv[2 * p + 1]};
-                            acc1[t] = __builtin_amdgcn_fdot2(wv[4 * t + p], xp, acc1[t], false);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        h8 b;
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) { b[2 * p] = wv[4 * t + p].x; b[2 * p + 1] = wv[4 * t + p].y; }
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
-                            if (mb < mblocks) {
-                                int m = mb * 16 + r;
-                                m = m < a.M ? m : a.M - 1;      // rows >= M: any finite data, result unused
-                                const h8 av = *(const h8*)(xl + (size_t)m * xs + kbase + 32 * t);
-                                accm[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, accm[mb], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-            }
+            AMQ_COMPUTE(u, i + u);
+            __builtin_amdgcn_sched_barrier(0);
+            AMQ_ISSUE(u, i + u + GEMV_U);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#pragma unroll
+    for (int u = 0; u < GEMV_U; ++u) {
+        if (i + u < nt) {
+            AMQ_COMPUTE(u, i + u);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + u + GEMV_U < nt) AMQ_ISSUE(u, i + u + GEMV_U);
+        }
+    }
+    i += GEMV_U;
+#pragma unroll
+    for (int u = 0; u < GEMV_U; ++u)
+        if (i + u < nt) AMQ_COMPUTE(u, i + u);
+#undef AMQ_ISSUE
+#undef AMQ_COMPUTE
 
-    // ---- reduction: lanes (k-octet groups) -> waves (fixed order) -> y
-    __syncthreads();                // everyone is done reading xl; reuse red[]
-    if (!MFMA) {
+    // ---- cross-wave reduction in a fixed order -> y
+    __syncthreads();                // everyone is done reading xl; red[] is free
+    if (DOT) {
         float v = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
@@ -194,31 +209,27 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
         if (threadIdx.x < 16) {
             float tot = 0.f;
 #pragma unroll
-            for (int w = 0; w < GEMV_NW; ++w) tot += red[w * 16 + threadIdx.x];
+            for (int w = 0; w < NW; ++w) tot += red[w * 16 + threadIdx.x];
             store_out(s, 0, rt * 16 + threadIdx.x, tot);
         }
     } else {
-        // accm[mb][i] = D[m = mb*16 + 4*o + i][n = r]
-        float* redm = red;          // [NW][64 rows][16 cols]
+        // accm[i] = D[m = 4*o + i][n = r]
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-            if (mb < mblocks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    redm[(wave * 64 + mb * 16 + 4 * o + i) * 16 + r] = accm[mb][i];
+        for (int i = 0; i < 4; ++i)
+            if (4 * o + i < a.M) red[(wave * 16 + 4 * o + i) * 16 + r] = accm[i];
         __syncthreads();
-        for (int e = threadIdx.x; e < a.M * 16; e += GEMV_THREADS) {
+        for (int e = threadIdx.x; e < a.M * 16; e += NW * 64) {
             const int m = e >> 4, n = e & 15;
             float tot = 0.f;
 #pragma unroll
-            for (int w = 0; w < GEMV_NW; ++w) tot += redm[(w * 64 + m) * 16 + n];
+            for (int w = 0; w < NW; ++w) tot += red[(w * 16 + m) * 16 + n];
             store_out(s, m, rt * 16 + n, tot);
         }
     }
 }
 
-template <int PRO, bool MFMA>
-__global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
+template <int PRO, int NW, bool DOT>
+__global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xs = a.K + XPAD;
     _Float16* xl = (_Float16*)smem;
@@ -232,42 +243,60 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
     const int rt = (int)blockIdx.x - s.wg_begin;
     const int key = s.bits * 2 + s.mode;
     switch (key) {
-        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, MFMA>(a, s, rt, xl, red, xs); break;
-        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, MFMA>(a, s, rt, xl, red, xs); break;
-        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, MFMA>(a, s, rt, xl, red, xs); break;
-        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, MFMA>(a, s, rt, xl, red, xs); break;
-        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, MFMA>(a, s, rt, xl, red, xs); break;
-        default:               gemv_body<2, MODE_FMA, PRO, MFMA>(a, s, rt, xl, red, xs); break;
+        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
+        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
+        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
+        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
+        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
     }
 }
 
 size_t gemv_lds_bytes(int M, int K) {
     const size_t xbytes = (((size_t)M * (K + XPAD) * 2) + 15) & ~(size_t)15;
-    const size_t red = (M == 1) ? (size_t)GEMV_NW * 16 * 4 : (size_t)GEMV_NW * 64 * 16 * 4;
+    const size_t red = (size_t)16 /*max NW*/ * 16 * 16 * 4;
     return xbytes + red;
 }
 
-template <int PRO, bool MFMA>
+int gemv_pick_waves(int total_wg, int K) {
+    // enough bytes in flight per CU: few workgroups -> more waves per workgroup
+    const int G = K >> 7;
+    int nw = total_wg >= 1024 ? 4 : (total_wg >= 512 ? 8 : 16);
+    while (nw > 4 && G < 2 * nw) nw >>= 1;      // at least ~2 tiles per wave
+    return nw;
+}
+
+template <int PRO, int NW, bool DOT>
 static hipError_t launch_one(const GemvArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    auto kern = gemv_kernel<PRO, MFMA>;
+    auto kern = gemv_kernel<PRO, NW, DOT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(total_wg), dim3(GEMV_THREADS), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(total_wg), dim3(NW * 64), lds, st, a);
     return hipGetLastError();
+}
+
+template <int PRO>
+static hipError_t launch_pro(const GemvArgs& a, int total_wg, size_t lds, hipStream_t st) {
+    const bool dot = (a.flags & GEMV_FLAG_DOT) && a.M == 1;
+    int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_wg, a.K);
+    if (dot) {
+        if (nw == 4) return launch_one<PRO, 4, true>(a, total_wg, lds, st);
+        if (nw == 8) return launch_one<PRO, 8, true>(a, total_wg, lds, st);
+        return launch_one<PRO, 16, true>(a, total_wg, lds, st);
+    }
+    if (nw == 4) return launch_one<PRO, 4, false>(a, total_wg, lds, st);
+    if (nw == 8) return launch_one<PRO, 8, false>(a, total_wg, lds, st);
+    return launch_one<PRO, 16, false>(a, total_wg, lds, st);
 }
 
 hipError_t launch_gemv(const GemvArgs& a, int total_wg, hipStream_t st) {
     const size_t lds = gemv_lds_bytes(a.M, a.K);
-    const bool mfma = a.M > 1;
     switch (a.prologue) {
-        case PRO_NONE:
-            return mfma ? launch_one<PRO_NONE, true>(a, total_wg, lds, st) : launch_one<PRO_NONE, false>(a, total_wg, lds, st);
-        case PRO_RMSNORM:
-            return mfma ? launch_one<PRO_RMSNORM, true>(a, total_wg, lds, st) : launch_one<PRO_RMSNORM, false>(a, total_wg, lds, st);
-        default:
-            return mfma ? launch_one<PRO_SILU_MUL, true>(a, total_wg, lds, st) : launch_one<PRO_SILU_MUL, false>(a, total_wg, lds, st);
+        case PRO_NONE: return launch_pro<PRO_NONE>(a, total_wg, lds, st);
+        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(a, total_wg, lds, st);
+        default: return launch_pro<PRO_SILU_MUL>(a, total_wg, lds, st);
     }
 }
 

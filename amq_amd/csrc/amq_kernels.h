@@ -35,7 +35,11 @@ struct GemvArgs {
     const void* gamma;     // PRO_RMSNORM: fp16 [K]
     float eps;
     int prologue;
+    int flags;             // GEMV_FLAG_*
+    int force_waves;       // 0 = auto, else 4 / 8 / 16 waves per workgroup
 };
+enum { GEMV_FLAG_DOT = 1 };
+constexpr int GEMV_MAX_M = 16;
 
 size_t gemv_lds_bytes(int M, int K);
 hipError_t launch_gemv(const GemvArgs& a, int total_wg, hipStream_t st);

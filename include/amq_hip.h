@@ -57,6 +57,11 @@ extern "C" {
 int amq_version(void);
 const char* amq_last_error(void);
 
+/* process-wide tuning / A-B knobs (not needed for normal use) */
+#define AMQ_OPT_GEMV_DOT   1       /* 1: M == 1 runs the v_dot2c + wavefront-shuffle body instead of the MFMA body */
+#define AMQ_OPT_GEMV_WAVES 2       /* waves per GEMV workgroup: 0 = auto (default), 4, 8 or 16 */
+int amq_set_option(int option, int value);
+
 /* capabilities: writes up to `cap` ints {max_gemv_rows_for_K, lds_bytes, ...}; returns the count */
 int amq_query(int K, int* out, int cap);
 
@@ -87,8 +92,8 @@ int amq_dequantize_hqq_f16(int bits, const void* W_q, const void* scale, const v
                            int N, int K, int group, void* W_out, void* stream);
 
 /* ---- the hot path: y[M,N] = x[M,K] . W^T (+ bias) ------------------------ */
-/* few rows (decode).  M == 1: dot-product + wavefront reduction; 2 <= M: register-operand MFMA.
- * M is limited by LDS (M * (K + 8) * 2 + 32 KiB <= 160 KiB), AMQ_ESHAPE beyond -- use amq_gemm_f16.
+/* few rows (decode).  The unpacked weights are the MFMA B operand straight from registers (W never touches LDS).
+ * M <= 16 and M * (K + 8) * 2 + 16 KiB <= 160 KiB of LDS, AMQ_ESHAPE beyond -- use amq_gemm_f16.
  * x_stride / y_stride in elements (0 = dense). */
 int amq_gemv_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
                  const void* bias, void* y, int M, int N, int K, int group,

@@ -34,14 +34,27 @@ def bench_case(n, k, bits, m, iters, fn_name="gemv"):
     for i in range(copies):
         fn(x, bufs[i][0], bufs[i][1], bits, ops.MODE_HQQ, n, k, out=y)
     torch.cuda.synchronize()
+    # capture the launch sequence in a HIP graph: replay cost is device-side
+    # (kernel + ~1.2-1.5 us inter-kernel boundary), not Python/ctypes time
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for i in range(iters):
+                q, mt = bufs[i % copies]
+                fn(x, q, mt, bits, ops.MODE_HQQ, n, k, out=y)
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
     e0.record()
-    for i in range(iters):
-        q, mt = bufs[i % copies]
-        fn(x, q, mt, bits, ops.MODE_HQQ, n, k, out=y)
+    for _ in range(reps):
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
+    us = e0.elapsed_time(e1) * 1e3 / (iters * reps)
     b = layer_bytes(n, k, bits, m)
     return {"kernel": fn_name, "N": n, "K": k, "bits": bits, "M": m, "us": round(us, 3),
             "GBps": round(b / us / 1e3, 1), "bytes": b, "copies": copies}
@@ -51,7 +64,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=400)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--dot", type=int, default=0)
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--gemm", type=int, default=1)
     args = ap.parse_args()
+    from amq_amd import _lib
+    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DOT, args.dot))
+    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_WAVES, args.waves))
     shapes = [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096)]
     if args.quick:
         shapes = shapes[:2]
@@ -60,6 +79,8 @@ def main():
             print(json.dumps(bench_case(n, k, bits, 1, args.iters)), flush=True)
     for m in (2, 4, 8):
         print(json.dumps(bench_case(4096, 4096, 4, m, args.iters)), flush=True)
+    if not args.gemm:
+        return
     for m in (64, 512, 4096):
         for bits in (4, 3, 2):
             r = bench_case(5120, 5120, bits, m, max(20, args.iters // 10), "gemm")
