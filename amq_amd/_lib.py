@@ -16,7 +16,7 @@ AMQ_OK = 0
 MODE_HQQ, MODE_FMA = 0, 1
 PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
-OPT_GEMV_DOT, OPT_GEMV_WAVES = 1, 2
+OPT_GEMV_DOT, OPT_GEMV_WAVES, OPT_GEMV_DEPTH = 1, 2, 3
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
@@ -43,6 +43,9 @@ SIGNATURES = {
     "amq_gemv_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_gemm_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_linear_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amq_rmsnorm_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "amq_gemv_f16w": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "amq_attn_decode_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),
 }
 

@@ -40,6 +40,7 @@ int check_mode(int mode) {
 constexpr size_t LDS_LIMIT = 160 * 1024;
 int g_opt_dot = 0;
 int g_opt_waves = 0;
+int g_opt_depth = 0;
 
 }  // namespace
 
@@ -51,8 +52,13 @@ const char* amq_last_error(void) { return g_err; }
 int amq_set_option(int option, int value) {
     if (option == AMQ_OPT_GEMV_DOT) { g_opt_dot = value ? 1 : 0; return AMQ_OK; }
     if (option == AMQ_OPT_GEMV_WAVES) {
-        if (value != 0 && value != 4 && value != 8 && value != 16) return fail(AMQ_EINVAL, "waves must be 0, 4, 8 or 16");
+        if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16) return fail(AMQ_EINVAL, "waves must be 0, 2, 4, 8 or 16");
         g_opt_waves = value;
+        return AMQ_OK;
+    }
+    if (option == AMQ_OPT_GEMV_DEPTH) {
+        if (value != 0 && value != 2 && value != 4) return fail(AMQ_EINVAL, "depth must be 0, 2 or 4");
+        g_opt_depth = value;
         return AMQ_OK;
     }
     return fail(AMQ_EINVAL, "unknown option %d", option);
@@ -137,6 +143,7 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     a.x = x; a.x2 = x2; a.gamma = gamma; a.eps = eps; a.prologue = prologue;
     a.flags = g_opt_dot ? amq::GEMV_FLAG_DOT : 0;
     a.force_waves = g_opt_waves;
+    a.force_depth = g_opt_depth;
     return check_hip(amq::launch_gemv(a, wg, (hipStream_t)stream), "gemv");
 }
 
@@ -164,6 +171,33 @@ int amq_linear_f16(int bits, int mode, const void* x, const void* qn, const void
     if (M <= 8 && amq::gemv_lds_bytes(M, K) <= 64 * 1024)
         return amq_gemv_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
     return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
+}
+
+int amq_rmsnorm_f16(const void* x, const void* gamma, void* y, int M, int K, float eps, void* stream) {
+    if (!x || !gamma || !y) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1 || K < 8 || (K % 8) != 0) return fail(AMQ_ESHAPE, "need M >= 1 and K %% 8 == 0 (got M=%d K=%d)", M, K);
+    return check_hip(amq::launch_rmsnorm(x, gamma, y, M, K, eps, (hipStream_t)stream), "rmsnorm");
+}
+
+int amq_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
+                  int N, int K, void* stream) {
+    if (!x || !W || !y) return fail(AMQ_EINVAL, "null pointer");
+    if (N < 1 || K < 512 || (K % 512) != 0) return fail(AMQ_ESHAPE, "need K %% 512 == 0 (got N=%d K=%d)", N, K);
+    if ((size_t)K * 2 + 64 > 64 * 1024) return fail(AMQ_ESHAPE, "K=%d too large for the fp16-weight GEMV", K);
+    return check_hip(amq::launch_gemv_f16w(x, W, bias, y, gamma, eps, N, K, (hipStream_t)stream), "gemv_f16w");
+}
+
+int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcache, void* vcache, void* out,
+                        const int* pos_dev, int pos, int batch, int n_heads, int n_kv_heads, int head_dim,
+                        int max_seq, float rope_theta, void* stream) {
+    if (!q || !k || !v || !kcache || !vcache || !out) return fail(AMQ_EINVAL, "null pointer");
+    if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
+    if (batch < 1 || n_heads < 1 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0)
+        return fail(AMQ_ESHAPE, "bad head configuration (%d q heads, %d kv heads)", n_heads, n_kv_heads);
+    if (max_seq < 1 || (!pos_dev && (pos < 0 || pos >= max_seq))) return fail(AMQ_ESHAPE, "position %d outside the cache (max_seq=%d)", pos, max_seq);
+    if (4 * 128 + (size_t)max_seq * 4 > LDS_LIMIT) return fail(AMQ_ESHAPE, "max_seq=%d too long for the single-pass decode attention", max_seq);
+    amq::AttnArgs a{q, k, v, kcache, vcache, out, pos_dev, pos, n_heads, n_kv_heads, max_seq, rope_theta};
+    return check_hip(amq::launch_attn_decode(a, batch, (hipStream_t)stream), "attn_decode");
 }
 
 }  // extern "C"

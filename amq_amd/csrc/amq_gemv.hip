@@ -30,7 +30,6 @@
 
 namespace amq {
 
-constexpr int GEMV_U = 4;            // tiles in flight per wave
 constexpr int XPAD = 8;              // halves of padding per staged x row (16 B)
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -110,7 +109,7 @@ __device__ __forceinline__ void store_out(const GemvSeg& s, int m, int n, float 
 }
 
 // ---------------------------------------------------------------- body
-template <int BITS, int MODE, int PRO, int NW, bool DOT>
+template <int BITS, int MODE, int PRO, int NW, bool DOT, int GEMV_U>
 __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, int rt,
                                           _Float16* xl, float* red, int xs) {
     const int lane = threadIdx.x & 63;
@@ -228,7 +227,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
     }
 }
 
-template <int PRO, int NW, bool DOT>
+template <int PRO, int NW, bool DOT, int U>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xs = a.K + XPAD;
@@ -243,12 +242,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvArgs a) {
     const int rt = (int)blockIdx.x - s.wg_begin;
     const int key = s.bits * 2 + s.mode;
     switch (key) {
-        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
-        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
-        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
-        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
-        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
-        default:               gemv_body<2, MODE_FMA, PRO, NW, DOT>(a, s, rt, xl, red, xs); break;
+        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
+        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
+        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
+        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
+        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
     }
 }
 
@@ -259,16 +258,17 @@ size_t gemv_lds_bytes(int M, int K) {
 }
 
 int gemv_pick_waves(int total_wg, int K) {
-    // enough bytes in flight per CU: few workgroups -> more waves per workgroup
+    // measured on MI355X (tools/microbench.py sweeps, profiles/): 8 waves x 2 tiles
+    // in flight is the best or within 3% of it for every Llama shape; tiny K
+    // falls back to 4 waves so each wave still owns >= 2 tiles.
+    (void)total_wg;
     const int G = K >> 7;
-    int nw = total_wg >= 1024 ? 4 : (total_wg >= 512 ? 8 : 16);
-    while (nw > 4 && G < 2 * nw) nw >>= 1;      // at least ~2 tiles per wave
-    return nw;
+    return G >= 16 ? 8 : 4;
 }
 
-template <int PRO, int NW, bool DOT>
+template <int PRO, int NW, bool DOT, int U>
 static hipError_t launch_one(const GemvArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    auto kern = gemv_kernel<PRO, NW, DOT>;
+    auto kern = gemv_kernel<PRO, NW, DOT, U>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -277,18 +277,22 @@ static hipError_t launch_one(const GemvArgs& a, int total_wg, size_t lds, hipStr
     return hipGetLastError();
 }
 
+template <int PRO, int NW>
+static hipError_t launch_nw(const GemvArgs& a, int total_wg, size_t lds, hipStream_t st) {
+    const bool dot = (a.flags & GEMV_FLAG_DOT) && a.M == 1;
+    const int u = a.force_depth ? a.force_depth : 2;
+    if (dot) return launch_one<PRO, NW, true, 4>(a, total_wg, lds, st);
+    if (u == 2) return launch_one<PRO, NW, false, 2>(a, total_wg, lds, st);
+    return launch_one<PRO, NW, false, 4>(a, total_wg, lds, st);
+}
+
 template <int PRO>
 static hipError_t launch_pro(const GemvArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    const bool dot = (a.flags & GEMV_FLAG_DOT) && a.M == 1;
     int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_wg, a.K);
-    if (dot) {
-        if (nw == 4) return launch_one<PRO, 4, true>(a, total_wg, lds, st);
-        if (nw == 8) return launch_one<PRO, 8, true>(a, total_wg, lds, st);
-        return launch_one<PRO, 16, true>(a, total_wg, lds, st);
-    }
-    if (nw == 4) return launch_one<PRO, 4, false>(a, total_wg, lds, st);
-    if (nw == 8) return launch_one<PRO, 8, false>(a, total_wg, lds, st);
-    return launch_one<PRO, 16, false>(a, total_wg, lds, st);
+    if (nw == 2) return launch_nw<PRO, 2>(a, total_wg, lds, st);
+    if (nw == 4) return launch_nw<PRO, 4>(a, total_wg, lds, st);
+    if (nw == 8) return launch_nw<PRO, 8>(a, total_wg, lds, st);
+    return launch_nw<PRO, 16>(a, total_wg, lds, st);
 }
 
 hipError_t launch_gemv(const GemvArgs& a, int total_wg, hipStream_t st) {

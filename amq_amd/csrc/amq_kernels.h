@@ -36,7 +36,8 @@ struct GemvArgs {
     float eps;
     int prologue;
     int flags;             // GEMV_FLAG_*
-    int force_waves;       // 0 = auto, else 4 / 8 / 16 waves per workgroup
+    int force_waves;       // 0 = auto, else 2 / 4 / 8 / 16 waves per workgroup
+    int force_depth;       // 0 = auto, else 2 / 4 tile loads in flight per wave
 };
 enum { GEMV_FLAG_DOT = 1 };
 constexpr int GEMV_MAX_M = 16;
@@ -50,6 +51,24 @@ struct GemmArgs {
     int M, N, K, bits, mode, x_stride, y_stride;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st);
+
+// decode-step surroundings (amq_decode.hip)
+struct AttnArgs {
+    const void* q;        // fp16 [B, n_heads, 128]      (un-rotated)
+    const void* k;        // fp16 [B, n_kv_heads, 128]   (un-rotated new key)
+    const void* v;        // fp16 [B, n_kv_heads, 128]
+    void* kcache;         // fp16 [B, n_kv_heads, max_seq, 128] rotated keys
+    void* vcache;         // fp16 [B, n_kv_heads, max_seq, 128]
+    void* out;            // fp16 [B, n_heads, 128]
+    const int* pos_dev;   // device int32 position of the new token (graph replay), or null -> pos
+    int pos;
+    int n_heads, n_kv_heads, max_seq;
+    float rope_theta;
+};
+hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st);
+hipError_t launch_rmsnorm(const void* x, const void* gamma, void* y, int M, int K, float eps, hipStream_t st);
+hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
+                            int N, int K, hipStream_t st);
 
 // reference formats -> native
 hipError_t launch_repack(int fmt, int bits, const void* qsrc, const void* s_src, const void* z_src,

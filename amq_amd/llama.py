@@ -1,0 +1,247 @@
+"""Mixed-precision Llama decode runner: the caller side of the hot path.
+
+Counterpart of what ``amq_speed_benchmark.py:231-256`` assembles (a Llama whose
+7 linears per block are 2/3/4-bit modules chosen by the arch JSON) and of the
+patched forward in ``kernel/monkeypatch/ftllama_modeling.py:70-341`` (static
+batch-1 KV cache, ``start_pos``), built MI355X-first:
+
+  * one token step = 5 launches per block (fused-RMSNorm q/k/v GEMV with three
+    bit-widths in one launch, RoPE+KV-append+attention, o_proj GEMV with
+    residual epilogue, fused-RMSNorm gate/up GEMV, SiLU*mul-prologue down GEMV
+    with residual epilogue) + fused final-norm lm_head GEMV + argmax;
+  * the whole step is captured once into a hipGraph and replayed per token
+    (position and token id live in device memory), so the ~165 launches cost
+    device-side boundaries only, no Python/ctypes time;
+  * prefill runs the same weights through the tiled MFMA GEMM.
+
+Weights: real HQQ layers via ``from_hqq_weights`` (tests, real checkpoints) or
+synthetic native payloads of the real shapes (``synthetic=True``; there is no
+network for checkpoints -- values do not affect speed).
+"""
+import math
+
+import torch
+
+from . import ops
+from .arch import MODEL_CONFIGS, arch_bits, uniform_arch
+from .hqq_format import HQQWeights
+
+EPS = 1e-5
+ROPE_THETA = 10000.0
+
+
+class _Lin:
+    """native weights of one linear"""
+    __slots__ = ("qn", "mn", "bits", "mode", "N", "K")
+
+    def __init__(self, qn, mn, bits, mode, N, K):
+        self.qn, self.mn, self.bits, self.mode, self.N, self.K = qn, mn, bits, mode, N, K
+
+    def seg(self, y, residual=None):
+        return dict(qn=self.qn, mn=self.mn, bits=self.bits, mode=self.mode, N=self.N, y=y, residual=residual)
+
+    def nbytes(self):
+        return self.qn.numel() * 4 + self.mn.numel() * 2
+
+
+def _synthetic_linear(n, k, bits, gen, device):
+    """Random native payload + (scale, zero) giving roughly unit-gain layers:
+    any bit pattern is a valid weight matrix in the native layout."""
+    qb, mb = ops.native_sizes(bits, n, k)
+    qn = torch.randint(-2 ** 31, 2 ** 31 - 1, (qb // 4,), dtype=torch.int32, device=device, generator=gen)
+    std_q = math.sqrt((4.0 ** bits - 1.0) / 12.0)
+    s0 = 0.5 / (math.sqrt(k) * std_q)
+    r = torch.rand(mb // 4, 2, device=device, generator=gen)
+    meta = torch.empty(mb // 4, 2, dtype=torch.float16, device=device)
+    meta[:, 0] = (s0 * (0.75 + 0.5 * r[:, 0])).to(torch.float16)
+    meta[:, 1] = ((2 ** bits - 1) / 2.0 + (r[:, 1] - 0.5)).to(torch.float16)
+    return _Lin(qn, meta.reshape(-1).contiguous(), bits, ops.MODE_HQQ, n, k)
+
+
+class QuantLlama:
+    def __init__(self, config, arch_linear=None, device="cuda:0", max_seq=256, seed=0, synthetic=True,
+                 hqq_layers=None, dense=None):
+        """config: an entry of arch.MODEL_CONFIGS (or its name).
+        arch_linear: {'self_attn.q_proj': [bits]*n_block, ...}; default uniform 4.
+        hqq_layers: {(block, name): HQQWeights} real quantized layers (else synthetic).
+        dense: {'embed','lm_head','norm','ln1'[n_block],'ln2'[n_block]} fp16 tensors (else synthetic)."""
+        if isinstance(config, str):
+            config = MODEL_CONFIGS[config]
+        self.cfg = config
+        self.dev = torch.device(device)
+        self.H = config["hidden_size"]
+        self.I = config["intermediate_size"]
+        self.nh, self.nkv = config["num_heads"], config["num_kv_heads"]
+        if config["head_dim"] != 128:
+            raise ValueError("head_dim must be 128")
+        self.kvd = self.nkv * 128
+        self.nb = config["n_block"]
+        self.vocab = config["vocab_size"]
+        self.max_seq = max_seq
+        arch_linear = arch_linear or uniform_arch(config, 4)["linear"]
+        self.arch_linear = arch_linear
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        dev = self.dev
+
+        def lin(block, name):
+            n, k = config["linear_shape"][name]
+            bits = arch_bits(arch_linear, name, block)
+            if hqq_layers is not None:
+                h: HQQWeights = hqq_layers[(block, name)].to(dev)
+                assert h.nbits == bits and tuple(h.shape) == (n, k)
+                qn, mn = ops.repack_from_hqq(h.W_q.contiguous(), h.scale.reshape(-1).contiguous(),
+                                             h.zero.reshape(-1).contiguous(), bits, n, k)
+                return _Lin(qn, mn, bits, ops.MODE_HQQ, n, k)
+            if not synthetic:
+                raise ValueError("no weights given")
+            return _synthetic_linear(n, k, bits, gen, dev)
+
+        self.blocks = []
+        for b in range(self.nb):
+            blk = {name: lin(b, name) for name in config["linear"]}
+            if dense is not None:
+                blk["ln1"], blk["ln2"] = dense["ln1"][b].to(dev), dense["ln2"][b].to(dev)
+            else:
+                blk["ln1"] = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
+                blk["ln2"] = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
+            blk["kc"] = torch.zeros(1, self.nkv, max_seq, 128, dtype=torch.float16, device=dev)
+            blk["vc"] = torch.zeros(1, self.nkv, max_seq, 128, dtype=torch.float16, device=dev)
+            self.blocks.append(blk)
+        if dense is not None:
+            self.embed, self.lm_head, self.norm = dense["embed"].to(dev), dense["lm_head"].to(dev), dense["norm"].to(dev)
+        else:
+            self.embed = (torch.randn(self.vocab, self.H, device=dev, generator=gen)).to(torch.float16)
+            self.lm_head = (torch.randn(self.vocab, self.H, device=dev, generator=gen) / math.sqrt(self.H)).to(torch.float16)
+            self.norm = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
+
+        f16 = dict(dtype=torch.float16, device=dev)
+        self.x = torch.zeros(1, self.H, **f16)
+        self.q = torch.zeros(1, self.H, **f16)
+        self.k = torch.zeros(1, self.kvd, **f16)
+        self.v = torch.zeros(1, self.kvd, **f16)
+        self.att = torch.zeros(1, self.H, **f16)
+        self.gate = torch.zeros(1, self.I, **f16)
+        self.up = torch.zeros(1, self.I, **f16)
+        self.logits = torch.zeros(self.vocab, **f16)
+        self.token = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.graph = None
+
+    # ----------------------------------------------------------------- sizes
+    def linear_bytes_per_token(self):
+        """algorithmic bytes of the quantized linears per decode token"""
+        return sum(blk[name].nbytes() for blk in self.blocks for name in self.cfg["linear"])
+
+    def total_bytes_per_token(self, context):
+        kv = 2 * self.nb * self.nkv * 128 * 2 * context
+        return self.linear_bytes_per_token() + self.lm_head.numel() * 2 + kv
+
+    # ----------------------------------------------------------------- decode
+    def _step(self):
+        """one token: reads self.token / self.pos (device), writes self.logits, self.token, self.pos"""
+        H = self.H
+        torch.index_select(self.embed, 0, self.token, out=self.x)
+        for blk in self.blocks:
+            ops.gemv_grouped(self.x, [blk["self_attn.q_proj"].seg(self.q), blk["self_attn.k_proj"].seg(self.k),
+                                      blk["self_attn.v_proj"].seg(self.v)], H, prologue=ops.PRO_RMSNORM,
+                             gamma=blk["ln1"], eps=EPS)
+            ops.attn_decode(self.q, self.k, self.v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, ROPE_THETA)
+            ops.gemv_grouped(self.att, [blk["self_attn.o_proj"].seg(self.x, residual=self.x)], H)
+            ops.gemv_grouped(self.x, [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H,
+                             prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=EPS)
+            ops.gemv_grouped(self.gate, [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I,
+                             prologue=ops.PRO_SILU_MUL, x2=self.up)
+        ops.gemv_f16w(self.x.reshape(-1), self.lm_head, gamma=self.norm, eps=EPS, out=self.logits)
+        torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
+        self.pos.add_(1)
+
+    def capture(self):
+        """capture one token step into a hipGraph (replayed by decode_step)"""
+        if self.graph is not None:
+            return
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        saved = (self.token.clone(), self.pos.clone())
+        with torch.cuda.stream(side):
+            self._step()                       # warm-up outside capture (allocator, lazy init)
+            side.synchronize()
+            self.token.copy_(saved[0]); self.pos.copy_(saved[1])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                self._step()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.token.copy_(saved[0]); self.pos.copy_(saved[1])
+        self.graph = g
+
+    def decode_step(self, use_graph=True):
+        if use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+        else:
+            self._step()
+
+    # ---------------------------------------------------------------- prefill
+    def _rope(self, t, positions):
+        # HF apply_rotary_pos_emb: cos/sin in fp32 -> fp16; rotate_half
+        inv = 1.0 / (ROPE_THETA ** (torch.arange(0, 128, 2, device=self.dev, dtype=torch.float32) / 128.0))
+        fr = positions.to(torch.float32)[:, None] * inv[None, :]
+        emb = torch.cat([fr, fr], dim=-1)
+        cos, sin = emb.cos().to(torch.float16)[:, None, :], emb.sin().to(torch.float16)[:, None, :]
+        t1, t2 = t[..., :64], t[..., 64:]
+        rot = torch.cat([-t2, t1], dim=-1)
+        return t * cos + rot * sin
+
+    def prefill(self, ids):
+        """ids: int64 [S] prompt.  Fills the KV caches, leaves the next token in self.token and pos = S."""
+        S = ids.numel()
+        if S > self.max_seq:
+            raise ValueError("prompt longer than the KV cache")
+        H, nh, nkv = self.H, self.nh, self.nkv
+        x = self.embed.index_select(0, ids.to(self.dev))
+        positions = torch.arange(S, device=self.dev)
+
+        def lin(l, inp):
+            return ops.linear(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K)
+
+        for blk in self.blocks:
+            h = ops.rmsnorm(x, blk["ln1"], EPS)
+            q = lin(blk["self_attn.q_proj"], h).view(S, nh, 128)
+            k = lin(blk["self_attn.k_proj"], h).view(S, nkv, 128)
+            v = lin(blk["self_attn.v_proj"], h).view(S, nkv, 128)
+            q, k = self._rope(q, positions), self._rope(k, positions)
+            blk["kc"][0, :, :S] = k.transpose(0, 1)
+            blk["vc"][0, :, :S] = v.transpose(0, 1)
+            qh, kh, vh = q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1)
+            if nkv != nh:
+                kh = kh.repeat_interleave(nh // nkv, dim=0)
+                vh = vh.repeat_interleave(nh // nkv, dim=0)
+            a = torch.nn.functional.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
+            a = a.transpose(0, 1).reshape(S, H).contiguous()
+            x = x + lin(blk["self_attn.o_proj"], a)
+            h2 = ops.rmsnorm(x, blk["ln2"], EPS)
+            g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
+            x = x + lin(blk["mlp.down_proj"], torch.nn.functional.silu(g) * u)
+        last = x[S - 1].contiguous()
+        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=EPS, out=self.logits)
+        torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
+        self.pos.fill_(S)
+        return self.logits
+
+    def reset(self):
+        self.pos.zero_()
+        self.token.zero_()
+
+    def generate(self, ids, gen_len, use_graph=True):
+        """greedy: prefill + gen_len tokens (min_new_tokens = max_new_tokens = gen_len,
+        amq/utils/speed.py:34-39).  Returns the generated ids (device tensor)."""
+        if ids.numel() + gen_len > self.max_seq:
+            raise ValueError("sequence does not fit the KV cache")
+        out = torch.empty(gen_len, dtype=torch.int64, device=self.dev)
+        self.prefill(ids)
+        out[0:1] = self.token
+        for i in range(1, gen_len):
+            self.decode_step(use_graph)
+            out[i:i + 1] = self.token
+        return out

@@ -203,3 +203,55 @@ def gemv_grouped(x, segments, K, prologue=PRO_NONE, x2=None, gamma=None, eps=0.0
             raise ValueError("x2 rows != x rows")
     _lib.check(_lib.load().amq_gemv_grouped_f16(arr, len(segments), _lib.ptr(xx), _lib.ptr(x2), _lib.ptr(gamma),
                                                 ctypes.c_float(eps), prologue, M, K, GROUP, 0, _lib.current_stream()))
+
+
+# ---------------------------------------------------------------- decode-step surroundings
+def rmsnorm(x, gamma, eps, out=None):
+    K = x.shape[-1]
+    x2 = _prep_x(x, K)
+    _need(gamma, torch.float16, "gamma", K)
+    y = out if out is not None else torch.empty_like(x2)
+    _need(y, torch.float16, "y", x2.numel())
+    _lib.check(_lib.load().amq_rmsnorm_f16(_lib.ptr(x2), _lib.ptr(gamma), _lib.ptr(y), x2.shape[0], K,
+                                           ctypes.c_float(eps), _lib.current_stream()))
+    return y.reshape(x.shape)
+
+
+def gemv_f16w(x, W, bias=None, gamma=None, eps=0.0, out=None):
+    """y[N] = (RMSNorm'ed if gamma) x[K] . W[N,K]^T, fp16 weights (lm_head)."""
+    N, K = W.shape
+    _need(W, torch.float16, "W", N * K)
+    _need(x, torch.float16, "x", K)
+    if gamma is not None:
+        _need(gamma, torch.float16, "gamma", K)
+    if bias is not None:
+        _need(bias, torch.float16, "bias", N)
+    y = out if out is not None else torch.empty(N, dtype=torch.float16, device=x.device)
+    _need(y, torch.float16, "y", N)
+    _lib.check(_lib.load().amq_gemv_f16w(_lib.ptr(x), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(gamma),
+                                         ctypes.c_float(eps), N, K, _lib.current_stream()))
+    return y
+
+
+def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_theta=10000.0):
+    """One new token per sequence.  q [B, n_heads*128], k/v [B, n_kv_heads*128],
+    caches [B, n_kv_heads, max_seq, 128]; ``pos`` is an int or a device int32 tensor."""
+    B = kcache.shape[0]
+    max_seq = kcache.shape[2]
+    _need(q, torch.float16, "q", B * n_heads * 128)
+    _need(k, torch.float16, "k", B * n_kv_heads * 128)
+    _need(v, torch.float16, "v", B * n_kv_heads * 128)
+    _need(kcache, torch.float16, "kcache", B * n_kv_heads * max_seq * 128)
+    _need(vcache, torch.float16, "vcache", B * n_kv_heads * max_seq * 128)
+    _need(out, torch.float16, "out", B * n_heads * 128)
+    if isinstance(pos, torch.Tensor):
+        _need(pos, torch.int32, "pos", 1)
+        pos_dev, pos_i = ctypes.cast(pos.data_ptr(), ctypes.c_void_p), 0
+    else:
+        pos_dev, pos_i = None, int(pos)
+        if not 0 <= pos_i < max_seq:
+            raise ValueError(f"pos {pos_i} outside the cache (max_seq={max_seq})")
+    _lib.check(_lib.load().amq_attn_decode_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(kcache), _lib.ptr(vcache),
+                                               _lib.ptr(out), pos_dev, pos_i, B, n_heads, n_kv_heads, 128, max_seq,
+                                               ctypes.c_float(rope_theta), _lib.current_stream()))
+    return out

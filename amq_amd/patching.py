@@ -1,0 +1,157 @@
+"""prepare_for_inference / patch_linearlayers -- the reference's plug-in API
+(hqq/utils/patching.py:39-49, 143-223) for the HIP backend.
+
+    prepare_for_inference(model, backend="hip", load_path=None)
+
+walks ``named_children`` and replaces every HQQLinear by a HIPQuantLinear, with
+the reference's cache-file behaviour (patching.py:178-208): if ``load_path`` is
+given and missing, the patched ``model.state_dict()`` is saved there; if it
+exists, empty modules are created and the state dict is loaded instead of
+re-packing.  ``backend="gptq"`` and ``backend="ft"`` are accepted as aliases so
+that ``amq_speed_benchmark.py:137-139`` runs unchanged: both produce
+HIPQuantLinear modules (one class serves 2/3/4 bit).
+
+Reference caches written by the CUDA build (``*_GPTQLinear.pt`` / ``*_FTLinear.pt``,
+keys ``<module>.qweight|scales|zeros`` and ``<module>.qweight|scales|scaled_zeros``)
+are imported with ``load_reference_cache``.
+"""
+import os
+
+import torch
+
+from .hqq_format import HQQWeights, from_hqq_layer
+from .quant_linear import HIPQuantLinear
+
+HIP_BACKENDS = ("hip", "gptq", "ft")
+
+
+def is_hqq_layer(layer):
+    """HQQLinear / HQQLinearLoRA of the reference (quantize.py:387, peft.py) by
+    duck typing -- this package never imports the reference."""
+    if isinstance(layer, HQQWeightsModule):
+        return True
+    cls = type(layer).__name__
+    if cls == "HQQLinear":
+        return hasattr(layer, "W_q") and hasattr(layer, "meta")
+    if cls == "HQQLinearLoRA":
+        return hasattr(layer, "linear_layer")
+    return False
+
+
+class HQQWeightsModule(torch.nn.Module):
+    """Minimal stand-in for HQQLinear holding an HQQWeights (used by the
+    synthetic-model builders and tests; real HQQLinear objects work as well)."""
+
+    def __init__(self, weights: HQQWeights):
+        super().__init__()
+        self.weights = weights
+        self.W_q = weights.W_q
+        self.meta = weights.meta
+        self.bias = weights.bias
+        self.name = weights.name
+        self.device = weights.W_q.device
+
+
+def patch_linearlayers(model, fct, patch_param=None, verbose=False):
+    """patching.py:39-49: recursive named_children walk; sets ``layer.name``."""
+
+    def _patch_linear(mod):
+        for name, layer in mod.named_children():
+            if is_hqq_layer(layer):
+                layer.name = name
+                setattr(mod, name, fct(layer, patch_param))
+            else:
+                _patch_linear(layer)
+
+    _patch_linear(model)
+
+
+def _inner(layer):
+    return layer.linear_layer if type(layer).__name__ == "HQQLinearLoRA" else layer
+
+
+def patch_hqq_to_hip(layer, patch_params=None, load=False):
+    """Counterpart of patch_hqq_to_gptq / patch_hqq_to_ft (autogptq.py:291-341,
+    ft.py:148-197): HQQLinear -> HIPQuantLinear on the layer's device."""
+    if not is_hqq_layer(layer):
+        return layer
+    hqq_layer = _inner(layer)
+    h = hqq_layer.weights if isinstance(hqq_layer, HQQWeightsModule) else from_hqq_layer(hqq_layer)
+    h.name = getattr(hqq_layer, "name", None) or getattr(layer, "name", None)
+    n, k = h.shape
+    device = (patch_params or {}).get("device", None) or h.W_q.device
+    if load:
+        new = HIPQuantLinear(h.nbits, h.group_size, k, n, bias=h.bias, name=h.name).to(device)
+    else:
+        new = HIPQuantLinear.from_hqq(h, device=device)
+    if type(layer).__name__ == "HQQLinearLoRA":
+        layer.linear_layer = new
+        return layer
+    return new
+
+
+def patch_hqq_to_hip_load(layer, patch_params=None):
+    return patch_hqq_to_hip(layer, patch_params, load=True)
+
+
+def patch_add_weight_param(layer, patch_param):
+    """patching.py:76-91: dummy ``.weight`` so HF code can query dtype/device."""
+    if isinstance(layer, HIPQuantLinear) and not hasattr(layer, "weight"):
+        layer.weight = torch.nn.Parameter(torch.zeros((1,), device=layer.qweight.device, dtype=torch.float16),
+                                          requires_grad=False)
+    return layer
+
+
+def _walk_hip(model, fct):
+    for name, layer in model.named_children():
+        if isinstance(layer, HIPQuantLinear):
+            setattr(model, name, fct(layer, None))
+        else:
+            _walk_hip(layer, fct)
+
+
+def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False, load_path=None):
+    """patching.py:143-223 for the HIP backend."""
+    if backend not in HIP_BACKENDS:
+        raise RuntimeError(f"backend '{backend}' is not available in amq_amd (use one of {HIP_BACKENDS})")
+    if allow_merge:
+        raise NotImplementedError("allow_merge (LoRA zero merging) is not part of the AMQ speed path")
+    if load_path is not None and os.path.exists(load_path) is False:
+        patch_linearlayers(model, patch_hqq_to_hip, verbose=verbose)
+        print("Saving the model to", load_path)
+        torch.save(model.state_dict(), load_path)
+    elif load_path is not None and os.path.exists(load_path) is True:
+        patch_linearlayers(model, patch_hqq_to_hip_load, verbose=verbose)
+        print("Loading the model from", load_path)
+        model.load_state_dict(torch.load(load_path, weights_only=True))
+    else:
+        print("No load_path provided, using the model as is")
+        patch_linearlayers(model, patch_hqq_to_hip, verbose=verbose)
+    _walk_hip(model, patch_add_weight_param)
+    return model
+
+
+def load_reference_cache(state_dict, device="cuda"):
+    """Import a backend cache written by the reference's CUDA build
+    (patching.py:182-189 / 198-205).  Returns {module_prefix: HIPQuantLinear}.
+
+    GPTQLinear entries: ``<p>.qweight`` int32, ``<p>.scales``/``<p>.zeros`` fp32;
+    FT_QuantLinear entries: ``<p>.qweight`` int16, ``<p>.scales``/``<p>.scaled_zeros`` fp16."""
+    out = {}
+    prefixes = sorted({k[: -len(".qweight")] for k in state_dict if k.endswith(".qweight")})
+    for p in prefixes:
+        qw = state_dict[p + ".qweight"].to(device)
+        bias = state_dict.get(p + ".bias")
+        bias = None if bias is None else bias.to(device)
+        if qw.dtype == torch.int16:
+            out[p] = HIPQuantLinear.from_ft_buffers(qw, state_dict[p + ".scales"].to(device),
+                                                    state_dict[p + ".scaled_zeros"].to(device), bias=bias, name=p.split(".")[-1])
+        elif qw.dtype == torch.int32:
+            scales = state_dict[p + ".scales"].to(device)
+            k_over_g, n = scales.shape
+            bits = qw.shape[0] * 32 // (k_over_g * 128)
+            out[p] = HIPQuantLinear.from_gptq_buffers(qw, scales, state_dict[p + ".zeros"].to(device), bits, bias=bias,
+                                                      name=p.split(".")[-1])
+        else:
+            raise ValueError(f"{p}.qweight: unexpected dtype {qw.dtype}")
+    return out

@@ -1,0 +1,147 @@
+"""HIPQuantLinear -- drop-in for the reference's two kernel-backed modules
+
+    GPTQLinear      hqq/backends/autogptq.py:27-288   (2/3-bit, auto_gptq kernels)
+    FT_QuantLinear  hqq/backends/ft.py:57-145         (4-bit, faster_transformer kernels)
+
+Same surface: attributes ``bits, group_size, infeatures, outfeatures, bias,
+name``; weights live in registered buffers so ``model.to(device)``,
+``state_dict()/load_state_dict()`` and ``copy.deepcopy`` (amq_speed_benchmark.py:231)
+work; ``forward(x)`` takes fp16 with any leading dims and returns
+``x.shape[:-1] + (outfeatures,)`` with bias added.  One class serves all three
+bit-widths: the weights are held in the MI355X-native AMQ-T16 layout
+ and every forward goes through libamq_hip.so -- few rows take the
+weight-streaming GEMV, many rows the tiled MFMA GEMM (the reference switches at
+rows < 128, autogptq.py:163, and tokens < 8, ft.py:129).  There is no eager /
+CPU fallback: without a GPU or the built library, forward raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .hqq_format import GROUP, HQQWeights, from_hqq_layer, pack_rows
+
+
+class HIPQuantLinear(nn.Module):
+    QUANT_TYPE = "hip-amq-t16"
+
+    def __init__(self, bits, group_size, infeatures, outfeatures, bias=False, name=None,
+                 mode=ops.MODE_HQQ, weight_dtype=torch.float16):
+        super().__init__()
+        if bits not in [2, 3, 4]:
+            raise NotImplementedError("Only 2,3,4 bits are supported.")     # autogptq.py:44-45
+        group_size = group_size if group_size != -1 else infeatures
+        if group_size != GROUP:
+            raise NotImplementedError("Only group_size 128 is supported.")   # the only size AMQ produces
+        if infeatures % 128 or outfeatures % 16:
+            raise ValueError(f"need infeatures % 128 == 0 and outfeatures % 16 == 0 (got {infeatures}, {outfeatures})")
+        assert weight_dtype == torch.float16, "Only fp16 is supported."      # ft.py:62
+        self.bits = bits
+        self.group_size = group_size
+        self.infeatures = infeatures
+        self.outfeatures = outfeatures
+        self.maxq = 2 ** bits - 1
+        self.mode = mode
+        self.name = name
+        self.register_buffer("qweight", torch.zeros(infeatures * outfeatures * bits // 32, dtype=torch.int32))
+        self.register_buffer("meta", torch.zeros(infeatures // GROUP * outfeatures * 2, dtype=torch.float16))
+        # dequant arithmetic travels with the weights (0: (q - z) * s two roundings, 1: fma(q, s, c))
+        self.register_buffer("mode_flag", torch.tensor([mode], dtype=torch.int32))
+        if bias is not None and bias is not False:
+            self.register_buffer("bias", torch.zeros(outfeatures, dtype=weight_dtype))
+            if isinstance(bias, torch.Tensor):
+                self.bias.copy_(bias.detach().to(weight_dtype))
+        else:
+            self.bias = None
+
+    # ------------------------------------------------------------------ build
+    def _set_native(self, qn, mn, mode):
+        self.qweight = qn
+        self.meta = mn
+        self.mode = mode
+        self.mode_flag = torch.tensor([mode], dtype=torch.int32, device=qn.device)
+        if self.bias is not None:
+            self.bias = self.bias.to(qn.device)
+
+    @classmethod
+    def from_hqq(cls, hqq, device=None):
+        """From an HQQLinear (reference object, duck-typed) or HQQWeights."""
+        h = hqq if isinstance(hqq, HQQWeights) else from_hqq_layer(hqq)
+        n, k = h.shape
+        dev = torch.device(device) if device is not None else h.W_q.device
+        if dev.type != "cuda":
+            raise RuntimeError("HIPQuantLinear.from_hqq needs a GPU device (repack runs as a HIP kernel)")
+        mod = cls(h.nbits, h.group_size, k, n, bias=h.bias, name=h.name)
+        qn, mn = ops.repack_from_hqq(h.W_q.to(dev).contiguous(), h.scale.to(dev).reshape(-1).contiguous(),
+                                     h.zero.to(dev).reshape(-1).contiguous(), h.nbits, n, k)
+        mod._set_native(qn, mn, ops.MODE_HQQ)
+        return mod
+
+    @classmethod
+    def from_gptq_buffers(cls, qweight, scales, zeros, bits, bias=None, name=None):
+        """From GPTQLinear buffers (autogptq.py:55-75): qweight int32 [K/32*bits, N],
+        scales / zeros fp32 [K/G, N].  Keeps the reference kernels' arithmetic
+        w = fma(q, s, -zeros) (auto_gptq_kernel.cu:206)."""
+        n = qweight.shape[1]
+        k = qweight.shape[0] * 32 // bits
+        mod = cls(bits, GROUP, k, n, bias=bias, name=name, mode=ops.MODE_FMA)
+        qn, mn = ops.repack_from_gptq(qweight.contiguous(), scales.contiguous(), zeros.contiguous(), bits, n, k)
+        mod._set_native(qn, mn, ops.MODE_FMA)
+        return mod
+
+    @classmethod
+    def from_ft_buffers(cls, qweight, scales, scaled_zeros, bias=None, name=None):
+        """From FT_QuantLinear buffers (ft.py:75-88): qweight int16 [N/4, K],
+        scales / scaled_zeros fp16 [K/G, N].  w = fma(q, s, scaled_zeros) (gemv_cuda.cu:151)."""
+        k = qweight.shape[1]
+        n = qweight.shape[0] * 4
+        mod = cls(4, GROUP, k, n, bias=bias, name=name, mode=ops.MODE_FMA)
+        qn, mn = ops.repack_from_awq(qweight.contiguous(), scales.contiguous(), scaled_zeros.contiguous(), n, k)
+        mod._set_native(qn, mn, ops.MODE_FMA)
+        return mod
+
+    def pack(self, W, scales, zeros):
+        """Signature of GPTQLinear.pack / FT_QuantLinear.pack (autogptq.py:111,
+        ft.py:103): W = dequantized weight [N,K], scales / zeros = HQQ meta
+        reshaped to [N, K/G].  The integers are recovered exactly as the
+        reference does, ``round((W + z*s) / s)`` (autogptq.py:120), then packed
+        on the GPU; the raw fp16 (scale, zero) are kept, so the module
+        dequantizes like HQQ itself ((q - z) * s), not like the kernels' fma."""
+        if W.device.type != "cuda":
+            raise RuntimeError("HIPQuantLinear.pack needs GPU tensors")
+        n, k = self.outfeatures, self.infeatures
+        scale_zeros = zeros * scales
+        s_rep = torch.repeat_interleave(scales, self.group_size, dim=1)
+        sz_rep = torch.repeat_interleave(scale_zeros, self.group_size, dim=1)
+        intweight = torch.round((W + sz_rep) / s_rep).to(torch.int32).clamp_(0, self.maxq)
+        W_q = pack_rows(intweight.reshape(-1, self.group_size), self.bits)
+        qn, mn = ops.repack_from_hqq(W_q.contiguous(), scales.to(torch.float16).reshape(-1).contiguous(),
+                                     zeros.to(torch.float16).reshape(-1).contiguous(), self.bits, n, k)
+        self._set_native(qn, mn, ops.MODE_HQQ)
+
+    def post_init(self):
+        pass
+
+    # ---------------------------------------------------------------- forward
+    def _mode(self):
+        return self.mode
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self.mode = int(self.mode_flag.item())
+
+    def forward(self, x):
+        x_dtype = x.dtype
+        if x_dtype != torch.float16:
+            # the reference casts (with a warning) too: autogptq.py:166-169
+            x = x.to(torch.float16)
+        out = ops.linear(x, self.qweight, self.meta, self.bits, self.mode, self.outfeatures, self.infeatures,
+                         bias=self.bias)
+        return out if x_dtype == torch.float16 else out.to(x_dtype)
+
+    def dequantize(self):
+        """W[N,K] fp16 exactly as Quantizer.dequantize would give it (MODE_HQQ)."""
+        return ops.dequantize(self.qweight, self.meta, self.bits, self.mode, self.outfeatures, self.infeatures)
+
+    def extra_repr(self):
+        return (f"in_features={self.infeatures}, out_features={self.outfeatures}, bits={self.bits}, "
+                f"group_size={self.group_size}, bias={self.bias is not None}, mode={self.mode}")

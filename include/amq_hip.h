@@ -59,7 +59,8 @@ const char* amq_last_error(void);
 
 /* process-wide tuning / A-B knobs (not needed for normal use) */
 #define AMQ_OPT_GEMV_DOT   1       /* 1: M == 1 runs the v_dot2c + wavefront-shuffle body instead of the MFMA body */
-#define AMQ_OPT_GEMV_WAVES 2       /* waves per GEMV workgroup: 0 = auto (default), 4, 8 or 16 */
+#define AMQ_OPT_GEMV_WAVES 2       /* waves per GEMV workgroup: 0 = auto (default), 2, 4, 8 or 16 */
+#define AMQ_OPT_GEMV_DEPTH 3       /* tile loads in flight per wave: 0 = auto (default), 2 or 4 */
 int amq_set_option(int option, int value);
 
 /* capabilities: writes up to `cap` ints {max_gemv_rows_for_K, lds_bytes, ...}; returns the count */
@@ -124,6 +125,19 @@ typedef struct amq_segment {
 int amq_gemv_grouped_f16(const amq_segment* segments /* host */, int nseg,
                          const void* x, const void* x2, const void* gamma, float eps, int prologue,
                          int M, int K, int group, int x_stride, void* stream);
+
+/* ---- decode-step surroundings (next tier: what sits between the linears in one token step) ---- */
+/* y = gamma * fp16(x * rsqrt(mean(x^2) + eps)), rows of K; replaces FT layernorm_forward_cuda (ft/layernorm/layernorm.cu:25-77) */
+int amq_rmsnorm_f16(const void* x, const void* gamma, void* y, int M, int K, float eps, void* stream);
+/* y[N] = (optionally RMSNorm'ed) x[K] . W^T for fp16 W[N,K] (lm_head), K % 512 == 0; gamma NULL = no norm */
+int amq_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
+                  int N, int K, void* stream);
+/* one new token per sequence: RoPE(q, k) at position *pos_dev (or pos if pos_dev is NULL), append k/v to the
+ * cache [B, n_kv_heads, max_seq, 128], out = softmax(q K^T / sqrt(128)) V.  head_dim must be 128.
+ * Replaces FT single_query_attention (ft/attention/decoder_masked_multihead_attention.cu:30-61) with HF-Llama numerics. */
+int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcache, void* vcache, void* out,
+                        const int* pos_dev, int pos, int batch, int n_heads, int n_kv_heads, int head_dim,
+                        int max_seq, float rope_theta, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,162 @@
+"""GPU: decode-step surroundings and the token-step runner vs plain torch references."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rms_ref(x, g, eps):
+    xf = x.float()
+    return g * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(torch.float16)
+
+
+def test_rmsnorm_matches_llama_rmsnorm():
+    from amq_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(5, 4096, generator=g) * 3).half().to(_dev())
+    gamma = (1 + 0.1 * torch.randn(4096, generator=g)).half().to(_dev())
+    y = ops.rmsnorm(x, gamma, 1e-5)
+    ref = _rms_ref(x, gamma, 1e-5)
+    assert torch.allclose(y.float(), ref.float(), rtol=2e-3, atol=2e-3)
+    assert (y != ref).float().mean() < 0.02          # same two-rounding arithmetic; rsqrt/sum order may flip an ulp
+
+
+@pytest.mark.parametrize("norm", [False, True])
+def test_gemv_f16w(norm):
+    from amq_amd import ops
+    g = torch.Generator().manual_seed(1)
+    n, k = 1000, 1024
+    w = (torch.randn(n, k, generator=g) * 0.03).half().to(_dev())
+    x = torch.randn(k, generator=g).half().to(_dev())
+    gamma = (1 + 0.1 * torch.randn(k, generator=g)).half().to(_dev())
+    y = ops.gemv_f16w(x, w, gamma=gamma if norm else None, eps=1e-5)
+    xin = _rms_ref(x[None], gamma, 1e-5)[0] if norm else x
+    ref = (w.double() @ xin.double())
+    err = (y.double() - ref).abs()
+    assert torch.all(err <= 1e-3 * ref.abs() + 1e-3 * ref.pow(2).mean().sqrt())
+
+
+def _rope_ref(t, pos):
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32, device=t.device) / 128.0))
+    fr = torch.tensor([float(pos)], device=t.device)[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos().half(), emb.sin().half()
+    rot = torch.cat([-t[..., 64:], t[..., :64]], -1)
+    return t * cos + rot * sin
+
+
+@pytest.mark.parametrize("nh,nkv", [(4, 4), (8, 2)])
+def test_attn_decode_sequence(nh, nkv):
+    """feed tokens one by one; compare each step with eager HF-style attention over the running cache"""
+    from amq_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    max_seq = 48
+    kc = torch.zeros(1, nkv, max_seq, 128, dtype=torch.float16, device=dev)
+    vc = torch.zeros_like(kc)
+    out = torch.zeros(1, nh * 128, dtype=torch.float16, device=dev)
+    ks, vs = [], []
+    posd = torch.zeros(1, dtype=torch.int32, device=dev)
+    for pos in range(40):
+        q = torch.randn(1, nh, 128, generator=g).half().to(dev)
+        k = torch.randn(1, nkv, 128, generator=g).half().to(dev)
+        v = torch.randn(1, nkv, 128, generator=g).half().to(dev)
+        if pos % 2:
+            posd.fill_(pos)
+            ops.attn_decode(q.reshape(1, -1), k.reshape(1, -1), v.reshape(1, -1), kc, vc, out, posd, nh, nkv)
+        else:
+            ops.attn_decode(q.reshape(1, -1), k.reshape(1, -1), v.reshape(1, -1), kc, vc, out, pos, nh, nkv)
+        ks.append(_rope_ref(k[0], pos)); vs.append(v[0])
+        K = torch.stack(ks, 1).repeat_interleave(nh // nkv, 0)     # [nh, T, 128]
+        V = torch.stack(vs, 1).repeat_interleave(nh // nkv, 0)
+        qr = _rope_ref(q[0], pos)                                   # [nh, 128]
+        w = (torch.matmul(qr[:, None, :], K.transpose(1, 2)) * (128 ** -0.5))
+        p = torch.softmax(w.float(), -1).half()
+        ref = torch.matmul(p, V)[:, 0, :].reshape(-1)
+        assert torch.allclose(out[0].float(), ref.float(), rtol=1e-2, atol=3e-3), (pos, (out[0].float() - ref.float()).abs().max())
+        # the cache holds the rotated keys / raw values
+        assert torch.equal(kc[0, :, pos], ks[-1]) and torch.equal(vc[0, :, pos], vs[-1])
+
+
+def _ref_model(m):
+    """dense fp16 torch mirror of a QuantLlama (weights dequantized by the bit-exact dequantize kernel)"""
+    from amq_amd import ops
+    blocks = []
+    for blk in m.blocks:
+        d = {}
+        for name in m.cfg["linear"]:
+            l = blk[name]
+            d[name] = ops.dequantize(l.qn, l.mn, l.bits, l.mode, l.N, l.K)
+        d["ln1"], d["ln2"] = blk["ln1"], blk["ln2"]
+        blocks.append(d)
+    return blocks
+
+
+def _ref_forward(m, blocks, ids):
+    """HF-Llama-style eager forward of the whole prefix (fp16 linears, fp32 softmax); returns last-token logits"""
+    import torch.nn.functional as F
+    S = ids.numel()
+    x = m.embed.index_select(0, ids)
+    pos = torch.arange(S, device=ids.device)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32, device=ids.device) / 128.0))
+    emb = torch.cat([pos.float()[:, None] * inv[None], pos.float()[:, None] * inv[None]], -1)
+    cos, sin = emb.cos().half()[:, None], emb.sin().half()[:, None]
+
+    def rope(t):
+        return t * cos + torch.cat([-t[..., 64:], t[..., :64]], -1) * sin
+
+    for d in blocks:
+        h = _rms_ref(x, d["ln1"], 1e-5)
+        q = rope(F.linear(h, d["self_attn.q_proj"]).view(S, m.nh, 128)).transpose(0, 1)
+        k = rope(F.linear(h, d["self_attn.k_proj"]).view(S, m.nkv, 128)).transpose(0, 1).repeat_interleave(m.nh // m.nkv, 0)
+        v = F.linear(h, d["self_attn.v_proj"]).view(S, m.nkv, 128).transpose(0, 1).repeat_interleave(m.nh // m.nkv, 0)
+        w = torch.matmul(q, k.transpose(1, 2)) * (128 ** -0.5)
+        w = w + torch.full((S, S), float("-inf"), device=ids.device).triu(1).half()
+        a = torch.matmul(torch.softmax(w.float(), -1).half(), v).transpose(0, 1).reshape(S, m.H)
+        x = x + F.linear(a, d["self_attn.o_proj"])
+        h2 = _rms_ref(x, d["ln2"], 1e-5)
+        x = x + F.linear(F.silu(F.linear(h2, d["mlp.gate_proj"])) * F.linear(h2, d["mlp.up_proj"]), d["mlp.down_proj"])
+    return F.linear(_rms_ref(x[-1:], m.norm, 1e-5), m.lm_head)[0]
+
+
+@pytest.mark.parametrize("gqa", [False, True])
+def test_token_step_runner_matches_dense_reference(gqa):
+    """prefill (MFMA GEMM path) + graph-replayed decode steps (GEMV path) reproduce a dense fp16
+    HF-style forward with the same (bit-exactly dequantized) weights."""
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 2 if gqa else 4, 1, vocab=1024))
+    rng = np.random.default_rng(0)
+    al = {name: [int(b) for b in rng.choice([2, 3, 4], size=2)] for name in cfg["linear"]}
+    m = QuantLlama(cfg, al, device="cuda:0", max_seq=64, seed=3)
+    blocks = _ref_model(m)
+    ids = torch.randint(0, 1024, (12,), generator=torch.Generator().manual_seed(5)).to(_dev())
+    logits = m.prefill(ids).clone()
+    ref = _ref_forward(m, blocks, ids)
+    scale = ref.float().abs().max()
+    assert (logits.float() - ref.float()).abs().max() <= 2e-2 * scale
+    seq = ids.clone()
+    for step in range(6):
+        tok = m.token.clone()
+        seq = torch.cat([seq, tok])
+        m.decode_step(use_graph=(step >= 2))        # eager launches first, then hipGraph replays
+        ref = _ref_forward(m, blocks, seq)
+        assert (m.logits.float() - ref.float()).abs().max() <= 2e-2 * scale, step
+        assert int(m.pos.item()) == seq.numel()
+
+
+def test_generate_is_deterministic_and_graph_equals_eager():
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 4, 1, vocab=1024))
+    m = QuantLlama(cfg, None, device="cuda:0", max_seq=64, seed=1)
+    ids = torch.arange(10, device=_dev())
+    a = m.generate(ids, 12, use_graph=True).clone()
+    m.reset()
+    b = m.generate(ids, 12, use_graph=False).clone()
+    assert torch.equal(a, b)

@@ -66,11 +66,13 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--dot", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--gemm", type=int, default=1)
     args = ap.parse_args()
     from amq_amd import _lib
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DOT, args.dot))
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_WAVES, args.waves))
+    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DEPTH, args.depth))
     shapes = [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096)]
     if args.quick:
         shapes = shapes[:2]
