@@ -152,13 +152,23 @@ hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void
 // scores and softmax in fp32; probabilities cast to fp16 before P.V (eager attention path).
 constexpr int ATT_D = 128;
 
+// cos/sin of (pos * theta^(-2i/128)), i = 0..63, as fp16 -- the values HF's rotary embedding feeds
+// apply_rotary_pos_emb.  Computed by lanes 0..63 (accurate sincosf; one call per lane).
+__device__ __forceinline__ void rope_cs(float theta, int pos, int i, _Float16* c16, _Float16* s16) {
+    const float inv_freq = 1.0f / powf(theta, (float)(2 * i) / (float)ATT_D);   // LlamaRotaryEmbedding: 1 / base^(2i/d), fp32
+    float sn, cs;
+    sincosf((float)pos * inv_freq, &sn, &cs);
+    *c16 = (_Float16)cs;
+    *s16 = (_Float16)sn;
+}
+
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* qs = (_Float16*)smem;                 // [128] rotated q
     _Float16* ks = (_Float16*)smem + ATT_D;         // [128] rotated new key (also what is appended)
     float* sc = (float*)(smem + 4 * ATT_D);         // [T] scores / probabilities
     __shared__ float red[8];
-    __shared__ float part[2][ATT_D];
+    __shared__ float part[16][ATT_D];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int pos = a.pos_dev ? *a.pos_dev : a.pos;
     const int T = pos + 1;
@@ -170,12 +180,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     _Float16* kc = (_Float16*)a.kcache + ((size_t)b * a.n_kv_heads + kvh) * (size_t)a.max_seq * ATT_D;
     _Float16* vc = (_Float16*)a.vcache + ((size_t)b * a.n_kv_heads + kvh) * (size_t)a.max_seq * ATT_D;
 
+    // every thread fetches its cached key row while wave 0 rotates q / k: one key per thread per pass
+    h8 krow[16];
+    const int t_own = tid;
+    if (t_own < pos) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) krow[j] = *(const h8*)(kc + (size_t)t_own * ATT_D + 8 * j);
+    }
     if (tid < 64) {
         const int i = tid;                          // rotary pair (i, i + 64)
-        const float inv_freq = powf(a.rope_theta, -(float)(2 * i) / (float)ATT_D);
-        float sn, cs;
-        sincosf((float)pos * inv_freq, &sn, &cs);
-        const _Float16 c16 = (_Float16)cs, s16 = (_Float16)sn;
+        _Float16 c16, s16;
+        rope_cs(a.rope_theta, pos, i, &c16, &s16);
         const _Float16 q0 = q[i], q1 = q[i + 64];
         qs[i] = q0 * c16 + (-q1) * s16;             // q*cos + rotate_half(q)*sin  (fp16 ops, HF apply_rotary_pos_emb)
         qs[i + 64] = q1 * c16 + q0 * s16;
@@ -192,29 +207,25 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     }
     __syncthreads();
 
-    // scores: 4 lanes per key (32 dims each), 64 keys per pass; the new key comes from LDS
+    // scores: one key per thread (the new key comes from LDS)
     const float scale = rsqrtf((float)ATT_D);
-    const int sub = tid & 3;
     float lmax = -INFINITY;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        const int t = t0 + (tid >> 2);
+    for (int t = tid; t < T; t += 256) {
         float s = 0.f;
-        if (t < T) {
-            const _Float16* kr = (t == pos) ? (ks + 32 * sub) : (kc + (size_t)t * ATT_D + 32 * sub);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const h8 kv = *(const h8*)(kr + 8 * j);
-                const h8 qv = *(const h8*)(qs + 32 * sub + 8 * j);
+        for (int j = 0; j < 16; ++j) {
+            h8 kv;
+            if (t == pos) kv = *(const h8*)(ks + 8 * j);
+            else if (t == t_own) kv = krow[j];
+            else kv = *(const h8*)(kc + (size_t)t * ATT_D + 8 * j);
+            const h8 qv = *(const h8*)(qs + 8 * j);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += (float)qv[e] * (float)kv[e];
-            }
+            for (int e = 0; e < 8; ++e) s += (float)qv[e] * (float)kv[e];
         }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
         // HF eager attention: matmul(q, k^T) -> fp16, * scaling -> fp16, softmax in fp32
-        const _Float16 s16v = (_Float16)((float)(_Float16)s * scale);
-        if (t < T && sub == 0) sc[t] = (float)s16v;
-        if (t < T) lmax = fmaxf(lmax, (float)s16v);
+        const float sv = (float)(_Float16)((float)(_Float16)s * scale);
+        sc[t] = sv;
+        lmax = fmaxf(lmax, sv);
     }
     lmax = wave_max_f(lmax);
     if ((tid & 63) == 0) red[tid >> 6] = lmax;
@@ -231,19 +242,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     __syncthreads();
     const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
 
-    // out[d] = sum_t p_t * V[t][d]; thread = (d, half of the keys)
-    const int d = tid & 127, half = tid >> 7;
-    float o = 0.f;
-    for (int t = half; t < T; t += 2) {
+    // out = sum_t p_t * V[t]: 16 key groups x 16 lanes, 8 dims (16 B) per lane
+    const int kg = tid >> 4, l = tid & 15;
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = kg; t < T; t += 16) {
         const _Float16 p16 = (_Float16)(sc[t] * inv);            // softmax(...).to(fp16)
-        const _Float16 vv = (t == pos) ? vn[d] : vc[(size_t)t * ATT_D + d];
-        o += (float)p16 * (float)vv;
+        const h8 vv = (t == pos) ? *(const h8*)(vn + 8 * l) : *(const h8*)(vc + (size_t)t * ATT_D + 8 * l);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += (float)p16 * (float)vv[e];
     }
-    part[half][d] = o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[kg][8 * l + e] = o[e];
     __syncthreads();
     if (tid < ATT_D) {
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) tot += part[g][tid];
         _Float16* out = (_Float16*)a.out + ((size_t)b * a.n_heads + h) * ATT_D;
-        out[tid] = (_Float16)(part[0][tid] + part[1][tid]);
+        out[tid] = (_Float16)tot;
     }
 }
 

@@ -17,6 +17,9 @@ from amq_amd import ops  # noqa: E402
 from amq_amd.hqq_format import random_hqq  # noqa: E402
 
 
+HOT = False
+
+
 def layer_bytes(n, k, bits, m=1):
     return n * k * bits // 8 + 4 * n * k // 128 + 2 * m * k + 2 * m * n
 
@@ -27,6 +30,8 @@ def bench_case(n, k, bits, m, iters, fn_name="gemv"):
     qn0, mn0 = ops.repack_from_hqq(h.W_q, h.scale.reshape(-1), h.zero.reshape(-1), bits, n, k)
     per = qn0.numel() * 4 + mn0.numel() * 2
     copies = max(2, min(64, (768 << 20) // per + 1))
+    if HOT:
+        copies = 1
     bufs = [(qn0.clone(), mn0.clone()) for _ in range(copies)]
     x = torch.randn(m, k, device=dev).half()
     y = torch.empty(m, n, device=dev, dtype=torch.float16)
@@ -68,7 +73,10 @@ def main():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--gemm", type=int, default=1)
+    ap.add_argument("--hot", type=int, default=0, help="1: a single weight buffer (stays in L2 / Infinity Cache)")
     args = ap.parse_args()
+    global HOT
+    HOT = bool(args.hot)
     from amq_amd import _lib
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DOT, args.dot))
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_WAVES, args.waves))
