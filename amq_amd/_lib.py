@@ -16,7 +16,8 @@ AMQ_OK = 0
 MODE_HQQ, MODE_FMA = 0, 1
 PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
-OPT_GEMV_DOT, OPT_GEMV_WAVES, OPT_GEMV_DEPTH = 1, 2, 3
+OPT_GEMV_DOT, OPT_GEMV_WAVES, OPT_GEMV_DEPTH, OPT_GEMV_RPT, OPT_GEMV_MATH = 1, 2, 3, 4, 5
+MATH_EXACT, MATH_LINEAR = 0, 1
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 

@@ -41,6 +41,8 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 int g_opt_dot = 0;
 int g_opt_waves = 0;
 int g_opt_depth = 0;
+int g_opt_rpt = 0;
+int g_opt_math = 0;
 
 }  // namespace
 
@@ -52,13 +54,23 @@ const char* amq_last_error(void) { return g_err; }
 int amq_set_option(int option, int value) {
     if (option == AMQ_OPT_GEMV_DOT) { g_opt_dot = value ? 1 : 0; return AMQ_OK; }
     if (option == AMQ_OPT_GEMV_WAVES) {
-        if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16) return fail(AMQ_EINVAL, "waves must be 0, 2, 4, 8 or 16");
+        if (value != 0 && value != 4 && value != 8 && value != 16) return fail(AMQ_EINVAL, "waves must be 0, 4, 8 or 16");
         g_opt_waves = value;
         return AMQ_OK;
     }
     if (option == AMQ_OPT_GEMV_DEPTH) {
         if (value != 0 && value != 2 && value != 4) return fail(AMQ_EINVAL, "depth must be 0, 2 or 4");
         g_opt_depth = value;
+        return AMQ_OK;
+    }
+    if (option == AMQ_OPT_GEMV_RPT) {
+        if (value < 0 || value > 64) return fail(AMQ_EINVAL, "row-tiles per workgroup must be 0..64");
+        g_opt_rpt = value;
+        return AMQ_OK;
+    }
+    if (option == AMQ_OPT_GEMV_MATH) {
+        if (value != AMQ_MATH_EXACT && value != AMQ_MATH_LINEAR) return fail(AMQ_EINVAL, "math must be AMQ_MATH_EXACT or AMQ_MATH_LINEAR");
+        g_opt_math = value;
         return AMQ_OK;
     }
     return fail(AMQ_EINVAL, "unknown option %d", option);
@@ -68,7 +80,7 @@ int amq_query(int K, int* out, int cap) {
     int vals[4];
     int maxm = 0;
     for (int m = 1; m <= amq::GEMV_MAX_M; ++m)
-        if (amq::gemv_lds_bytes(m, K) <= LDS_LIMIT) maxm = m;
+        if (amq::gemv_lds_bytes(m, K, 1) <= LDS_LIMIT) maxm = m;
     vals[0] = maxm;                 // largest M amq_gemv_f16 accepts for this K
     vals[1] = (int)LDS_LIMIT;
     vals[2] = amq::TILE_N;
@@ -124,10 +136,12 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     if (prologue == AMQ_PRO_RMSNORM && !gamma) return fail(AMQ_EINVAL, "RMSNorm prologue needs gamma");
     if (prologue == AMQ_PRO_SILU_MUL && !x2) return fail(AMQ_EINVAL, "SiLU*mul prologue needs x2");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
-    if (M > amq::GEMV_MAX_M || amq::gemv_lds_bytes(M, K) > LDS_LIMIT)
+    int bitmask = 0;
+    for (int i = 0; i < nseg; ++i) bitmask |= 1 << (segs[i].bits & 7);
+    const int copies = g_opt_math == AMQ_MATH_LINEAR ? __builtin_popcount(bitmask) : 1;
+    if (M > amq::GEMV_MAX_M || amq::gemv_lds_bytes(M, K, copies) > LDS_LIMIT)
         return fail(AMQ_ESHAPE, "M=%d rows of K=%d do not fit LDS for the GEMV path; use amq_gemm_f16", M, K);
     amq::GemvArgs a{};
-    int wg = 0;
     for (int i = 0; i < nseg; ++i) {
         const amq_segment& s = segs[i];
         if (int rc = check_shape(s.bits, s.N, K, group)) return rc;
@@ -135,16 +149,16 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
         if (!s.qweight_native || !s.meta_native || !s.y) return fail(AMQ_EINVAL, "segment %d: null pointer", i);
         amq::GemvSeg& d = a.seg[i];
         d.qweight = s.qweight_native; d.meta = s.meta_native; d.bias = s.bias; d.residual = s.residual; d.y = s.y;
-        d.N = s.N; d.bits = s.bits; d.mode = s.mode; d.wg_begin = wg;
+        d.N = s.N; d.bits = s.bits; d.mode = s.mode;
         d.y_stride = s.y_stride ? s.y_stride : s.N;
-        wg += s.N / 16;
     }
     a.nseg = nseg; a.M = M; a.K = K; a.x_stride = x_stride ? x_stride : K;
     a.x = x; a.x2 = x2; a.gamma = gamma; a.eps = eps; a.prologue = prologue;
-    a.flags = g_opt_dot ? amq::GEMV_FLAG_DOT : 0;
+    a.flags = (g_opt_dot ? amq::GEMV_FLAG_DOT : 0) | (g_opt_math == AMQ_MATH_LINEAR ? amq::GEMV_FLAG_LINEAR : 0);
     a.force_waves = g_opt_waves;
     a.force_depth = g_opt_depth;
-    return check_hip(amq::launch_gemv(a, wg, (hipStream_t)stream), "gemv");
+    a.force_rpt = g_opt_rpt;
+    return check_hip(amq::launch_gemv(a, (hipStream_t)stream), "gemv");
 }
 
 int amq_gemv_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
@@ -168,7 +182,7 @@ int amq_gemm_f16(int bits, int mode, const void* x, const void* qn, const void* 
 int amq_linear_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
                    int M, int N, int K, int group, void* stream) {
     // few rows: weight-streaming GEMV family; otherwise the tiled MFMA GEMM
-    if (M <= 8 && amq::gemv_lds_bytes(M, K) <= 64 * 1024)
+    if (M <= 8 && amq::gemv_lds_bytes(M, K, 1) <= 64 * 1024)
         return amq_gemv_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
     return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
 }

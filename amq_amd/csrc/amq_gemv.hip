@@ -5,32 +5,39 @@
 //   gemv_kernel<2,Batch,256,128>          (amq/kernel/ft/quantization_new/gemv/gemv_cuda.cu:73-204)
 // with one kernel family over the native AMQ-T16 layout (amq_common.cuh).
 //
-// Structure (HBM-bound by design: every byte of W is read exactly once):
-//   * one workgroup = 16 output rows x all of K; its weight bytes are one
-//     contiguous range.  NW waves (4 / 8 / 16, picked from the grid size) take
-//     the K/128 tiles round-robin.
-//   * each wave keeps U tile loads (16/12/8 B per lane, non-temporal) in flight
-//     in a rolling register ring: a slot is re-issued as soon as it has been
-//     consumed, and the first U leave BEFORE x is staged, so the HBM round trip
-//     overlaps the prologue.
-//   * x (optionally RMSNorm'ed or SiLU(gate)*up) is staged once in LDS as fp16;
-//     lanes read their 8-wide k-octets with ds_read_b128 (4 addresses per
-//     instruction, broadcast over 16 lanes -> conflict free).
-//   * the unpacked fp16x8 register block IS the MFMA B operand (layout chosen
-//     for that): v_mfma_f32_16x16x32_f16 against the x rows; W never touches
-//     LDS, the k-octet reduction happens inside the matrix core, and M = 1..16
-//     costs the same VALU work.  (M == 1 can alternatively run the
-//     v_dot2c_f32_f16 + wavefront-shuffle reduction body: GEMV_FLAG_DOT; it is
-//     slower on gfx950 because dot2c is a 4-cycle VOP3 issue -- DESIGN.md.)
-//   * fixed-order cross-wave sum through LDS: deterministic, no atomics.
+// Structure (every byte of W is read exactly once; see DESIGN.md for the measurements behind each choice):
+//   * a workgroup owns whole row-tiles (16 output rows x all of K, one contiguous
+//     byte range each) and walks rt = first, first + stride, ...; x is staged
+//     (RMSNorm / SiLU*mul fused) ONCE per workgroup, not once per row-tile.
+//   * its NW waves take the K/128 tiles of a row-tile round-robin.  Each wave keeps
+//     U tile loads (16/12/8 B per lane, non-temporal) in flight in a register ring
+//     that runs ACROSS row-tile boundaries and is primed before x is staged.
+//     A slot is refilled only after its tile is consumed (straight-line pipeline,
+//     counted vmcnt; the tail drains).
+//   * the unpacked fp16x8 register block IS the MFMA B operand (layout chosen for
+//     that): v_mfma_f32_16x16x32_f16 against x rows read from LDS with ds_read_b128.
+//     W never touches LDS; M = 1..16 cost the same VALU work.
+//   * MATH_EXACT  (default): scaled-subnormal unpack = the reference's two-rounding
+//                 dequant, 12 VALU cycles per weight pair (amq_common.cuh).
+//     MATH_DOT    (A/B only, M == 1): same weights, v_dot2c_f32_f16 + wavefront-shuffle
+//                 reduction instead of MFMA.
+//     MATH_LINEAR (opt-in): the masked field is fed to the MFMA as the fp16 subnormal
+//                 q*2^(sh-24) (gfx950 MFMA honours fp16 subnormals -- measured), x is staged
+//                 pre-scaled by 2^-sh, and scale / zero are applied per group in fp32:
+//                 y += s*(2^24*sum(x'q') - z*sum_g(x)).  2 VALU cycles per pair; results
+//                 are the real-valued dequant (no per-weight fp16 roundings), ~3e-4 of the
+//                 output rms away from the reference's rounded-weight result.
+//   * per row-tile, fixed-order cross-wave sum through double-buffered LDS and one
+//     barrier: deterministic, no atomics.
 //   * several linears that share x (q/k/v, gate/up) with different bit-widths
-//     run as segments of ONE launch (wave-uniform switch on bits).
+//     run as segments of ONE launch; a workgroup serves one segment.
 #include "amq_common.cuh"
 #include "amq_kernels.h"
 
 namespace amq {
 
 constexpr int XPAD = 8;              // halves of padding per staged x row (16 B)
+enum { MATH_EXACT = 0, MATH_DOT = 1, MATH_LINEAR = 2 };
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -40,39 +47,36 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + __expf(-g)); }
 
+// log2 of the pre-scale of x for MATH_LINEAR: field shift of pair P = 4*t + p of a lane (amq_common.cuh layout)
+__device__ __forceinline__ int lin_shift(int bits, int t, int p) {
+    const int P = 4 * t + p;
+    if (bits == 4) return (p & 1) ? 4 : 0;                       // fields 0,4 | (>>8) 0,4
+    if (bits == 2) { const int i = P & 7; return i < 5 ? 2 * i : 2 * (i - 5); }   // 0..8 | (>>10) 0,2,4
+    if (P == 15) return 0;                                       // 3-bit spare-bit pair, assembled at 0
+    const int i = P % 5;
+    return i < 3 ? 3 * i : 3 * (i - 3);                          // 0,3,6 | (>>9) 0,3
+}
+
 // ---------------------------------------------------------------- staging
-// Writes the (transformed) activations into LDS as fp16 [M][xs].
-template <int PRO, int NW>
-__device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* red, int xs) {
+// Writes the (transformed) activations into LDS as fp16.
+//   exact / dot : xl[m][xs]
+//   linear      : for every bit-width b in lin_mask a copy xl_b[m][xs] pre-scaled by 2^-shift, and
+//                 xg[m][G] = per-group sums of x (fp32)
+template <int PRO, int NW, bool LIN>
+__device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* xg, float* red, int xs) {
     constexpr int THREADS = NW * 64;
     const int tid = threadIdx.x;
     const int K = a.K;
     const int chunks = K >> 3;      // 8 halves per chunk
+    const size_t copy_stride = (size_t)a.M * xs;
     for (int m = 0; m < a.M; ++m) {
         const _Float16* xrow = (const _Float16*)a.x + (size_t)m * a.x_stride;
         _Float16* lrow = xl + (size_t)m * xs;
-        if (PRO == PRO_NONE) {
-            for (int c = tid; c < chunks; c += THREADS)
-                *(h8*)(lrow + 8 * c) = *(const h8*)(xrow + 8 * c);
-        } else if (PRO == PRO_SILU_MUL) {
-            // x = fp16(fp16(silu(gate)) * up)  -- HF LlamaMLP: act_fn(gate) * up
-            const _Float16* urow = (const _Float16*)a.x2 + (size_t)m * a.x_stride;
-            for (int c = tid; c < chunks; c += THREADS) {
-                h8 g = *(const h8*)(xrow + 8 * c);
-                h8 u = *(const h8*)(urow + 8 * c);
-                h8 r;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    _Float16 s = (_Float16)silu_f((float)g[i]);
-                    r[i] = s * u[i];
-                }
-                *(h8*)(lrow + 8 * c) = r;
-            }
-        } else {  // PRO_RMSNORM
+        float rstd = 1.0f;
+        if (PRO == PRO_RMSNORM) {
             float ss = 0.f;
             for (int c = tid; c < chunks; c += THREADS) {
                 h8 v = *(const h8*)(xrow + 8 * c);
-                *(h8*)(lrow + 8 * c) = v;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { float f = (float)v[i]; ss += f * f; }
             }
@@ -83,18 +87,48 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* 
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) tot += red[w];
-            const float rstd = rsqrtf(tot / (float)K + a.eps);
-            // HF LlamaRMSNorm: weight * (x.float() * rstd).to(fp16)
-            for (int c = tid; c < chunks; c += THREADS) {
-                h8 v = *(h8*)(lrow + 8 * c);
-                h8 gm = *(const h8*)((const _Float16*)a.gamma + 8 * c);
-                h8 r;
+            rstd = rsqrtf(tot / (float)K + a.eps);
+        }
+        for (int c = tid; c < chunks; c += THREADS) {
+            h8 v = *(const h8*)(xrow + 8 * c);
+            h8 r;
+            if (PRO == PRO_NONE) {
+                r = v;
+            } else if (PRO == PRO_SILU_MUL) {
+                // x = fp16(fp16(silu(gate)) * up)  -- HF LlamaMLP: act_fn(gate) * up
+                const h8 u = *(const h8*)((const _Float16*)a.x2 + (size_t)m * a.x_stride + 8 * c);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    _Float16 nrm = (_Float16)((float)v[i] * rstd);
-                    r[i] = gm[i] * nrm;
-                }
+                for (int i = 0; i < 8; ++i) { _Float16 s = (_Float16)silu_f((float)v[i]); r[i] = s * u[i]; }
+            } else {
+                // HF LlamaRMSNorm: weight * (x.float() * rstd).to(fp16)
+                const h8 gm = *(const h8*)((const _Float16*)a.gamma + 8 * c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { _Float16 nrm = (_Float16)((float)v[i] * rstd); r[i] = gm[i] * nrm; }
+            }
+            if (!LIN) {
                 *(h8*)(lrow + 8 * c) = r;
+            } else {
+                const int t = (c >> 2) & 3;
+                int slot = 0;
+#pragma unroll
+                for (int b = 2; b <= 4; ++b) {
+                    if (a.lin_mask & (1 << b)) {
+                        h8 q;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const _Float16 sc = (_Float16)(1.0f / (float)(1 << lin_shift(b, t, p)));
+                            q[2 * p] = r[2 * p] * sc;
+                            q[2 * p + 1] = r[2 * p + 1] * sc;
+                        }
+                        *(h8*)(lrow + slot * copy_stride + 8 * c) = q;
+                        ++slot;
+                    }
+                }
+                float cs = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cs += (float)r[i];
+                cs += __shfl_xor(cs, 1); cs += __shfl_xor(cs, 2); cs += __shfl_xor(cs, 4); cs += __shfl_xor(cs, 8);
+                if ((tid & 15) == 0) xg[(size_t)m * (K >> 7) + (c >> 4)] = cs;    // 16 chunks = one 128-k group
             }
         }
     }
@@ -108,46 +142,137 @@ __device__ __forceinline__ void store_out(const GemvSeg& s, int m, int n, float 
     ((_Float16*)s.y)[(size_t)m * s.y_stride + n] = y;
 }
 
+// and-only unpack for MATH_LINEAR: out[4t+p] = packed fp16 subnormals q * 2^(shift-24)
+template <int BITS>
+__device__ __forceinline__ void unpack_lane_sub(const uint32_t* w, h2* out) {
+    if (BITS == 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t u = w[t], v = u >> 8;
+            out[4 * t + 0] = as_h2(u & 0x000F000Fu);
+            out[4 * t + 1] = as_h2(u & 0x00F000F0u);
+            out[4 * t + 2] = as_h2(v & 0x000F000Fu);
+            out[4 * t + 3] = as_h2(v & 0x00F000F0u);
+        }
+    } else if (BITS == 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const uint32_t u = w[d], v = u >> 10;
+            out[8 * d + 0] = as_h2(u & 0x00030003u);
+            out[8 * d + 1] = as_h2(u & 0x000C000Cu);
+            out[8 * d + 2] = as_h2(u & 0x00300030u);
+            out[8 * d + 3] = as_h2(u & 0x00C000C0u);
+            out[8 * d + 4] = as_h2(u & 0x03000300u);
+            out[8 * d + 5] = as_h2(v & 0x00030003u);
+            out[8 * d + 6] = as_h2(v & 0x000C000Cu);
+            out[8 * d + 7] = as_h2(v & 0x00300030u);
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t u = w[d], v = u >> 9;
+            out[5 * d + 0] = as_h2(u & 0x00070007u);
+            out[5 * d + 1] = as_h2(u & 0x00380038u);
+            out[5 * d + 2] = as_h2(u & 0x01C001C0u);
+            out[5 * d + 3] = as_h2(v & 0x00070007u);
+            out[5 * d + 4] = as_h2(v & 0x00380038u);
+        }
+        out[15] = as_h2(((w[0] >> 15) & 0x00010001u) | ((w[1] >> 14) & 0x00020002u) | ((w[2] >> 13) & 0x00040004u));
+    }
+}
+
 // ---------------------------------------------------------------- body
-template <int BITS, int MODE, int PRO, int NW, bool DOT, int GEMV_U>
-__device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, int rt,
-                                          _Float16* xl, float* red, int xs) {
+template <int BITS, int MODE, int PRO, int NW, int U, int MATH>
+__device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, int local, _Float16* lds_x,
+                                          const _Float16* xl, float* xg, float* red, int xs) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = a.K >> 7;
     const int r = lane & 15, o = lane >> 4;
-    const uint32_t* qw = (const uint32_t*)s.qweight + (size_t)rt * G * (64 * BITS);
-    const h2* mt = (const h2*)s.meta + (size_t)rt * G * 16 + r;
-    const int nt = (G - wave + NW - 1) / NW;          // tiles owned by this wave: g = wave + i*NW
+    const int wgc = s.wg_count;
+    const int nt = (G - wave + NW - 1) / NW;                      // tiles of one row-tile owned by this wave: g = wave + i*NW
+    const int n_my = (s.n_rt - local + wgc - 1) / wgc;            // row-tiles of this workgroup: rt = local + j*wgc
+    const int total = n_my * nt;
+    const uint32_t* qw = (const uint32_t*)s.qweight;
+    const h2* mt = (const h2*)s.meta + r;
 
-    LanePayload<BITS> pay[GEMV_U];
-    h2 meta[GEMV_U];
-#define AMQ_ISSUE(slot, i)                                                                       \
+    LanePayload<BITS> pay[U];
+    h2 meta[U];
+    int ii = 0, ij = 0;                                           // issue cursor (tile, row-tile)
+#ifdef AMQ_ABL_NOLOAD      /* ablation build: no weight traffic, compute on whatever is in the registers */
+#define AMQ_ISSUE(slot)                                                                          \
     do {                                                                                         \
-        const int g_ = wave + (i) * NW;                                                          \
-        pay[slot] = load_payload<BITS>(qw + (size_t)g_ * (64 * BITS), lane);                      \
-        meta[slot] = as_h2(AMQ_STREAM_LOAD((const uint32_t*)(mt + (size_t)g_ * 16)));            \
+        asm volatile("" : "+v"(pay[slot].w[0]), "+v"(meta[slot]));                               \
+        if (++ii == nt) { ii = 0; ++ij; }                                                        \
     } while (0)
+#else
+#define AMQ_ISSUE(slot)                                                                          \
+    do {                                                                                         \
+        const size_t tile_ = (size_t)(local + ij * wgc) * G + (wave + ii * NW);                  \
+        pay[slot] = load_payload<BITS>(qw + tile_ * (64 * BITS), lane);                           \
+        meta[slot] = as_h2(AMQ_STREAM_LOAD((const uint32_t*)(mt + tile_ * 16)));                 \
+        if (++ii == nt) { ii = 0; ++ij; }                                                        \
+    } while (0)
+#endif
 
 #pragma unroll
-    for (int u = 0; u < GEMV_U; ++u)
-        if (u < nt) AMQ_ISSUE(u, u);                  // HBM requests leave before the prologue
+    for (int u = 0; u < U; ++u)
+        if (u < total) AMQ_ISSUE(u);                               // HBM requests leave before x is staged
 
-    stage_x<PRO, NW>(a, xl, red, xs);
+#ifndef AMQ_ABL_NOSTAGE
+    stage_x<PRO, NW, MATH == MATH_LINEAR>(a, lds_x, xg, red, xs);
+#endif
     __syncthreads();
 
     float acc1[4] = {0.f, 0.f, 0.f, 0.f};
     f4 accm = (f4){0.f, 0.f, 0.f, 0.f};
-    int mrow = r < a.M ? r : a.M - 1;                 // A rows >= M: any finite data, result unused
+    const int mrow = r < a.M ? r : a.M - 1;                       // A rows >= M: any finite data, result unused
     const _Float16* xrow = xl + (size_t)mrow * xs + 8 * o;
+    int ci = 0, cj = 0, par = 0;                                  // compute cursor, red[] parity
+
+    // end of a row-tile for this wave: publish partials, one barrier, fixed-order sum by the first M*16 threads
+#define AMQ_FINISH()                                                                             \
+    do {                                                                                         \
+        float* rp_ = red + par * (NW * 16 * 16);                                                 \
+        if (MATH == MATH_DOT) {                                                                  \
+            float v_ = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);                                \
+            v_ += __shfl_xor(v_, 16);                                                            \
+            v_ += __shfl_xor(v_, 32);                                                            \
+            if (lane < 16) rp_[wave * 256 + lane] = v_;                                          \
+            acc1[0] = acc1[1] = acc1[2] = acc1[3] = 0.f;                                         \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                     \
+                if (4 * o + i_ < a.M) rp_[wave * 256 + (4 * o + i_) * 16 + r] = accm[i_];        \
+            accm = (f4){0.f, 0.f, 0.f, 0.f};                                                     \
+        }                                                                                        \
+        __syncthreads();                                                                         \
+        const int rt_ = local + cj * wgc;                                                        \
+        for (int e_ = threadIdx.x; e_ < a.M * 16; e_ += NW * 64) {                               \
+            float tot_ = 0.f;                                                                    \
+            _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) tot_ += rp_[w_ * 256 + e_];        \
+            store_out(s, e_ >> 4, rt_ * 16 + (e_ & 15), tot_);                                   \
+        }                                                                                        \
+        par ^= 1;                                                                                \
+    } while (0)
 
     // consume one tile out of ring slot `slot`
-#define AMQ_COMPUTE(slot, i)                                                                     \
+#ifdef AMQ_ABL_NOCOMPUTE   /* ablation build: keep the loads and the row-tile protocol, drop unpack / LDS reads / MFMA */
+#define AMQ_COMPUTE(slot)                                                                        \
     do {                                                                                         \
+        uint32_t x_ = 0;                                                                         \
+        _Pragma("unroll") for (int d_ = 0; d_ < BITS; ++d_) x_ ^= pay[slot].w[d_];               \
+        accm[0] += (float)(x_ & 1u) + (float)meta[slot].x;                                       \
+        if (++ci == nt) { AMQ_FINISH(); ci = 0; ++cj; }                                          \
+    } while (0)
+#else
+#define AMQ_COMPUTE(slot)                                                                        \
+    do {                                                                                         \
+        const int g_ = wave + ci * NW;                                                           \
+        const int kbase = g_ << 7;                                                               \
         h2 wv[16];                                                                               \
-        dequant_lane_sd<BITS, MODE>(pay[slot].w, meta[slot], wv);                                \
-        const int kbase = (wave + (i) * NW) << 7;                                                \
-        if (DOT) {                                                                               \
+        if (MATH == MATH_LINEAR) unpack_lane_sub<BITS>(pay[slot].w, wv);                         \
+        else dequant_lane_sd<BITS, MODE>(pay[slot].w, meta[slot], wv);                           \
+        if (MATH == MATH_DOT) {                                                                  \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                      \
                 const h8 xv = *(const h8*)(xl + kbase + 8 * o + 32 * t);                         \
                 _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                  \
@@ -156,119 +281,124 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
                 }                                                                                \
             }                                                                                    \
         } else {                                                                                 \
+            f4 c_ = (MATH == MATH_LINEAR) ? (f4){0.f, 0.f, 0.f, 0.f} : accm;                     \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                      \
                 h8 b;                                                                            \
                 _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                  \
                     b[2 * p] = wv[4 * t + p].x; b[2 * p + 1] = wv[4 * t + p].y;                  \
                 }                                                                                \
                 const h8 av = *(const h8*)(xrow + kbase + 32 * t);                               \
-                accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, accm, 0, 0, 0);             \
+                c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, c_, 0, 0, 0);                 \
+            }                                                                                    \
+            if (MATH == MATH_LINEAR) {                                                           \
+                /* rows m = 4*o + i of this lane's column r: y += s*(2^24*S - z*X_g)  (HQQ) */   \
+                /*                                            y += s*2^24*S + c*X_g    (FMA) */   \
+                const float sf = (float)meta[slot].x, zf = (float)meta[slot].y;                  \
+                const float s24 = sf * 16777216.0f;                                              \
+                const float zx = (MODE == MODE_HQQ) ? -(sf * zf) : zf;                           \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                               \
+                    if (i_ < a.M) {                                                              \
+                        const int m_ = (4 * o + i_) < a.M ? (4 * o + i_) : a.M - 1;              \
+                        const float xs_ = xg[(size_t)m_ * G + g_];                               \
+                        accm[i_] = __builtin_fmaf(s24, c_[i_], __builtin_fmaf(zx, xs_, accm[i_])); \
+                    }                                                                            \
+                }                                                                                \
+            } else {                                                                             \
+                accm = c_;                                                                       \
             }                                                                                    \
         }                                                                                        \
+        if (++ci == nt) { AMQ_FINISH(); ci = 0; ++cj; }                                          \
     } while (0)
+#endif
 
-    // Software pipeline over this wave's tiles.  A slot is refilled only after
-    // its tile has been fully consumed (sched_barrier keeps the compiler from
-    // hoisting the load into temporaries + a vmcnt(0)/v_mov rotation, which is
-    // what a naive ring compiles to); the main loop refills unconditionally so
-    // the waits stay counted (vmcnt((U-1)*loads)), the tail drains.
-    int i = 0;
-    for (; i + 2 * GEMV_U <= nt; i += GEMV_U) {
+    if (nt == 0) {                                                // K < 128 * NW: this wave owns no tile
+        for (int j = 0; j < n_my; ++j) { AMQ_FINISH(); ++cj; }
+        return;
+    }
+
+    // Software pipeline over this wave's tile stream.  A slot is refilled only after its
+    // tile has been fully consumed (sched_barrier keeps the compiler from hoisting the load
+    // into temporaries + a vmcnt(0)/v_mov rotation -- what a naive ring compiles to); the
+    // main loop refills unconditionally so its waits stay counted, the tail drains.
+    int idx = 0;
+    for (; idx + 2 * U <= total; idx += U) {
 #pragma unroll
-        for (int u = 0; u < GEMV_U; ++u) {
-            AMQ_COMPUTE(u, i + u);
+        for (int u = 0; u < U; ++u) {
+            AMQ_COMPUTE(u);
             __builtin_amdgcn_sched_barrier(0);
-            AMQ_ISSUE(u, i + u + GEMV_U);
+            AMQ_ISSUE(u);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
-    for (int u = 0; u < GEMV_U; ++u) {
-        if (i + u < nt) {
-            AMQ_COMPUTE(u, i + u);
+    for (int u = 0; u < U; ++u) {
+        if (idx + u < total) {
+            AMQ_COMPUTE(u);
             __builtin_amdgcn_sched_barrier(0);
-            if (i + u + GEMV_U < nt) AMQ_ISSUE(u, i + u + GEMV_U);
+            if (idx + u + U < total) AMQ_ISSUE(u);
         }
     }
-    i += GEMV_U;
+    idx += U;
 #pragma unroll
-    for (int u = 0; u < GEMV_U; ++u)
-        if (i + u < nt) AMQ_COMPUTE(u, i + u);
+    for (int u = 0; u < U; ++u)
+        if (idx + u < total) AMQ_COMPUTE(u);
 #undef AMQ_ISSUE
 #undef AMQ_COMPUTE
-
-    // ---- cross-wave reduction in a fixed order -> y
-    __syncthreads();                // everyone is done reading xl; red[] is free
-    if (DOT) {
-        float v = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < 16) red[wave * 16 + lane] = v;
-        __syncthreads();
-        if (threadIdx.x < 16) {
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) tot += red[w * 16 + threadIdx.x];
-            store_out(s, 0, rt * 16 + threadIdx.x, tot);
-        }
-    } else {
-        // accm[i] = D[m = 4*o + i][n = r]
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (4 * o + i < a.M) red[(wave * 16 + 4 * o + i) * 16 + r] = accm[i];
-        __syncthreads();
-        for (int e = threadIdx.x; e < a.M * 16; e += NW * 64) {
-            const int m = e >> 4, n = e & 15;
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) tot += red[(w * 16 + m) * 16 + n];
-            store_out(s, m, rt * 16 + n, tot);
-        }
-    }
+#undef AMQ_FINISH
 }
 
-template <int PRO, int NW, bool DOT, int U>
+template <int PRO, int NW, int U, int MATH>
 __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xs = a.K + XPAD;
     _Float16* xl = (_Float16*)smem;
-    float* red = (float*)(smem + (((size_t)a.M * xs * 2 + 15) & ~(size_t)15));
+    const size_t xbytes = ((size_t)a.M * xs * 2 * (MATH == MATH_LINEAR ? a.lin_copies : 1) + 15) & ~(size_t)15;
+    float* xg = (float*)(smem + xbytes);                                        // [M][G] (linear math only)
+    const size_t xgbytes = (MATH == MATH_LINEAR) ? (((size_t)a.M * (a.K >> 7) * 4 + 15) & ~(size_t)15) : 0;
+    float* red = (float*)(smem + xbytes + xgbytes);                             // [2][NW][16][16]
 
     int sidx = 0;
 #pragma unroll
     for (int i = 1; i < GEMV_MAX_SEG; ++i)
         if (i < a.nseg && (int)blockIdx.x >= a.seg[i].wg_begin) sidx = i;
     const GemvSeg& s = a.seg[sidx];
-    const int rt = (int)blockIdx.x - s.wg_begin;
+    const int local = (int)blockIdx.x - s.wg_begin;
+
+    const _Float16* xuse = xl;
+    if (MATH == MATH_LINEAR) {
+        int slot = 0;
+        for (int b = 2; b < s.bits; ++b) slot += (a.lin_mask >> b) & 1;
+        xuse = xl + (size_t)slot * a.M * xs;
+    }
     const int key = s.bits * 2 + s.mode;
     switch (key) {
-        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
-        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
-        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
-        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
-        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
-        default:               gemv_body<2, MODE_FMA, PRO, NW, DOT, U>(a, s, rt, xl, red, xs); break;
+        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
+        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
+        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
+        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
+        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
     }
 }
 
-size_t gemv_lds_bytes(int M, int K) {
-    const size_t xbytes = (((size_t)M * (K + XPAD) * 2) + 15) & ~(size_t)15;
-    const size_t red = (size_t)16 /*max NW*/ * 16 * 16 * 4;
-    return xbytes + red;
+size_t gemv_lds_bytes(int M, int K, int copies) {
+    const size_t xbytes = (((size_t)M * (K + XPAD) * 2 * copies) + 15) & ~(size_t)15;
+    const size_t xg = (((size_t)M * (K >> 7) * 4 + 15) & ~(size_t)15);
+    const size_t red = (size_t)2 * 16 /*max NW*/ * 16 * 16 * 4;
+    return xbytes + xg + red;
 }
 
-int gemv_pick_waves(int total_wg, int K) {
-    // measured on MI355X (tools/microbench.py sweeps, profiles/): 8 waves x 2 tiles
-    // in flight is the best or within 3% of it for every Llama shape; tiny K
-    // falls back to 4 waves so each wave still owns >= 2 tiles.
-    (void)total_wg;
+int gemv_pick_waves(int total_rt, int K) {
+    // measured on MI355X (tools/microbench.py sweeps, profiles/): 8 waves x 2 tiles in flight is the
+    // best or within 3% of it for every Llama shape; tiny K falls back to 4 waves (>= 2 tiles per wave).
+    (void)total_rt;
     const int G = K >> 7;
     return G >= 16 ? 8 : 4;
 }
 
-template <int PRO, int NW, bool DOT, int U>
+template <int PRO, int NW, int U, int MATH>
 static hipError_t launch_one(const GemvArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    auto kern = gemv_kernel<PRO, NW, DOT, U>;
+    auto kern = gemv_kernel<PRO, NW, U, MATH>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -279,28 +409,50 @@ static hipError_t launch_one(const GemvArgs& a, int total_wg, size_t lds, hipStr
 
 template <int PRO, int NW>
 static hipError_t launch_nw(const GemvArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    const bool dot = (a.flags & GEMV_FLAG_DOT) && a.M == 1;
     const int u = a.force_depth ? a.force_depth : 2;
-    if (dot) return launch_one<PRO, NW, true, 4>(a, total_wg, lds, st);
-    if (u == 2) return launch_one<PRO, NW, false, 2>(a, total_wg, lds, st);
-    return launch_one<PRO, NW, false, 4>(a, total_wg, lds, st);
+    if ((a.flags & GEMV_FLAG_DOT) && a.M == 1) return launch_one<PRO, NW, 2, MATH_DOT>(a, total_wg, lds, st);
+    if (a.flags & GEMV_FLAG_LINEAR) {
+        if (u == 4) return launch_one<PRO, NW, 4, MATH_LINEAR>(a, total_wg, lds, st);
+        return launch_one<PRO, NW, 2, MATH_LINEAR>(a, total_wg, lds, st);
+    }
+    if (u == 4) return launch_one<PRO, NW, 4, MATH_EXACT>(a, total_wg, lds, st);
+    return launch_one<PRO, NW, 2, MATH_EXACT>(a, total_wg, lds, st);
 }
 
 template <int PRO>
-static hipError_t launch_pro(const GemvArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_wg, a.K);
-    if (nw == 2) return launch_nw<PRO, 2>(a, total_wg, lds, st);
+static hipError_t launch_pro(const GemvArgs& a, int nw, int total_wg, size_t lds, hipStream_t st) {
     if (nw == 4) return launch_nw<PRO, 4>(a, total_wg, lds, st);
-    if (nw == 8) return launch_nw<PRO, 8>(a, total_wg, lds, st);
-    return launch_nw<PRO, 16>(a, total_wg, lds, st);
+    if (nw == 16) return launch_nw<PRO, 16>(a, total_wg, lds, st);
+    return launch_nw<PRO, 8>(a, total_wg, lds, st);
 }
 
-hipError_t launch_gemv(const GemvArgs& a, int total_wg, hipStream_t st) {
-    const size_t lds = gemv_lds_bytes(a.M, a.K);
+// Fills the per-segment workgroup ranges and launches.  rpt = row-tiles per workgroup.
+hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
+    int total_rt = 0;
+    for (int i = 0; i < a.nseg; ++i) { a.seg[i].n_rt = a.seg[i].N / 16; total_rt += a.seg[i].n_rt; }
+    const int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_rt, a.K);
+    // persistent-style grid: about 24 waves per CU (256 CUs); a workgroup walks `rpt` row-tiles
+    int rpt = a.force_rpt;
+    if (rpt <= 0) {
+        const int target = 256 * 24 / nw;
+        rpt = (total_rt + target - 1) / target;
+        if (rpt < 1) rpt = 1;
+    }
+    int wg = 0, mask = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        a.seg[i].wg_begin = wg;
+        a.seg[i].wg_count = (a.seg[i].n_rt + rpt - 1) / rpt;
+        wg += a.seg[i].wg_count;
+        mask |= 1 << a.seg[i].bits;
+    }
+    const bool lin = (a.flags & GEMV_FLAG_LINEAR) && !((a.flags & GEMV_FLAG_DOT) && a.M == 1);
+    a.lin_mask = lin ? mask : 0;
+    a.lin_copies = lin ? __builtin_popcount(mask) : 1;
+    const size_t lds = gemv_lds_bytes(a.M, a.K, a.lin_copies);
     switch (a.prologue) {
-        case PRO_NONE: return launch_pro<PRO_NONE>(a, total_wg, lds, st);
-        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(a, total_wg, lds, st);
-        default: return launch_pro<PRO_SILU_MUL>(a, total_wg, lds, st);
+        case PRO_NONE: return launch_pro<PRO_NONE>(a, nw, wg, lds, st);
+        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(a, nw, wg, lds, st);
+        default: return launch_pro<PRO_SILU_MUL>(a, nw, wg, lds, st);
     }
 }
 

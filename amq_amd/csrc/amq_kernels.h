@@ -20,9 +20,10 @@ struct GemvSeg {
     int N;
     int bits;              // 2 | 3 | 4
     int mode;              // MODE_HQQ | MODE_FMA
-    int wg_begin;          // first workgroup of this segment
+    int wg_begin;          // first workgroup of this segment          (filled by launch_gemv)
+    int wg_count;          // workgroups serving this segment          (filled by launch_gemv)
+    int n_rt;              // row-tiles (N / 16)                        (filled by launch_gemv)
     int y_stride;          // elements between output rows
-    int _pad;
 };
 
 struct GemvArgs {
@@ -36,14 +37,17 @@ struct GemvArgs {
     float eps;
     int prologue;
     int flags;             // GEMV_FLAG_*
-    int force_waves;       // 0 = auto, else 2 / 4 / 8 / 16 waves per workgroup
+    int force_waves;       // 0 = auto, else 4 / 8 / 16 waves per workgroup
     int force_depth;       // 0 = auto, else 2 / 4 tile loads in flight per wave
+    int force_rpt;         // 0 = auto, else row-tiles per workgroup
+    int lin_mask;          // linear math: bit b set = a segment with b-bit weights is present (filled by launch_gemv)
+    int lin_copies;        // number of pre-scaled x copies in LDS                          (filled by launch_gemv)
 };
-enum { GEMV_FLAG_DOT = 1 };
+enum { GEMV_FLAG_DOT = 1, GEMV_FLAG_LINEAR = 2 };
 constexpr int GEMV_MAX_M = 16;
 
-size_t gemv_lds_bytes(int M, int K);
-hipError_t launch_gemv(const GemvArgs& a, int total_wg, hipStream_t st);
+size_t gemv_lds_bytes(int M, int K, int copies);
+hipError_t launch_gemv(GemvArgs& a, hipStream_t st);
 
 // y[M,N] = x[M,K] . W^T for any M (MFMA, LDS-staged x tiles)
 struct GemmArgs {

@@ -59,8 +59,16 @@ const char* amq_last_error(void);
 
 /* process-wide tuning / A-B knobs (not needed for normal use) */
 #define AMQ_OPT_GEMV_DOT   1       /* 1: M == 1 runs the v_dot2c + wavefront-shuffle body instead of the MFMA body */
-#define AMQ_OPT_GEMV_WAVES 2       /* waves per GEMV workgroup: 0 = auto (default), 2, 4, 8 or 16 */
+#define AMQ_OPT_GEMV_WAVES 2       /* waves per GEMV workgroup: 0 = auto (default), 4, 8 or 16 */
 #define AMQ_OPT_GEMV_DEPTH 3       /* tile loads in flight per wave: 0 = auto (default), 2 or 4 */
+#define AMQ_OPT_GEMV_RPT   4       /* row-tiles walked by one GEMV workgroup: 0 = auto (default), 1..64 */
+#define AMQ_OPT_GEMV_MATH  5       /* AMQ_MATH_EXACT (default) or AMQ_MATH_LINEAR */
+/* GEMV arithmetic.  EXACT reproduces the reference's dequantized fp16 weights (two fp16 roundings per
+ * weight) and accumulates x*w in fp32.  LINEAR skips the per-weight roundings: y = sum_g s_g*(sum_k x_k q_k
+ * - z_g sum_k x_k) in fp32 (scale / zero applied once per 128-group) -- the real-valued dequant; it is
+ * ~3x cheaper in VALU work and lands within ~1e-3 of the output rms of the reference result (tests). */
+#define AMQ_MATH_EXACT  0
+#define AMQ_MATH_LINEAR 1
 int amq_set_option(int option, int value);
 
 /* capabilities: writes up to `cap` ints {max_gemv_rows_for_K, lds_bytes, ...}; returns the count */

@@ -44,7 +44,7 @@ def test_version_sizes_and_validation():
     assert rc == -2 and b"group" in lib.amq_last_error()
     rc = lib.amq_gemv_f16(4, 0, one, one, one, None, one, 17, 4096, 4096, 128, 0, 0, None)
     assert rc == -2 and b"amq_gemm_f16" in lib.amq_last_error()
-    assert lib.amq_set_option(2, 5) == -1 and lib.amq_set_option(3, 3) == -1 and lib.amq_set_option(3, 0) == 0 and lib.amq_set_option(2, 0) == 0 and lib.amq_set_option(99, 0) == -1
+    assert lib.amq_set_option(2, 5) == -1 and lib.amq_set_option(4, 65) == -1 and lib.amq_set_option(5, 2) == -1 and lib.amq_set_option(5, 0) == 0 and lib.amq_set_option(3, 3) == -1 and lib.amq_set_option(3, 0) == 0 and lib.amq_set_option(2, 0) == 0 and lib.amq_set_option(99, 0) == -1
     rc = lib.amq_gemm_f16(4, 7, one, one, one, None, one, 40, 4096, 4096, 128, 0, 0, None)
     assert rc == -1
     out = (ctypes.c_int * 4)()

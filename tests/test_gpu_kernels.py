@@ -242,6 +242,37 @@ def test_gemv_variants_agree(opt):
     _assert_close(y, y_ref, f"gemv variant {opt}")
 
 
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k,m,rpt", [(256, 1024, 1, 0), (4096, 4096, 1, 3), (512, 2048, 5, 2), (11008, 4096, 1, 0), (64, 384, 3, 0)])
+def test_gemv_linear_math_and_persistent_rows(bits, n, k, m, rpt):
+    """opt-in AMQ_MATH_LINEAR (scale/zero applied per group in fp32, no per-weight fp16 rounding) and
+    several row-tiles per workgroup.  Linear math is compared (a) with the exact real-valued dequant
+    sum_k x_k * (q_k - z) * s in fp64: fp32-accumulation accuracy; (b) with the reference's rounded-weight
+    result: within 2e-3 of the output rms (the reference's own weight-rounding noise is ~3e-4 rms)."""
+    from amq_amd import ops, _lib
+    lib = _lib.load()
+    h, qn, mn, w_ref = _random_case(bits, n, k, seed=11 * bits + m)
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(n + m)).to(torch.float16)
+    q = hqq_ref.unpack(h.W_q.numpy(), bits, (n, k)).astype(np.float64)
+    s64 = np.repeat(h.scale.numpy().astype(np.float64).reshape(n, -1), 128, axis=1)
+    z64 = np.repeat(h.zero.numpy().astype(np.float64).reshape(n, -1), 128, axis=1)
+    y_real = x.numpy().astype(np.float64) @ ((q - z64) * s64).T
+    y_ref = linear_ref.linear_f16(x.numpy(), w_ref).astype(np.float64)
+    rms = np.sqrt(np.mean(y_ref ** 2))
+    try:
+        _lib.check(lib.amq_set_option(_lib.OPT_GEMV_RPT, rpt))
+        y_exact = ops.gemv(x.to(_dev()), qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy()
+        _lib.check(lib.amq_set_option(_lib.OPT_GEMV_MATH, _lib.MATH_LINEAR))
+        y_lin = ops.gemv(x.to(_dev()), qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy().astype(np.float64)
+    finally:
+        lib.amq_set_option(_lib.OPT_GEMV_MATH, _lib.MATH_EXACT)
+        lib.amq_set_option(_lib.OPT_GEMV_RPT, 0)
+    _assert_close(y_exact, y_ref, "exact math, rpt=%d" % rpt)
+    assert np.max(np.abs(y_lin - y_real) - 2.0 ** -10 * np.abs(y_real)) <= 1e-4 * rms      # (a)
+    assert np.max(np.abs(y_lin - y_ref)) <= 2e-3 * rms + 1e-3 * np.max(np.abs(y_ref)) * 0   # (b)
+    assert np.sqrt(np.mean((y_lin - y_ref) ** 2)) <= 6e-4 * rms
+
+
 def test_gemv_is_deterministic():
     from amq_amd import ops
     h, qn, mn, _ = _random_case(3, 4096, 4096, seed=5)

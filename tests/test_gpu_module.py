@@ -1,0 +1,115 @@
+"""GPU: the drop-in module surface (HIPQuantLinear, prepare_for_inference) behaves like the reference pair."""
+import copy
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hqq_ref, linear_ref
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+class _Block(torch.nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        for k, v in layers.items():
+            setattr(self, k, v)
+
+
+def _toy_model(bias=False):
+    from amq_amd.hqq_format import random_hqq
+    from amq_amd.patching import HQQWeightsModule
+    specs = {"q_proj": (2, 256, 512), "k_proj": (3, 128, 512), "down_proj": (4, 512, 256)}
+    hs = {k: random_hqq(n, kk, b, seed=i, bias=bias) for i, (k, (b, n, kk)) in enumerate(specs.items())}
+    model = torch.nn.Module()
+    model.layers = torch.nn.ModuleList([_Block({k: HQQWeightsModule(h.to(_dev())) for k, h in hs.items()})])
+    model.norm = torch.nn.LayerNorm(8)            # a non-quantized child that must be left alone
+    return model, hs
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_prepare_for_inference_cache_roundtrip(tmp_path, bias):
+    from amq_amd.patching import prepare_for_inference
+    from amq_amd.quant_linear import HIPQuantLinear
+    model, hs = _toy_model(bias)
+    path = str(tmp_path / "toy_HIPLinear.pt")
+    prepare_for_inference(model, backend="gptq", load_path=path)          # legacy backend name accepted
+    assert os.path.exists(path)
+    blk = model.layers[0]
+    assert isinstance(blk.q_proj, HIPQuantLinear) and blk.q_proj.name == "q_proj" and isinstance(model.norm, torch.nn.LayerNorm)
+    assert (blk.q_proj.bits, blk.q_proj.infeatures, blk.q_proj.outfeatures, blk.q_proj.group_size) == (2, 512, 256, 128)
+    assert hasattr(blk.q_proj, "weight")                                   # dummy param like patch_add_weight_param
+    x = torch.randn(2, 3, 512, generator=torch.Generator().manual_seed(0)).half()
+    outs = {}
+    for name in ("q_proj", "k_proj"):
+        h = hs[name]
+        y = getattr(blk, name)(x.to(_dev()))
+        assert y.shape == (2, 3, h.shape[0]) and y.dtype == torch.float16
+        w = hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), h.nbits, h.shape)
+        ref = linear_ref.linear_f16(x.numpy(), w, None if h.bias is None else h.bias.numpy()).astype(np.float32)
+        err = np.abs(y.float().cpu().numpy() - ref)
+        assert np.all(err <= 1e-3 * np.abs(ref) + 1e-3 * np.sqrt(np.mean(ref ** 2)))
+        outs[name] = y
+    # second model: load the cache instead of re-packing (patching.py:185-189 behaviour)
+    model2, _ = _toy_model(bias)
+    prepare_for_inference(model2, backend="hip", load_path=path)
+    for name in ("q_proj", "k_proj"):
+        assert torch.equal(getattr(model2.layers[0], name)(x.to(_dev())), outs[name])
+    # deepcopy / cpu round trip / setattr, as amq_speed_benchmark.py:231-256 does
+    m3 = copy.deepcopy(model).to("cpu").to(_dev())
+    assert torch.equal(m3.layers[0].q_proj(x.to(_dev())), outs["q_proj"])
+    with pytest.raises(RuntimeError):
+        prepare_for_inference(model2, backend="marlin")
+
+
+def test_float32_input_is_cast_like_the_reference():
+    from amq_amd.quant_linear import HIPQuantLinear
+    from amq_amd.hqq_format import random_hqq
+    h = random_hqq(64, 256, 4, seed=3)
+    m = HIPQuantLinear.from_hqq(h, device=_dev())
+    x = torch.randn(5, 256).to(_dev())
+    y = m(x)
+    assert y.dtype == torch.float32 and y.shape == (5, 64)
+    assert torch.allclose(y, m(x.half()).float())
+    with pytest.raises(NotImplementedError):
+        HIPQuantLinear(8, 128, 256, 64)
+    with pytest.raises(NotImplementedError):
+        HIPQuantLinear(4, 64, 256, 64)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "hqq_b*_128x512.npz"))), ids=os.path.basename)
+def test_pack_and_reference_buffer_imports(path):
+    """pack(W, scales, zeros) (GPTQLinear.pack signature) and the GPTQ / AWQ buffer imports on reference captures"""
+    from amq_amd.quant_linear import HIPQuantLinear
+    from amq_amd.patching import load_reference_cache
+    g = {k: v for k, v in np.load(path).items()}
+    bits, (n, k) = int(g["nbits"]), tuple(int(v) for v in g["shape"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+    m = HIPQuantLinear(bits, 128, k, n)
+    m = m.to(_dev())
+    m.pack(t(g["W_deq"]), t(g["scale"].reshape(n, -1)), t(g["zero"].reshape(n, -1)))
+    assert np.array_equal(m.dequantize().cpu().numpy().view(np.uint16), g["W_deq"].view(np.uint16))
+    sd = {"model.layers.0.mlp.up_proj.qweight": torch.from_numpy(g["gptq_qweight"]),
+          "model.layers.0.mlp.up_proj.scales": torch.from_numpy(g["gptq_scales"]),
+          "model.layers.0.mlp.up_proj.zeros": torch.from_numpy(g["gptq_zeros"])}
+    if bits == 4:
+        sd.update({"model.layers.0.self_attn.q_proj.qweight": torch.from_numpy(g["awq_qweight"]),
+                   "model.layers.0.self_attn.q_proj.scales": torch.from_numpy(g["awq_scales"]),
+                   "model.layers.0.self_attn.q_proj.scaled_zeros": torch.from_numpy(g["awq_scaled_zeros"])})
+    mods = load_reference_cache(sd)
+    up = mods["model.layers.0.mlp.up_proj"]
+    assert (up.bits, up.outfeatures, up.infeatures, up.name) == (bits, n, k, "up_proj")
+    y = up(t(g["gptq_x"])).float().cpu().numpy()
+    yf = g["gptq_y"].astype(np.float32)
+    assert np.max(np.abs(y - yf)) <= 3e-3 * np.sqrt(np.mean(yf ** 2))
+    if bits == 4:
+        q = mods["model.layers.0.self_attn.q_proj"]
+        assert torch.equal(q.qweight, up.qweight)

@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--dot", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--depth", type=int, default=0)
+    ap.add_argument("--rpt", type=int, default=0)
+    ap.add_argument("--math", type=int, default=0)
     ap.add_argument("--gemm", type=int, default=1)
     ap.add_argument("--hot", type=int, default=0, help="1: a single weight buffer (stays in L2 / Infinity Cache)")
     args = ap.parse_args()
@@ -81,6 +83,8 @@ def main():
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DOT, args.dot))
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_WAVES, args.waves))
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DEPTH, args.depth))
+    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_RPT, args.rpt))
+    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_MATH, args.math))
     shapes = [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096)]
     if args.quick:
         shapes = shapes[:2]
