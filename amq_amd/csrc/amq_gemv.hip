@@ -196,6 +196,16 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
     const uint32_t* qw = (const uint32_t*)s.qweight;
     const h2* mt = (const h2*)s.meta + r;
 
+#ifdef AMQ_ABL_NOMETA      /* ablation: no scale/zero traffic */
+#define AMQ_META_LOAD(slot, tile_) meta[slot] = as_h2(0x40003c00u + (uint32_t)(tile_ & 1))
+#else
+#define AMQ_META_LOAD(slot, tile_) meta[slot] = as_h2(AMQ_STREAM_LOAD((const uint32_t*)(mt + (tile_) * 16)))
+#endif
+#ifdef AMQ_ABL_NOXLDS      /* ablation: A operand from registers instead of LDS */
+#define AMQ_XREAD(p) ((h8){(_Float16)1, (_Float16)2, (_Float16)-1, (_Float16)0.5f, (_Float16)1, (_Float16)-2, (_Float16)1, (_Float16)3} + (h8)(_Float16)(float)(kbase & 1))
+#else
+#define AMQ_XREAD(p) (*(const h8*)(p))
+#endif
     LanePayload<BITS> pay[U];
     h2 meta[U];
     int ii = 0, ij = 0;                                           // issue cursor (tile, row-tile)
@@ -210,7 +220,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
     do {                                                                                         \
         const size_t tile_ = (size_t)(local + ij * wgc) * G + (wave + ii * NW);                  \
         pay[slot] = load_payload<BITS>(qw + tile_ * (64 * BITS), lane);                           \
-        meta[slot] = as_h2(AMQ_STREAM_LOAD((const uint32_t*)(mt + tile_ * 16)));                 \
+        AMQ_META_LOAD(slot, tile_);                                                              \
         if (++ii == nt) { ii = 0; ++ij; }                                                        \
     } while (0)
 #endif
@@ -287,7 +297,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
                 _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                  \
                     b[2 * p] = wv[4 * t + p].x; b[2 * p + 1] = wv[4 * t + p].y;                  \
                 }                                                                                \
-                const h8 av = *(const h8*)(xrow + kbase + 32 * t);                               \
+                const h8 av = AMQ_XREAD(xrow + kbase + 32 * t);                                  \
                 c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, c_, 0, 0, 0);                 \
             }                                                                                    \
             if (MATH == MATH_LINEAR) {                                                           \
@@ -347,8 +357,11 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
 #undef AMQ_FINISH
 }
 
+#ifndef AMQ_LB_WAVES       /* A/B builds: minimum waves per SIMD the register allocator must leave room for */
+#define AMQ_LB_WAVES 1
+#endif
 template <int PRO, int NW, int U, int MATH>
-__global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvArgs a) {
+__global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES) void gemv_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xs = a.K + XPAD;
     _Float16* xl = (_Float16*)smem;

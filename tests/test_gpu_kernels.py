@@ -269,7 +269,7 @@ def test_gemv_linear_math_and_persistent_rows(bits, n, k, m, rpt):
         lib.amq_set_option(_lib.OPT_GEMV_RPT, 0)
     _assert_close(y_exact, y_ref, "exact math, rpt=%d" % rpt)
     assert np.max(np.abs(y_lin - y_real) - 2.0 ** -10 * np.abs(y_real)) <= 1e-4 * rms      # (a)
-    assert np.max(np.abs(y_lin - y_ref)) <= 2e-3 * rms + 1e-3 * np.max(np.abs(y_ref)) * 0   # (b)
+    assert np.max(np.abs(y_lin - y_ref) - 2.0 ** -10 * np.abs(y_ref)) <= 2e-3 * rms   # (b) (+ one fp16 ulp of y: both are rounded)
     assert np.sqrt(np.mean((y_lin - y_ref) ** 2)) <= 6e-4 * rms
 
 

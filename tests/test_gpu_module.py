@@ -109,7 +109,7 @@ def test_pack_and_reference_buffer_imports(path):
     assert (up.bits, up.outfeatures, up.infeatures, up.name) == (bits, n, k, "up_proj")
     y = up(t(g["gptq_x"])).float().cpu().numpy()
     yf = g["gptq_y"].astype(np.float32)
-    assert np.max(np.abs(y - yf)) <= 3e-3 * np.sqrt(np.mean(yf ** 2))
+    assert np.max(np.abs(y - yf)) <= 3e-3 * np.sqrt(np.mean(yf ** 2)) + 1e-3 * np.max(np.abs(yf))
     if bits == 4:
         q = mods["model.layers.0.self_attn.q_proj"]
         assert torch.equal(q.qweight, up.qweight)

@@ -18,6 +18,7 @@ from amq_amd.hqq_format import random_hqq  # noqa: E402
 
 
 HOT = False
+ZERO = False
 
 
 def layer_bytes(n, k, bits, m=1):
@@ -28,6 +29,8 @@ def bench_case(n, k, bits, m, iters, fn_name="gemv"):
     dev = torch.device("cuda:0")
     h = random_hqq(n, k, bits, seed=1).to(dev)
     qn0, mn0 = ops.repack_from_hqq(h.W_q, h.scale.reshape(-1), h.zero.reshape(-1), bits, n, k)
+    if ZERO:
+        qn0.zero_()
     per = qn0.numel() * 4 + mn0.numel() * 2
     copies = max(2, min(64, (768 << 20) // per + 1))
     if HOT:
@@ -75,10 +78,12 @@ def main():
     ap.add_argument("--rpt", type=int, default=0)
     ap.add_argument("--math", type=int, default=0)
     ap.add_argument("--gemm", type=int, default=1)
+    ap.add_argument("--zero", type=int, default=0, help="1: all-zero packed weights (data-dependent clock check)")
     ap.add_argument("--hot", type=int, default=0, help="1: a single weight buffer (stays in L2 / Infinity Cache)")
     args = ap.parse_args()
-    global HOT
+    global HOT, ZERO
     HOT = bool(args.hot)
+    ZERO = bool(args.zero)
     from amq_amd import _lib
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DOT, args.dot))
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_WAVES, args.waves))

@@ -7,6 +7,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 filt = sys.argv[2] if len(sys.argv) > 2 else "gemv"
+import json
 for f in sorted(glob.glob(root + "/**/*kernel_trace.csv", recursive=True)):
     d = defaultdict(list)
     for r in csv.DictReader(open(f)):

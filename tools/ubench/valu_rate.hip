@@ -34,6 +34,9 @@ KERNEL(k_dot2c,   "v_dot2c_f32_f16 %4, %0, %8\n v_dot2c_f32_f16 %5, %1, %8\n v_d
 KERNEL(k_dot2,    "v_dot2_f32_f16 %4, %0, %8, %4\n v_dot2_f32_f16 %5, %1, %8, %5\n v_dot2_f32_f16 %6, %2, %8, %6\n v_dot2_f32_f16 %7, %3, %8, %7\n")
 KERNEL(k_and_or,  "v_and_or_b32 %0, %0, %10, %8\n v_and_or_b32 %1, %1, %10, %8\n v_and_or_b32 %2, %2, %10, %8\n v_and_or_b32 %3, %3, %10, %8\n")
 KERNEL(k_and,     "v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n")
+KERNEL(k_and_lit, "v_and_b32 %0, 0x3c003c0, %0\n v_and_b32 %1, 0x3c003c0, %1\n v_and_b32 %2, 0x3c003c0, %2\n v_and_b32 %3, 0x3c003c0, %3\n")
+KERNEL(k_and_sgpr,"v_and_b32 %0, %10, %0\n v_and_b32 %1, %10, %1\n v_and_b32 %2, %10, %2\n v_and_b32 %3, %10, %3\n")
+KERNEL(k_pkmul_sgpr,"v_pk_mul_f16 %0, %0, %10 op_sel_hi:[1,0]\n v_pk_mul_f16 %1, %1, %10 op_sel_hi:[1,0]\n v_pk_mul_f16 %2, %2, %10 op_sel_hi:[1,0]\n v_pk_mul_f16 %3, %3, %10 op_sel_hi:[1,0]\n")
 KERNEL(k_perm,    "v_perm_b32 %0, %0, %8, %9\n v_perm_b32 %1, %1, %8, %9\n v_perm_b32 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n")
 KERNEL(k_mad24,   "v_mad_u32_u24 %0, %0, %8, %9\n v_mad_u32_u24 %1, %1, %8, %9\n v_mad_u32_u24 %2, %2, %8, %9\n v_mad_u32_u24 %3, %3, %8, %9\n")
 KERNEL(k_lshr,    "v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 3, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3\n")
@@ -66,6 +69,19 @@ __global__ void k_mfma(uint64_t* out, uint32_t seed) {
     if (c0[0] + c1[1] + c2[2] + c3[3] == 1.2345f) out[0] = 0;
 }
 
+__global__ void k_mfma_dep(uint64_t* out, uint32_t seed) {
+    h8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(float)((seed + threadIdx.x + i) & 7); b[i] = (_Float16)1.0f; }
+    f4 c0 = {0, 0, 0, 0};
+    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < LOOPS; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    }
+    uint64_t t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    if (c0[0] == 1.2345f) out[0] = 0;
+}
 typedef void (*kern_t)(uint64_t*, uint32_t);
 struct Case { const char* name; kern_t k; int per_loop; };
 
@@ -75,11 +91,11 @@ int main() {
     Case cases[] = {
         {"v_pk_add_f16", k_pk_add, 64}, {"v_pk_mul_f16", k_pk_mul, 64}, {"v_pk_fma_f16", k_pk_fma, 64},
         {"v_dot2c_f32_f16", k_dot2c, 64}, {"v_dot2_f32_f16", k_dot2, 64}, {"v_and_or_b32", k_and_or, 64},
-        {"v_and_b32", k_and, 64}, {"v_perm_b32", k_perm, 64}, {"v_mad_u32_u24", k_mad24, 64}, {"v_lshrrev_b32", k_lshr, 64},
+        {"v_and_b32", k_and, 64}, {"v_and_b32 literal", k_and_lit, 64}, {"v_and_b32 sgpr", k_and_sgpr, 64}, {"v_pk_mul_f16 sgpr opsel", k_pkmul_sgpr, 64}, {"v_perm_b32", k_perm, 64}, {"v_mad_u32_u24", k_mad24, 64}, {"v_lshrrev_b32", k_lshr, 64},
         {"v_fma_f32", k_fma32, 64}, {"v_fmac_f32", k_fmac32, 64}, {"v_add_f16", k_add16, 64}, {"v_fma_mix_f32", k_fmamix, 64},
         {"v_cvt_f16_u16", k_cvtu16, 64}, {"v_bfe_u32", k_bfe, 64}, {"v_lshl_or_b32", k_lshlor, 64},
         {"v_pk_mad_u16", k_pkmad16, 64}, {"v_pk_mul_lo_u16", k_pkmul16, 64},
-        {"mfma_16x16x32_f16", k_mfma, 16},
+        {"mfma_16x16x32_f16", k_mfma, 16}, {"mfma_16x16x32 dependent", k_mfma_dep, 16},
     };
     printf("%-20s %10s %10s %10s   (cycles per wave-instruction per SIMD; s_memtime ticks)\n", "op", "1w/SIMD", "2w/SIMD", "4w/SIMD");
     for (auto& c : cases) {
