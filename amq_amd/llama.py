@@ -245,3 +245,110 @@ class QuantLlama:
             self.decode_step(use_graph)
             out[i:i + 1] = self.token
         return out
+
+
+class DenseLlama(QuantLlama):
+    """fp16 baseline with the same runner interface (the reference's ``result['fp16']`` row,
+    amq_speed_benchmark.py:171-197): plain library GEMMs (torch / hipBLASLt) for the seven
+    linears, the same RMSNorm / attention / lm_head kernels around them."""
+
+    def __init__(self, config, device="cuda:0", max_seq=256, seed=0):
+        if isinstance(config, str):
+            config = MODEL_CONFIGS[config]
+        # build the shared parts through the parent with a minimal (2-bit) arch, then drop the quantized linears
+        self._dense_init(config, device, max_seq, seed)
+
+    def _dense_init(self, config, device, max_seq, seed):
+        self.cfg = config
+        self.dev = torch.device(device)
+        self.H, self.I = config["hidden_size"], config["intermediate_size"]
+        self.nh, self.nkv = config["num_heads"], config["num_kv_heads"]
+        self.kvd = self.nkv * 128
+        self.nb, self.vocab, self.max_seq = config["n_block"], config["vocab_size"], max_seq
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        dev = self.dev
+        f16 = dict(dtype=torch.float16, device=dev)
+        self.blocks = []
+        for _ in range(self.nb):
+            blk = {}
+            for name in config["linear"]:
+                n, k = config["linear_shape"][name]
+                blk[name] = (torch.randn(n, k, device=dev, generator=gen) * (0.5 / math.sqrt(k))).to(torch.float16)
+            blk["ln1"] = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
+            blk["ln2"] = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
+            blk["kc"] = torch.zeros(1, self.nkv, max_seq, 128, **f16)
+            blk["vc"] = torch.zeros(1, self.nkv, max_seq, 128, **f16)
+            self.blocks.append(blk)
+        self.embed = torch.randn(self.vocab, self.H, device=dev, generator=gen).to(torch.float16)
+        self.lm_head = (torch.randn(self.vocab, self.H, device=dev, generator=gen) / math.sqrt(self.H)).to(torch.float16)
+        self.norm = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
+        self.x = torch.zeros(1, self.H, **f16)
+        self.att = torch.zeros(1, self.H, **f16)
+        self.logits = torch.zeros(self.vocab, **f16)
+        self.token = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.graph = None
+
+    def linear_bytes_per_token(self):
+        return sum(blk[name].numel() * 2 for blk in self.blocks for name in self.cfg["linear"])
+
+    def _step(self):
+        F = torch.nn.functional
+        torch.index_select(self.embed, 0, self.token, out=self.x)
+        x = self.x
+        for blk in self.blocks:
+            h = ops.rmsnorm(x, blk["ln1"], EPS)
+            q = F.linear(h, blk["self_attn.q_proj"])
+            k = F.linear(h, blk["self_attn.k_proj"])
+            v = F.linear(h, blk["self_attn.v_proj"])
+            ops.attn_decode(q, k, v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, ROPE_THETA)
+            x = x + F.linear(self.att, blk["self_attn.o_proj"])
+            h2 = ops.rmsnorm(x, blk["ln2"], EPS)
+            x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]),
+                             blk["mlp.down_proj"])
+        ops.gemv_f16w(x.reshape(-1).contiguous(), self.lm_head, gamma=self.norm, eps=EPS, out=self.logits)
+        torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
+        self.pos.add_(1)
+
+    def prefill(self, ids):
+        F = torch.nn.functional
+        S = ids.numel()
+        if S > self.max_seq:
+            raise ValueError("prompt longer than the KV cache")
+        H, nh, nkv = self.H, self.nh, self.nkv
+        x = self.embed.index_select(0, ids.to(self.dev))
+        positions = torch.arange(S, device=self.dev)
+        for blk in self.blocks:
+            h = ops.rmsnorm(x, blk["ln1"], EPS)
+            q = F.linear(h, blk["self_attn.q_proj"]).view(S, nh, 128)
+            k = F.linear(h, blk["self_attn.k_proj"]).view(S, nkv, 128)
+            v = F.linear(h, blk["self_attn.v_proj"]).view(S, nkv, 128)
+            q, k = self._rope(q, positions), self._rope(k, positions)
+            blk["kc"][0, :, :S] = k.transpose(0, 1)
+            blk["vc"][0, :, :S] = v.transpose(0, 1)
+            qh, kh, vh = q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1)
+            if nkv != nh:
+                kh = kh.repeat_interleave(nh // nkv, dim=0)
+                vh = vh.repeat_interleave(nh // nkv, dim=0)
+            a = F.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
+            a = a.transpose(0, 1).reshape(S, H).contiguous()
+            x = x + F.linear(a, blk["self_attn.o_proj"])
+            h2 = ops.rmsnorm(x, blk["ln2"], EPS)
+            x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]), blk["mlp.down_proj"])
+        last = x[S - 1].contiguous()
+        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=EPS, out=self.logits)
+        torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
+        self.pos.fill_(S)
+        return self.logits
+
+
+def get_memory_footprint(model):
+    """bytes of weights + buffers (amq_speed_benchmark.py:87-95 counts parameters and buffers)"""
+    tot = model.embed.numel() * 2 + model.lm_head.numel() * 2 + model.norm.numel() * 2
+    for blk in model.blocks:
+        for k, v in blk.items():
+            if isinstance(v, torch.Tensor):
+                tot += v.numel() * v.element_size()
+            elif hasattr(v, "nbytes"):
+                tot += v.nbytes()
+    return tot

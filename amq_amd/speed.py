@@ -1,0 +1,120 @@
+"""benchmark_speed -- the reference's timing harness (amq/utils/speed.py:15-255) for QuantLlama.
+
+Same metric definitions and result keys:
+  TPS   gen_len / median(t_generate); t_generate covers prefill + gen_len greedy tokens,
+        synchronize-bracketed perf_counter                          (speed.py:22-46)
+  GeMV  1 / median(per-token forward latency) after one un-timed prefill; every token is
+        timed individually with a device sync on both sides         (speed.py:50-127)
+  GeMM  1 / median(prefill forward latency)                          (speed.py:61-71)
+  TTFT  median ms of prefill + argmax (the reference also counts tokenizer encode/decode;
+        no tokenizer files exist offline, so ids are used directly)  (speed.py:186-239)
+Returns ``{mode: {'B.S.G': value}}`` (+ ``'peak_memory'``) like the reference.
+The reference's static KV cache is batch-1 (ftllama_modeling.py:61-68); so is this runner.
+"""
+import gc
+import time
+
+import numpy as np
+import torch
+
+
+def cleanup():
+    torch.cuda.empty_cache()
+    gc.collect()
+
+
+@torch.inference_mode()
+def device_warmup(device):
+    """speed.py:15-19"""
+    w = torch.randn((4096, 4096)).to(device)
+    for _ in range(100):
+        torch.mm(w, w)
+
+
+@torch.inference_mode()
+def benchmark_tps(model, input_ids, gen_seq_len, iteration):
+    times = []
+    for _ in range(iteration):
+        cleanup()
+        model.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.generate(input_ids, gen_seq_len)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    return gen_seq_len / np.median(times)
+
+
+@torch.inference_mode()
+def benchmark_gemv_gemm(model, input_ids, gen_seq_len, iteration, mode="gemv"):
+    times = []
+    for _ in range(iteration):
+        cleanup()
+        model.reset()
+        if mode.lower() == "gemm":
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        model.prefill(input_ids)
+        if mode.lower() == "gemm":
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        if mode.lower() == "gemv":
+            for _ in range(gen_seq_len):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                model.decode_step()
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+    return 1 / np.median(times)
+
+
+@torch.inference_mode()
+def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 128, 128), mode="TPS", get_peak_memory=True):
+    """speed.py:131-255.  ``model``: a runner with reset()/prefill()/decode_step()/generate()
+    (QuantLlama or DenseLlama).  ``tokenizer`` / ``use_ft`` are accepted for signature parity."""
+    assert mode.lower() in ["tps", "gemv", "gemm", "ttft"], \
+        "speed benchmark mode should be one of ['TPS', 'GeMV', 'GeMM', 'TTFT']"
+    batch_size, input_seq_len, gen_seq_len = sizes
+    if batch_size != 1:
+        raise NotImplementedError("the static KV cache is batch 1 (as in the reference's FT path)")
+    if input_seq_len + gen_seq_len > model.max_seq:
+        raise ValueError("sizes do not fit the model's KV cache")
+    device = model.dev
+    data = {mode.lower(): {}}
+    if get_peak_memory:
+        cleanup()
+        torch.cuda.reset_peak_memory_stats(device=device)
+        data["peak_memory"] = {}
+    input_ids = torch.randint(0, model.vocab - 1, (input_seq_len,), dtype=torch.long).to(device)   # speed.py:162
+    device_warmup(device)
+    cleanup()
+    if get_peak_memory:
+        torch.cuda.reset_peak_memory_stats(device=device)
+    if mode.lower() == "tps":
+        model.capture()
+        speed = benchmark_tps(model, input_ids, gen_seq_len, iteration)
+    elif mode.lower() in ("gemv", "gemm"):
+        model.capture()
+        speed = benchmark_gemv_gemm(model, input_ids, gen_seq_len, iteration, mode)
+    else:
+        times = []
+        for _ in range(iteration):
+            cleanup()
+            model.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.prefill(input_ids)
+            _ = int(model.token.item())           # argmax token back on the host (the decode of one token)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1000)
+        speed = np.median(times)
+    key = f"{batch_size}.{input_seq_len}.{gen_seq_len}"
+    data[mode.lower()][key] = float(speed)
+    if get_peak_memory:
+        data["peak_memory"][key] = torch.cuda.max_memory_allocated(device=device) / 1024 ** 3
+    torch.cuda.reset_peak_memory_stats(device=device)
+    cleanup()
+    return data
+
+
+__all__ = ["benchmark_speed"]

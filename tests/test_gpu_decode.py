@@ -160,3 +160,28 @@ def test_generate_is_deterministic_and_graph_equals_eager():
     m.reset()
     b = m.generate(ids, 12, use_graph=False).clone()
     assert torch.equal(a, b)
+
+
+def test_speed_harness_modes_and_schema(tmp_path, monkeypatch):
+    """benchmark_speed / the CLI produce the reference's result schema ({row: {mode: {'B.S.G': v}}, 'args'})"""
+    from amq_amd import arch, speed_benchmark
+    arch.MODEL_CONFIGS["tiny-512"] = dict(arch._cfg(2, 512, 1024, 4, 4, 2 * (4 * 512 * 512 + 3 * 512 * 1024), vocab=1024))
+    try:
+        a, usage = arch.synthesize_arch(arch.MODEL_CONFIGS["tiny-512"], 3.0, seed=1, tol=0.3)
+        stats = tmp_path / "iter_0.stats"
+        arch.write_stats(str(stats), a, usage)
+        monkeypatch.chdir(tmp_path)
+        res = speed_benchmark.main(["--model_name", "tiny-512", "--tps", "--gemv", "--gemm", "--ttft", "--memory", "--peak_memory",
+                                    "--seq_length", "16", "--gen_length", "8", "--target_bits", str(usage),
+                                    "--arch_path", str(stats), "--file_name", "out.json"])
+    finally:
+        arch.MODEL_CONFIGS.pop("tiny-512", None)
+    row = f"{usage}bit"
+    assert set(res) == {"fp16", row, "args"}
+    for r in ("fp16", row):
+        for mode in ("tps", "gemv", "gemm", "ttft"):
+            assert list(res[r][mode]) == ["1.16.8"] and res[r][mode]["1.16.8"] > 0
+        assert res[r]["memory"] > 0 and "peak_memory" in res[r]
+    assert res[row]["memory"] < res["fp16"]["memory"]
+    import json, os
+    assert json.load(open(tmp_path / "benchmark" / "outputs" / "out.json"))["args"]["gen_length"] == 8
