@@ -203,15 +203,20 @@ int amq_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const
 
 int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcache, void* vcache, void* out,
                         const int* pos_dev, int pos, int batch, int n_heads, int n_kv_heads, int head_dim,
-                        int max_seq, float rope_theta, void* stream) {
+                        int max_seq, float rope_theta, const void* rope_table, void* stream) {
     if (!q || !k || !v || !kcache || !vcache || !out) return fail(AMQ_EINVAL, "null pointer");
     if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
     if (batch < 1 || n_heads < 1 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0)
         return fail(AMQ_ESHAPE, "bad head configuration (%d q heads, %d kv heads)", n_heads, n_kv_heads);
     if (max_seq < 1 || (!pos_dev && (pos < 0 || pos >= max_seq))) return fail(AMQ_ESHAPE, "position %d outside the cache (max_seq=%d)", pos, max_seq);
     if (4 * 128 + (size_t)max_seq * 4 > LDS_LIMIT) return fail(AMQ_ESHAPE, "max_seq=%d too long for the single-pass decode attention", max_seq);
-    amq::AttnArgs a{q, k, v, kcache, vcache, out, pos_dev, pos, n_heads, n_kv_heads, max_seq, rope_theta};
+    amq::AttnArgs a{q, k, v, kcache, vcache, out, pos_dev, pos, n_heads, n_kv_heads, max_seq, rope_theta, rope_table};
     return check_hip(amq::launch_attn_decode(a, batch, (hipStream_t)stream), "attn_decode");
+}
+
+int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream) {
+    if (!table || max_seq < 1) return fail(AMQ_EINVAL, "bad rope table request");
+    return check_hip(amq::launch_rope_table(table, max_seq, rope_theta, (hipStream_t)stream), "rope_table");
 }
 
 }  // extern "C"

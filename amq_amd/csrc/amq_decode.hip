@@ -190,7 +190,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     if (tid < 64) {
         const int i = tid;                          // rotary pair (i, i + 64)
         _Float16 c16, s16;
-        rope_cs(a.rope_theta, pos, i, &c16, &s16);
+        if (a.rope_table) {
+            const h2 cs2 = ((const h2*)a.rope_table)[(size_t)pos * 64 + i];
+            c16 = cs2.x; s16 = cs2.y;
+        } else {
+            rope_cs(a.rope_theta, pos, i, &c16, &s16);
+        }
         const _Float16 q0 = q[i], q1 = q[i + 64];
         qs[i] = q0 * c16 + (-q1) * s16;             // q*cos + rotate_half(q)*sin  (fp16 ops, HF apply_rotary_pos_emb)
         qs[i + 64] = q1 * c16 + q0 * s16;
@@ -220,7 +225,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
             else kv = *(const h8*)(kc + (size_t)t * ATT_D + 8 * j);
             const h8 qv = *(const h8*)(qs + 8 * j);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += (float)qv[e] * (float)kv[e];
+            for (int e = 0; e < 4; ++e)
+                s = __builtin_amdgcn_fdot2((h2){qv[2 * e], qv[2 * e + 1]}, (h2){kv[2 * e], kv[2 * e + 1]}, s, false);
         }
         // HF eager attention: matmul(q, k^T) -> fp16, * scaling -> fp16, softmax in fp32
         const float sv = (float)(_Float16)((float)(_Float16)s * scale);
@@ -261,6 +267,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         _Float16* out = (_Float16*)a.out + ((size_t)b * a.n_heads + h) * ATT_D;
         out[tid] = (_Float16)tot;
     }
+}
+
+// cos/sin table for positions 0..max_seq-1 (HF LlamaRotaryEmbedding values, fp32 math, fp16 storage)
+__global__ void rope_table_kernel(_Float16* tab, int max_seq, float theta) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= max_seq * 64) return;
+    _Float16 c16, s16;
+    rope_cs(theta, idx >> 6, idx & 63, &c16, &s16);
+    tab[2 * idx] = c16;
+    tab[2 * idx + 1] = s16;
+}
+
+hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st) {
+    hipLaunchKernelGGL(rope_table_kernel, dim3((max_seq * 64 + 255) / 256), dim3(256), 0, st, (_Float16*)tab, max_seq, theta);
+    return hipGetLastError();
 }
 
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st) {

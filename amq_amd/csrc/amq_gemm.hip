@@ -21,7 +21,8 @@ namespace amq {
 
 constexpr int GM_BN = 128;
 constexpr int GM_THREADS = 256;
-constexpr int GM_LDA = 128 + 8;     // halves per staged x row (272 B: conflict-free ds_read_b128)
+constexpr int GM_LDA = 128 + 16;    // halves per staged x row: 288 B = 18 sixteen-byte slots -> slot (2r + o + 4t) mod 16 is
+                                    // distinct inside every ds_read_b128 lane group (272 B measured 2-way conflicts)
 
 template <int BITS, int MODE, int BM>
 __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {

@@ -61,7 +61,7 @@ __device__ __forceinline__ int lin_shift(int bits, int t, int p) {
 // Writes the (transformed) activations into LDS as fp16.
 //   exact / dot : xl[m][xs]
 //   linear      : for every bit-width b in lin_mask a copy xl_b[m][xs] pre-scaled by 2^-shift, and
-//                 xg[m][G] = per-group sums of x (fp32)
+//                 xg[G][16] = per-group sums of x per row (fp32; rows >= M are zero)
 template <int PRO, int NW, bool LIN>
 __device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* xg, float* red, int xs) {
     constexpr int THREADS = NW * 64;
@@ -69,6 +69,9 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* 
     const int K = a.K;
     const int chunks = K >> 3;      // 8 halves per chunk
     const size_t copy_stride = (size_t)a.M * xs;
+    if (LIN)
+        for (int i = tid; i < (K >> 7) * 16; i += THREADS) xg[i] = 0.f;      // (rows written below are disjoint from these only by thread; ordered by the barrier after staging)
+    if (LIN) __syncthreads();
     for (int m = 0; m < a.M; ++m) {
         const _Float16* xrow = (const _Float16*)a.x + (size_t)m * a.x_stride;
         _Float16* lrow = xl + (size_t)m * xs;
@@ -128,7 +131,7 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) cs += (float)r[i];
                 cs += __shfl_xor(cs, 1); cs += __shfl_xor(cs, 2); cs += __shfl_xor(cs, 4); cs += __shfl_xor(cs, 8);
-                if ((tid & 15) == 0) xg[(size_t)m * (K >> 7) + (c >> 4)] = cs;    // 16 chunks = one 128-k group
+                if ((tid & 15) == 0) xg[(size_t)(c >> 4) * 16 + m] = cs;          // 16 chunks = one 128-k group; [G][16 rows]
             }
         }
     }
@@ -306,13 +309,9 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
                 const float sf = (float)meta[slot].x, zf = (float)meta[slot].y;                  \
                 const float s24 = sf * 16777216.0f;                                              \
                 const float zx = (MODE == MODE_HQQ) ? -(sf * zf) : zf;                           \
-                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                               \
-                    if (i_ < a.M) {                                                              \
-                        const int m_ = (4 * o + i_) < a.M ? (4 * o + i_) : a.M - 1;              \
-                        const float xs_ = xg[(size_t)m_ * G + g_];                               \
-                        accm[i_] = __builtin_fmaf(s24, c_[i_], __builtin_fmaf(zx, xs_, accm[i_])); \
-                    }                                                                            \
-                }                                                                                \
+                const f4 xs4 = *(const f4*)(xg + g_ * 16 + 4 * o);                               \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                 \
+                    accm[i_] = __builtin_fmaf(s24, c_[i_], __builtin_fmaf(zx, xs4[i_], accm[i_])); \
             } else {                                                                             \
                 accm = c_;                                                                       \
             }                                                                                    \
@@ -366,8 +365,8 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES) void gemv_kernel(GemvArgs a)
     const int xs = a.K + XPAD;
     _Float16* xl = (_Float16*)smem;
     const size_t xbytes = ((size_t)a.M * xs * 2 * (MATH == MATH_LINEAR ? a.lin_copies : 1) + 15) & ~(size_t)15;
-    float* xg = (float*)(smem + xbytes);                                        // [M][G] (linear math only)
-    const size_t xgbytes = (MATH == MATH_LINEAR) ? (((size_t)a.M * (a.K >> 7) * 4 + 15) & ~(size_t)15) : 0;
+    float* xg = (float*)(smem + xbytes);                                        // [G][16] (linear math only)
+    const size_t xgbytes = (MATH == MATH_LINEAR) ? (size_t)(a.K >> 7) * 64 : 0;
     float* red = (float*)(smem + xbytes + xgbytes);                             // [2][NW][16][16]
 
     int sidx = 0;
@@ -396,7 +395,7 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES) void gemv_kernel(GemvArgs a)
 
 size_t gemv_lds_bytes(int M, int K, int copies) {
     const size_t xbytes = (((size_t)M * (K + XPAD) * 2 * copies) + 15) & ~(size_t)15;
-    const size_t xg = (((size_t)M * (K >> 7) * 4 + 15) & ~(size_t)15);
+    const size_t xg = (size_t)(K >> 7) * 64;
     const size_t red = (size_t)2 * 16 /*max NW*/ * 16 * 16 * 4;
     return xbytes + xg + red;
 }

@@ -68,7 +68,9 @@ struct AttnArgs {
     int pos;
     int n_heads, n_kv_heads, max_seq;
     float rope_theta;
+    const void* rope_table;   // fp16 [max_seq][64][2] (cos, sin) from launch_rope_table, or null -> computed in-kernel
 };
+hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st);
 hipError_t launch_rmsnorm(const void* x, const void* gamma, void* y, int M, int K, float eps, hipStream_t st);
 hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,

@@ -125,6 +125,7 @@ class QuantLlama:
         self.logits = torch.zeros(self.vocab, **f16)
         self.token = torch.zeros(1, dtype=torch.int64, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.rope_tab = ops.rope_table(max_seq, ROPE_THETA, dev)
         self.graph = None
 
     # ----------------------------------------------------------------- sizes
@@ -145,7 +146,8 @@ class QuantLlama:
             ops.gemv_grouped(self.x, [blk["self_attn.q_proj"].seg(self.q), blk["self_attn.k_proj"].seg(self.k),
                                       blk["self_attn.v_proj"].seg(self.v)], H, prologue=ops.PRO_RMSNORM,
                              gamma=blk["ln1"], eps=EPS)
-            ops.attn_decode(self.q, self.k, self.v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, ROPE_THETA)
+            ops.attn_decode(self.q, self.k, self.v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, ROPE_THETA,
+                            table=self.rope_tab)
             ops.gemv_grouped(self.att, [blk["self_attn.o_proj"].seg(self.x, residual=self.x)], H)
             ops.gemv_grouped(self.x, [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H,
                              prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=EPS)
@@ -287,6 +289,7 @@ class DenseLlama(QuantLlama):
         self.logits = torch.zeros(self.vocab, **f16)
         self.token = torch.zeros(1, dtype=torch.int64, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.rope_tab = ops.rope_table(max_seq, ROPE_THETA, dev)
         self.graph = None
 
     def linear_bytes_per_token(self):
@@ -301,7 +304,7 @@ class DenseLlama(QuantLlama):
             q = F.linear(h, blk["self_attn.q_proj"])
             k = F.linear(h, blk["self_attn.k_proj"])
             v = F.linear(h, blk["self_attn.v_proj"])
-            ops.attn_decode(q, k, v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, ROPE_THETA)
+            ops.attn_decode(q, k, v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, ROPE_THETA, table=self.rope_tab)
             x = x + F.linear(self.att, blk["self_attn.o_proj"])
             h2 = ops.rmsnorm(x, blk["ln2"], EPS)
             x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]),

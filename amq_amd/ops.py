@@ -233,7 +233,13 @@ def gemv_f16w(x, W, bias=None, gamma=None, eps=0.0, out=None):
     return y
 
 
-def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_theta=10000.0):
+def rope_table(max_seq, rope_theta, device):
+    tab = torch.empty(max_seq, 64, 2, dtype=torch.float16, device=device)
+    _lib.check(_lib.load().amq_rope_table_f16(_lib.ptr(tab), max_seq, ctypes.c_float(rope_theta), _lib.current_stream()))
+    return tab
+
+
+def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_theta=10000.0, table=None):
     """One new token per sequence.  q [B, n_heads*128], k/v [B, n_kv_heads*128],
     caches [B, n_kv_heads, max_seq, 128]; ``pos`` is an int or a device int32 tensor."""
     B = kcache.shape[0]
@@ -251,7 +257,9 @@ def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_the
         pos_dev, pos_i = None, int(pos)
         if not 0 <= pos_i < max_seq:
             raise ValueError(f"pos {pos_i} outside the cache (max_seq={max_seq})")
+    if table is not None:
+        _need(table, torch.float16, "rope table", max_seq * 128)
     _lib.check(_lib.load().amq_attn_decode_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(kcache), _lib.ptr(vcache),
                                                _lib.ptr(out), pos_dev, pos_i, B, n_heads, n_kv_heads, 128, max_seq,
-                                               ctypes.c_float(rope_theta), _lib.current_stream()))
+                                               ctypes.c_float(rope_theta), _lib.ptr(table), _lib.current_stream()))
     return out

@@ -145,7 +145,9 @@ int amq_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const
  * Replaces FT single_query_attention (ft/attention/decoder_masked_multihead_attention.cu:30-61) with HF-Llama numerics. */
 int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcache, void* vcache, void* out,
                         const int* pos_dev, int pos, int batch, int n_heads, int n_kv_heads, int head_dim,
-                        int max_seq, float rope_theta, void* stream);
+                        int max_seq, float rope_theta, const void* rope_table, void* stream);
+/* optional: fp16 [max_seq][64][2] (cos, sin) table for amq_attn_decode_f16 (NULL there = computed in-kernel, same values) */
+int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream);
 
 #ifdef __cplusplus
 }

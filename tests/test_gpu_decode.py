@@ -68,7 +68,8 @@ def test_attn_decode_sequence(nh, nkv):
         v = torch.randn(1, nkv, 128, generator=g).half().to(dev)
         if pos % 2:
             posd.fill_(pos)
-            ops.attn_decode(q.reshape(1, -1), k.reshape(1, -1), v.reshape(1, -1), kc, vc, out, posd, nh, nkv)
+            ops.attn_decode(q.reshape(1, -1), k.reshape(1, -1), v.reshape(1, -1), kc, vc, out, posd, nh, nkv,
+                            table=ops.rope_table(max_seq, 10000.0, dev) if pos % 4 == 1 else None)
         else:
             ops.attn_decode(q.reshape(1, -1), k.reshape(1, -1), v.reshape(1, -1), kc, vc, out, pos, nh, nkv)
         ks.append(_rope_ref(k[0], pos)); vs.append(v[0])
