@@ -196,7 +196,7 @@ int amq_rmsnorm_f16(const void* x, const void* gamma, void* y, int M, int K, flo
 int amq_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                   int N, int K, void* stream) {
     if (!x || !W || !y) return fail(AMQ_EINVAL, "null pointer");
-    if (N < 1 || K < 512 || (K % 512) != 0) return fail(AMQ_ESHAPE, "need K %% 512 == 0 (got N=%d K=%d)", N, K);
+    if (N < 1 || K < 8 || (K % 8) != 0) return fail(AMQ_ESHAPE, "need K %% 8 == 0 (got N=%d K=%d)", N, K);
     if ((size_t)K * 2 + 64 > 64 * 1024) return fail(AMQ_ESHAPE, "K=%d too large for the fp16-weight GEMV", K);
     return check_hip(amq::launch_gemv_f16w(x, W, bias, y, gamma, eps, N, K, (hipStream_t)stream), "gemv_f16w");
 }

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(F16W_WAVES * 64) void gemv_f16w_kernel(const _Float
     }
     __syncthreads();
     const int gw = blockIdx.x * F16W_WAVES + wave, nw = gridDim.x * F16W_WAVES;
-    const int steps = K >> 9;                       // 512 k per wave-load (host guarantees K % 512 == 0)
+    const int steps = (K + 511) >> 9;               // 512 k per wave-load; lanes past K are masked (K % 8 == 0)
     for (int row = gw; row < N; row += nw) {
         const _Float16* wr = W + (size_t)row * K + 8 * lane;
         float acc = 0.f;
@@ -109,10 +109,10 @@ __global__ __launch_bounds__(F16W_WAVES * 64) void gemv_f16w_kernel(const _Float
             u4 buf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (s + j < steps) buf[j] = AMQ_STREAM_LOAD((const u4*)(wr + (size_t)(s + j) * 512));
+                if (s + j < steps && (s + j) * 512 + 8 * lane < K) buf[j] = AMQ_STREAM_LOAD((const u4*)(wr + (size_t)(s + j) * 512));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (s + j < steps) {
+                if (s + j < steps && (s + j) * 512 + 8 * lane < K) {
                     const h8 xv = *(const h8*)(xl + (s + j) * 512 + 8 * lane);
                     const uint32_t wv[4] = {buf[j].x, buf[j].y, buf[j].z, buf[j].w};
 #pragma unroll

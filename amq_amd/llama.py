@@ -78,6 +78,8 @@ class QuantLlama:
         self.nb = config["n_block"]
         self.vocab = config["vocab_size"]
         self.max_seq = max_seq
+        self.eps = float(config.get("rms_norm_eps", EPS))
+        self.theta = float(config.get("rope_theta", ROPE_THETA))
         arch_linear = arch_linear or uniform_arch(config, 4)["linear"]
         self.arch_linear = arch_linear
         gen = torch.Generator(device=self.dev).manual_seed(seed)
@@ -125,7 +127,7 @@ class QuantLlama:
         self.logits = torch.zeros(self.vocab, **f16)
         self.token = torch.zeros(1, dtype=torch.int64, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.rope_tab = ops.rope_table(max_seq, ROPE_THETA, dev)
+        self.rope_tab = ops.rope_table(max_seq, self.theta, dev)
         self.graph = None
 
     # ----------------------------------------------------------------- sizes
@@ -145,15 +147,15 @@ class QuantLlama:
         for blk in self.blocks:
             ops.gemv_grouped(self.x, [blk["self_attn.q_proj"].seg(self.q), blk["self_attn.k_proj"].seg(self.k),
                                       blk["self_attn.v_proj"].seg(self.v)], H, prologue=ops.PRO_RMSNORM,
-                             gamma=blk["ln1"], eps=EPS)
-            ops.attn_decode(self.q, self.k, self.v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, ROPE_THETA,
+                             gamma=blk["ln1"], eps=self.eps)
+            ops.attn_decode(self.q, self.k, self.v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, self.theta,
                             table=self.rope_tab)
             ops.gemv_grouped(self.att, [blk["self_attn.o_proj"].seg(self.x, residual=self.x)], H)
             ops.gemv_grouped(self.x, [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H,
-                             prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=EPS)
+                             prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=self.eps)
             ops.gemv_grouped(self.gate, [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I,
                              prologue=ops.PRO_SILU_MUL, x2=self.up)
-        ops.gemv_f16w(self.x.reshape(-1), self.lm_head, gamma=self.norm, eps=EPS, out=self.logits)
+        ops.gemv_f16w(self.x.reshape(-1), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
         self.pos.add_(1)
 
@@ -187,7 +189,7 @@ class QuantLlama:
     # ---------------------------------------------------------------- prefill
     def _rope(self, t, positions):
         # HF apply_rotary_pos_emb: cos/sin in fp32 -> fp16; rotate_half
-        inv = 1.0 / (ROPE_THETA ** (torch.arange(0, 128, 2, device=self.dev, dtype=torch.float32) / 128.0))
+        inv = 1.0 / (self.theta ** (torch.arange(0, 128, 2, device=self.dev, dtype=torch.float32) / 128.0))
         fr = positions.to(torch.float32)[:, None] * inv[None, :]
         emb = torch.cat([fr, fr], dim=-1)
         cos, sin = emb.cos().to(torch.float16)[:, None, :], emb.sin().to(torch.float16)[:, None, :]
@@ -208,7 +210,7 @@ class QuantLlama:
             return ops.linear(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K)
 
         for blk in self.blocks:
-            h = ops.rmsnorm(x, blk["ln1"], EPS)
+            h = ops.rmsnorm(x, blk["ln1"], self.eps)
             q = lin(blk["self_attn.q_proj"], h).view(S, nh, 128)
             k = lin(blk["self_attn.k_proj"], h).view(S, nkv, 128)
             v = lin(blk["self_attn.v_proj"], h).view(S, nkv, 128)
@@ -222,11 +224,11 @@ class QuantLlama:
             a = torch.nn.functional.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
             a = a.transpose(0, 1).reshape(S, H).contiguous()
             x = x + lin(blk["self_attn.o_proj"], a)
-            h2 = ops.rmsnorm(x, blk["ln2"], EPS)
+            h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
             x = x + lin(blk["mlp.down_proj"], torch.nn.functional.silu(g) * u)
         last = x[S - 1].contiguous()
-        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=EPS, out=self.logits)
+        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
         self.pos.fill_(S)
         return self.logits
@@ -267,6 +269,8 @@ class DenseLlama(QuantLlama):
         self.nh, self.nkv = config["num_heads"], config["num_kv_heads"]
         self.kvd = self.nkv * 128
         self.nb, self.vocab, self.max_seq = config["n_block"], config["vocab_size"], max_seq
+        self.eps = float(config.get("rms_norm_eps", EPS))
+        self.theta = float(config.get("rope_theta", ROPE_THETA))
         gen = torch.Generator(device=self.dev).manual_seed(seed)
         dev = self.dev
         f16 = dict(dtype=torch.float16, device=dev)
@@ -289,7 +293,7 @@ class DenseLlama(QuantLlama):
         self.logits = torch.zeros(self.vocab, **f16)
         self.token = torch.zeros(1, dtype=torch.int64, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.rope_tab = ops.rope_table(max_seq, ROPE_THETA, dev)
+        self.rope_tab = ops.rope_table(max_seq, self.theta, dev)
         self.graph = None
 
     def linear_bytes_per_token(self):
@@ -300,16 +304,16 @@ class DenseLlama(QuantLlama):
         torch.index_select(self.embed, 0, self.token, out=self.x)
         x = self.x
         for blk in self.blocks:
-            h = ops.rmsnorm(x, blk["ln1"], EPS)
+            h = ops.rmsnorm(x, blk["ln1"], self.eps)
             q = F.linear(h, blk["self_attn.q_proj"])
             k = F.linear(h, blk["self_attn.k_proj"])
             v = F.linear(h, blk["self_attn.v_proj"])
-            ops.attn_decode(q, k, v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, ROPE_THETA, table=self.rope_tab)
+            ops.attn_decode(q, k, v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, self.theta, table=self.rope_tab)
             x = x + F.linear(self.att, blk["self_attn.o_proj"])
-            h2 = ops.rmsnorm(x, blk["ln2"], EPS)
+            h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]),
                              blk["mlp.down_proj"])
-        ops.gemv_f16w(x.reshape(-1).contiguous(), self.lm_head, gamma=self.norm, eps=EPS, out=self.logits)
+        ops.gemv_f16w(x.reshape(-1).contiguous(), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
         self.pos.add_(1)
 
@@ -322,7 +326,7 @@ class DenseLlama(QuantLlama):
         x = self.embed.index_select(0, ids.to(self.dev))
         positions = torch.arange(S, device=self.dev)
         for blk in self.blocks:
-            h = ops.rmsnorm(x, blk["ln1"], EPS)
+            h = ops.rmsnorm(x, blk["ln1"], self.eps)
             q = F.linear(h, blk["self_attn.q_proj"]).view(S, nh, 128)
             k = F.linear(h, blk["self_attn.k_proj"]).view(S, nkv, 128)
             v = F.linear(h, blk["self_attn.v_proj"]).view(S, nkv, 128)
@@ -336,10 +340,10 @@ class DenseLlama(QuantLlama):
             a = F.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
             a = a.transpose(0, 1).reshape(S, H).contiguous()
             x = x + F.linear(a, blk["self_attn.o_proj"])
-            h2 = ops.rmsnorm(x, blk["ln2"], EPS)
+            h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]), blk["mlp.down_proj"])
         last = x[S - 1].contiguous()
-        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=EPS, out=self.logits)
+        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
         self.pos.fill_(S)
         return self.logits

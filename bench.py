@@ -53,7 +53,7 @@ def build_model(device, seed=0, max_seq=1024):
 def gemv_roofline(m, reps=20):
     """time a graph holding only the GEMV launches of one token (4 per block)"""
     from amq_amd import ops
-    from amq_amd.llama import EPS
+    EPS = 1e-5
     dev = m.dev
     H, I = m.H, m.I
 

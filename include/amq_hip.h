@@ -137,7 +137,7 @@ int amq_gemv_grouped_f16(const amq_segment* segments /* host */, int nseg,
 /* ---- decode-step surroundings (next tier: what sits between the linears in one token step) ---- */
 /* y = gamma * fp16(x * rsqrt(mean(x^2) + eps)), rows of K; replaces FT layernorm_forward_cuda (ft/layernorm/layernorm.cu:25-77) */
 int amq_rmsnorm_f16(const void* x, const void* gamma, void* y, int M, int K, float eps, void* stream);
-/* y[N] = (optionally RMSNorm'ed) x[K] . W^T for fp16 W[N,K] (lm_head), K % 512 == 0; gamma NULL = no norm */
+/* y[N] = (optionally RMSNorm'ed) x[K] . W^T for fp16 W[N,K] (lm_head), K % 8 == 0; gamma NULL = no norm */
 int amq_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                   int N, int K, void* stream);
 /* one new token per sequence: RoPE(q, k) at position *pos_dev (or pos if pos_dev is NULL), append k/v to the

@@ -186,3 +186,30 @@ def test_speed_harness_modes_and_schema(tmp_path, monkeypatch):
     assert res[row]["memory"] < res["fp16"]["memory"]
     import json, os
     assert json.load(open(tmp_path / "benchmark" / "outputs" / "out.json"))["args"]["gen_length"] == 8
+
+
+def test_reference_checkpoints_mixed_arch_logits():
+    """tests/golden/ckpt: HQQ checkpoints written by the reference's own quantize_model/save_quantized (2/3/4 bit) and
+    the logits its CPU forward gives for a mixed arch assembled like amq_speed_benchmark.py:231-251.  The loader +
+    prefill (MFMA GEMM) + graph decode (GEMV) must reproduce them."""
+    import json, os
+    from amq_amd.checkpoint import load_mixed
+    root = os.path.join(os.path.dirname(__file__), "golden", "ckpt")
+    exp = np.load(os.path.join(root, "expected.npz"))
+    arch_linear = json.loads(str(exp["arch"]))
+    m = load_mixed({b: os.path.join(root, f"{b}bit") for b in (2, 3, 4)}, arch_linear, max_seq=64)
+    assert (m.H, m.I, m.nb, m.vocab) == (256, 512, 2, 256)
+    ids = torch.from_numpy(exp["ids"]).to(_dev())
+    ref = exp["logits"]                                            # [5, vocab] fp32
+    scale = np.abs(ref).max()
+    lg = m.prefill(ids).float().cpu().numpy()
+    assert np.abs(lg - ref[0]).max() <= 2e-2 * scale
+    toks = [int(m.token.item())]
+    for step in range(1, 5):
+        # feed the REFERENCE's greedy token so both see the same prefix even if an argmax tie flips
+        m.token.fill_(int(exp["tokens"][step - 1]))
+        m.decode_step(use_graph=(step >= 2))
+        lg = m.logits.float().cpu().numpy()
+        assert np.abs(lg - ref[step]).max() <= 2e-2 * scale, step
+        toks.append(int(m.token.item()))
+    assert toks == [int(t) for t in exp["tokens"]]
