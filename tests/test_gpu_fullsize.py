@@ -1,0 +1,73 @@
+"""GPU: BASELINE.json's full layer shapes (7B / 13B / 70B incl. GQA k/v 1024x8192 and 28672-wide MLP), checked
+through size-independent properties, because the CPU oracle cannot finish these sizes in seconds:
+  * GEMV (M=1, weight-streaming path) == row 0 of the tiled MFMA GEMM on the same weights (two independent kernels);
+  * both == torch matmul on the weights returned by the bit-exact dequantize kernel (fp32 accumulate);
+  * homogeneity in x: f(2x) == 2 f(x) exactly (power-of-two scaling commutes with every rounding in the path;
+    fp16-subnormal outputs excepted);
+  * determinism across repeated launches."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (N, K) from amq/configs/llama.json linear_shape
+    (4096, 4096), (11008, 4096), (4096, 11008),            # 7B
+    (5120, 5120), (13824, 5120), (5120, 13824),            # 13B
+    (8192, 8192), (1024, 8192), (28672, 8192), (8192, 28672),   # 70B
+]
+
+
+def _native(bits, n, k, seed):
+    from amq_amd.llama import _synthetic_linear
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    return _synthetic_linear(n, k, bits, g, torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("n,k", SHAPES)
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_fullsize_properties(bits, n, k):
+    from amq_amd import ops
+    dev = torch.device("cuda:0")
+    l = _native(bits, n, k, seed=n + k + bits)
+    x = torch.randn(1, k, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).half()
+    y = ops.gemv(x, l.qn, l.mn, bits, l.mode, n, k)
+    # (1) two independent kernels agree (fp32 accumulation order differs -> at most an fp16 ulp)
+    xm = torch.cat([x, torch.randn(16, k, device=dev).half()])
+    ym = ops.gemm(xm, l.qn, l.mn, bits, l.mode, n, k)
+    rms = y.float().pow(2).mean().sqrt()
+    assert (y[0].float() - ym[0].float()).abs().max() <= 2.0 ** -9 * y.float().abs().max() + 1e-3 * rms
+    # (2) against torch on the bit-exactly dequantized weights
+    w = ops.dequantize(l.qn, l.mn, bits, l.mode, n, k)
+    ref = (x.float() @ w.float().t())
+    err = (y.float() - ref).abs()
+    assert torch.all(err <= 1e-3 * ref.abs() + 1e-3 * rms)
+    assert torch.all((ym.float() - xm.float() @ w.float().t()).abs() <= 1e-3 * (xm.float() @ w.float().t()).abs() + 1e-3 * rms)
+    # (3) exact homogeneity, (4) determinism
+    y2 = ops.gemv(x * 2, l.qn, l.mn, bits, l.mode, n, k)
+    normal = y.float().abs() >= 2.0 ** -13          # fp16-subnormal outputs have fixed absolute spacing: not scale invariant
+    assert torch.equal(y2[normal], (y * 2)[normal]) and (y2.float() - 2 * y.float()).abs().max() <= 2.0 ** -24
+    assert torch.equal(ops.gemv(x, l.qn, l.mn, bits, l.mode, n, k), y)
+
+
+def test_llama70b_block_shapes_grouped_decode_step():
+    """one 70B-shaped block (GQA: 64 q heads, 8 kv heads) through the grouped launches of the token step"""
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama
+    cfg = dict(arch.MODEL_CONFIGS["Llama-2-70b-hf"])
+    cfg["n_block"] = 1
+    cfg["vocab_size"] = 2048
+    al = {name: [b] for name, b in zip(cfg["linear"], [4, 2, 3, 3, 2, 4, 3])}
+    m = QuantLlama(cfg, al, max_seq=48, seed=0)
+    ids = torch.randint(0, 2048, (20,), device="cuda:0")
+    m.prefill(ids)
+    a = m.logits.clone()
+    for _ in range(3):
+        m.decode_step()
+    assert torch.isfinite(m.logits.float()).all() and int(m.pos.item()) == 23
+    # same prefix through the eager path gives the same logits as the graph path
+    m2 = QuantLlama(cfg, al, max_seq=48, seed=0)
+    m2.prefill(ids)
+    assert torch.equal(m2.logits, a)
+    for _ in range(3):
+        m2.decode_step(use_graph=False)
+    assert torch.equal(m2.logits, m.logits)
