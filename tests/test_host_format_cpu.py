@@ -1,0 +1,69 @@
+"""CPU: host-side format plumbing of the product (amq_amd/hqq_format.py, checkpoint loader) against the oracle and
+the golden captures -- no GPU, no compute through the library."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from amq_amd import hqq_format
+from amq_amd.checkpoint import load_hqq_dir, runner_config
+from oracle import hqq_ref
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("rows", [8, 20, 52, 410])
+def test_pack_rows_equals_reference_bitpack(bits, rows):
+    if (bits == 4 and rows % 2) or (bits == 2 and rows % 4):
+        pytest.skip("HQQ packs 4/2-bit row chunks of equal size")
+    q = torch.randint(0, 2 ** bits, (rows, 128), generator=torch.Generator().manual_seed(rows + bits), dtype=torch.int32)
+    mine = hqq_format.pack_rows(q, bits).numpy()
+    ref = {4: hqq_ref.pack_4bit_u8, 3: hqq_ref.pack_3bit_32, 2: hqq_ref.pack_2bit_u8}[bits](q.numpy())
+    assert mine.dtype == ref.dtype and np.array_equal(mine, ref)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_quantize_rtn_is_a_valid_hqq_layer(bits):
+    w = torch.randn(64, 256, generator=torch.Generator().manual_seed(bits)) * 0.02
+    h = hqq_format.quantize_rtn(w.half(), bits)
+    assert h.scale.dtype == torch.float16 and h.scale.shape == (64 * 256 // 128, 1) and h.meta["packing"] == hqq_format.PACKING[bits]
+    deq = hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (64, 256)).astype(np.float32)
+    step = h.scale.float().numpy().repeat(128, axis=1).reshape(64, 256)
+    assert np.all(np.abs(deq - w.half().float().numpy()) <= 0.51 * step + 1e-4)      # round-to-nearest within half a step
+
+
+def test_from_hqq_layer_duck_typing_and_rejections():
+    class HQQLinear:                                    # same attribute surface as the reference class
+        pass
+    h = hqq_format.random_hqq(32, 256, 3, seed=1, bias=True)
+    layer = HQQLinear()
+    layer.W_q, layer.meta, layer.bias, layer.name = torch.nn.Parameter(h.W_q, requires_grad=False), dict(h.meta), h.bias, "q_proj"
+    got = hqq_format.from_hqq_layer(layer)
+    assert got.nbits == 3 and tuple(got.shape) == (32, 256) and got.name == "q_proj" and torch.equal(got.W_q, h.W_q)
+    for key, val, exc in (("axis", 0, ValueError), ("group_size", 64, ValueError), ("nbits", 8, NotImplementedError),
+                          ("view_as_float", True, ValueError)):
+        bad = dict(h.meta); bad[key] = val
+        layer.meta = bad
+        with pytest.raises(exc):
+            hqq_format.from_hqq_layer(layer)
+
+
+def test_checkpoint_loader_reads_reference_files():
+    root = os.path.join(GOLDEN, "ckpt")
+    for bits in (2, 3, 4):
+        hf, w = load_hqq_dir(os.path.join(root, f"{bits}bit"))
+        cfg = runner_config(hf)
+        assert (cfg["hidden_size"], cfg["intermediate_size"], cfg["n_block"], cfg["vocab_size"], cfg["head_dim"]) == (256, 512, 2, 256, 128)
+        q = w["model.layers.1.mlp.down_proj"]
+        assert isinstance(q, hqq_format.HQQWeights) and q.nbits == bits and tuple(q.shape) == (256, 512)
+        assert w["lm_head"]["weight"].shape == (256, 256) and w["model.norm"]["weight"].dtype == torch.float16
+        # the payload is a valid HQQ layer: the oracle dequantizes it to finite values in the weight range
+        d = hqq_ref.dequantize(q.W_q.numpy(), q.scale.numpy(), q.zero.numpy(), bits, (256, 512))
+        assert np.isfinite(d.astype(np.float32)).all() and np.abs(d.astype(np.float32)).max() < 1.0
+    exp = np.load(os.path.join(root, "expected.npz"))
+    assert set(json.loads(str(exp["arch"]))) == set(hqq_format.PACKING and ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj",
+                                                                            "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"])
