@@ -16,7 +16,7 @@ AMQ_OK = 0
 MODE_HQQ, MODE_FMA = 0, 1
 PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
-OPT_GEMV_DOT, OPT_GEMV_WAVES, OPT_GEMV_DEPTH, OPT_GEMV_RPT, OPT_GEMV_MATH = 1, 2, 3, 4, 5
+OPT_GEMV_DOT, OPT_GEMV_WAVES, OPT_GEMV_DEPTH, OPT_GEMV_RPT, OPT_GEMV_MATH, OPT_GEMM_NSUB = 1, 2, 3, 4, 5, 6
 MATH_EXACT, MATH_LINEAR = 0, 1
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t

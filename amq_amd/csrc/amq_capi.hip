@@ -63,6 +63,11 @@ int amq_set_option(int option, int value) {
         g_opt_depth = value;
         return AMQ_OK;
     }
+    if (option == AMQ_OPT_GEMM_NSUB) {
+        if (value != 0 && value != 2 && value != 4) return fail(AMQ_EINVAL, "gemm sub-tiles must be 0, 2 or 4");
+        amq::g_gemm_nsub = value;
+        return AMQ_OK;
+    }
     if (option == AMQ_OPT_GEMV_RPT) {
         if (value < 0 || value > 64) return fail(AMQ_EINVAL, "row-tiles per workgroup must be 0..64");
         g_opt_rpt = value;

@@ -187,6 +187,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) krow[j] = *(const h8*)(kc + (size_t)t_own * ATT_D + 8 * j);
     }
+    // ... and the first 8 value rows of its (key group, 8-dim slice): the K and V HBM round trips overlap
+    constexpr int VPRE = 8;
+    h8 vpre[VPRE];
+    {
+        const int kg0 = tid >> 4, l0 = tid & 15;
+#pragma unroll
+        for (int i = 0; i < VPRE; ++i) {
+            const int t = kg0 + 16 * i;
+            if (t < pos) vpre[i] = *(const h8*)(vc + (size_t)t * ATT_D + 8 * l0);
+        }
+    }
     if (tid < 64) {
         const int i = tid;                          // rotary pair (i, i + 64)
         _Float16 c16, s16;
@@ -251,8 +262,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     // out = sum_t p_t * V[t]: 16 key groups x 16 lanes, 8 dims (16 B) per lane
     const int kg = tid >> 4, l = tid & 15;
     float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = kg; t < T; t += 16) {
-        const _Float16 p16 = (_Float16)(sc[t] * inv);            // softmax(...).to(fp16)
+#pragma unroll
+    for (int i = 0; i < VPRE; ++i) {
+        const int t = kg + 16 * i;
+        if (t < T) {
+            const _Float16 p16 = (_Float16)(sc[t] * inv);        // softmax(...).to(fp16)
+            const h8 vv = (t == pos) ? *(const h8*)(vn + 8 * l) : vpre[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += (float)p16 * (float)vv[e];
+        }
+    }
+    for (int t = kg + 16 * VPRE; t < T; t += 16) {
+        const _Float16 p16 = (_Float16)(sc[t] * inv);
         const h8 vv = (t == pos) ? *(const h8*)(vn + 8 * l) : *(const h8*)(vc + (size_t)t * ATT_D + 8 * l);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += (float)p16 * (float)vv[e];

@@ -6,8 +6,8 @@
 //   (hqq/backends/autogptq.py:245-283)
 // for 2/3/4-bit alike, over the native AMQ-T16 layout.
 //
-// Structure: workgroup tile BM x 128 (BM = 128 or 64), BK = 128 (one quant group), 4 waves side by
-// side along N (wave tile BM x 32).  x tiles are double-buffered through LDS
+// Structure: workgroup tile BM x (64*NSUB) (BM = 128 or 64, NSUB = 2 or 4), BK = 128 (one quant group), 4 waves side by
+// side along N (wave tile BM x 16*NSUB).  x tiles are double-buffered through LDS
 // (register-staged: issue-early / write-late); the packed W tile never
 // touches LDS -- each lane's 16/12/8-byte payload unpacks (v_and_or +
 // v_pk_*_f16) directly into the B operand of v_mfma_f32_16x16x32_f16 and is
@@ -19,13 +19,15 @@
 
 namespace amq {
 
-constexpr int GM_BN = 128;
 constexpr int GM_THREADS = 256;
 constexpr int GM_LDA = 128 + 16;    // halves per staged x row: 288 B = 18 sixteen-byte slots -> slot (2r + o + 4t) mod 16 is
                                     // distinct inside every ds_read_b128 lane group (272 B measured 2-way conflicts)
 
-template <int BITS, int MODE, int BM>
+// NSUB = 16-column sub-tiles per wave: every A fragment read from LDS feeds NSUB MFMAs (LDS read traffic per
+// MFMA falls as 1/NSUB; accumulators grow as BM/16 * NSUB * 4 VGPRs).  Workgroup tile = BM x (4 waves * 16 * NSUB).
+template <int BITS, int MODE, int BM, int NSUB>
 __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
+    constexpr int GM_BN = 4 * 16 * NSUB;
     constexpr int MBLK = BM / 16;              // 16-row blocks per wave tile
     constexpr int ACH = BM * 16 / GM_THREADS;  // 16-byte chunks of the x tile per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -39,19 +41,21 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     // consecutive workgroups walk M for a fixed N panel: the packed W panel
     // (tiny) stays in L2 while x tiles stream
     const int bn = (int)blockIdx.x % ntn, bm = (int)blockIdx.x / ntn;
-    const int m0 = bm * BM, n0 = bn * GM_BN + wave * 32;
+    const int m0 = bm * BM, n0 = bn * GM_BN + wave * (16 * NSUB);
 
     const _Float16* x = (const _Float16*)a.x;
     const uint32_t* qw = (const uint32_t*)a.qweight;
     const h2* mt = (const h2*)a.meta;
 
-    f4 acc[MBLK][2];
+    f4 acc[MBLK][NSUB];
 #pragma unroll
-    for (int i = 0; i < MBLK; ++i) { acc[i][0] = (f4){0, 0, 0, 0}; acc[i][1] = (f4){0, 0, 0, 0}; }
+    for (int i = 0; i < MBLK; ++i)
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) acc[i][j] = (f4){0, 0, 0, 0};
 
     h8 areg[ACH];
-    LanePayload<BITS> pay[2];
-    h2 meta[2];
+    LanePayload<BITS> pay[NSUB];
+    h2 meta[NSUB];
     auto load_a = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     };
     auto load_b = [&](int kt) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NSUB; ++nb) {
             // clamp column blocks past N (ragged N % 128): computed, never stored
             const int nblk = min((n0 >> 4) + nb, (a.N >> 4) - 1);
             const size_t tile = (size_t)nblk * G + kt;
@@ -90,23 +94,23 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 
     for (int kt = 0; kt < G; ++kt) {
         const _Float16* ab = abuf(kt);
-        h2 wv[2][16];
-        dequant_lane_sd<BITS, MODE>(pay[0].w, meta[0], wv[0]);
-        dequant_lane_sd<BITS, MODE>(pay[1].w, meta[1], wv[1]);
+        h2 wv[NSUB][16];
+#pragma unroll
+        for (int nb = 0; nb < NSUB; ++nb) dequant_lane_sd<BITS, MODE>(pay[nb].w, meta[nb], wv[nb]);
         if (kt + 1 < G) { load_a(kt + 1); load_b(kt + 1); }      // issue early
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            h8 b0, b1;
+            h8 b[NSUB];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                b0[2 * p] = wv[0][4 * t + p].x; b0[2 * p + 1] = wv[0][4 * t + p].y;
-                b1[2 * p] = wv[1][4 * t + p].x; b1[2 * p + 1] = wv[1][4 * t + p].y;
-            }
+            for (int nb = 0; nb < NSUB; ++nb)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { b[nb][2 * p] = wv[nb][4 * t + p].x; b[nb][2 * p + 1] = wv[nb][4 * t + p].y; }
 #pragma unroll
             for (int mb = 0; mb < MBLK; ++mb) {
                 const h8 av = *(const h8*)(ab + (mb * 16 + r) * GM_LDA + 32 * t + 8 * o);
-                acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b0, acc[mb][0], 0, 0, 0);
-                acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b1, acc[mb][1], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NSUB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b[nb], acc[mb][nb], 0, 0, 0);
             }
         }
         if (kt + 1 < G) store_a(abuf(kt + 1));              // write late
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int mb = 0; mb < MBLK; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NSUB; ++nb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + mb * 16 + 4 * o + i;
@@ -132,22 +136,30 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
             }
 }
 
-template <int BITS, int MODE>
-static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
-    const int ntn = (a.N + GM_BN - 1) / GM_BN;
-    if (a.M > 64) {
-        const int ntm = (a.M + 127) / 128;
-        const size_t lds = 2 * 128 * GM_LDA * 2;
-        auto k = gemm_kernel<BITS, MODE, 128>;
+int g_gemm_nsub = 0;     // A/B knob: 0 = auto, 2 or 4
+
+template <int BITS, int MODE, int BM, int NSUB>
+static hipError_t gemm_launch_cfg(const GemmArgs& a, hipStream_t st) {
+    constexpr int BN = 4 * 16 * NSUB;
+    const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
+    const size_t lds = 2 * BM * GM_LDA * 2;
+    auto k = gemm_kernel<BITS, MODE, BM, NSUB>;
+    if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(GM_THREADS), lds, st, a);
-    } else {
-        const int ntm = (a.M + 63) / 64;
-        const size_t lds = 2 * 64 * GM_LDA * 2;
-        hipLaunchKernelGGL((gemm_kernel<BITS, MODE, 64>), dim3(ntm * ntn), dim3(GM_THREADS), lds, st, a);
     }
+    hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(GM_THREADS), lds, st, a);
     return hipGetLastError();
+}
+
+template <int BITS, int MODE>
+static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
+    if (a.M <= 64) return gemm_launch_cfg<BITS, MODE, 64, 2>(a, st);
+    // measured (5120x5120, M = 4096 / 16384): NSUB = 2 -> 0.81 / 0.89-0.92 PFLOP/s; NSUB = 4 needs ~390 VGPRs
+    // (one wave per SIMD) and drops to 0.68 / 0.76 -- kept only as an A/B knob
+    const bool wide = (g_gemm_nsub == 4);
+    if (wide) return gemm_launch_cfg<BITS, MODE, 128, 4>(a, st);
+    return gemm_launch_cfg<BITS, MODE, 128, 2>(a, st);
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st) {

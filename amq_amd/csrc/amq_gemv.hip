@@ -401,11 +401,13 @@ size_t gemv_lds_bytes(int M, int K, int copies) {
 }
 
 int gemv_pick_waves(int total_rt, int K) {
-    // measured on MI355X (tools/microbench.py sweeps, profiles/): 8 waves x 2 tiles in flight is the
-    // best or within 3% of it for every Llama shape; tiny K falls back to 4 waves (>= 2 tiles per wave).
-    (void)total_rt;
+    // measured on MI355X (tools/microbench.py / tools/abl3.sh sweeps, profiles/): 8 waves x 2 tiles in flight is the
+    // best or within 3% of it for every Llama shape with > 1 workgroup per CU; with <= 256 row-tiles (o_proj, down_proj:
+    // one workgroup per CU) 16 waves are 2-8% faster; tiny K falls back to 4 waves (>= 2 tiles per wave).
     const int G = K >> 7;
-    return G >= 16 ? 8 : 4;
+    if (G < 16) return 4;
+    if (total_rt <= 256 && G >= 32) return 16;
+    return 8;
 }
 
 template <int PRO, int NW, int U, int MATH>

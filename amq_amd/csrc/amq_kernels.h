@@ -55,6 +55,7 @@ struct GemmArgs {
     int M, N, K, bits, mode, x_stride, y_stride;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st);
+extern int g_gemm_nsub;
 
 // decode-step surroundings (amq_decode.hip)
 struct AttnArgs {

@@ -63,6 +63,7 @@ const char* amq_last_error(void);
 #define AMQ_OPT_GEMV_DEPTH 3       /* tile loads in flight per wave: 0 = auto (default), 2 or 4 */
 #define AMQ_OPT_GEMV_RPT   4       /* row-tiles walked by one GEMV workgroup: 0 = auto (default), 1..64 */
 #define AMQ_OPT_GEMV_MATH  5       /* AMQ_MATH_EXACT (default) or AMQ_MATH_LINEAR */
+#define AMQ_OPT_GEMM_NSUB  6       /* 16-column sub-tiles per GEMM wave: 0 = auto (default), 2 or 4 */
 /* GEMV arithmetic.  EXACT reproduces the reference's dequantized fp16 weights (two fp16 roundings per
  * weight) and accumulates x*w in fp32.  LINEAR skips the per-weight roundings: y = sum_g s_g*(sum_k x_k q_k
  * - z_g sum_k x_k) in fp32 (scale / zero applied once per 128-group) -- the real-valued dequant; it is

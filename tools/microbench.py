@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--rpt", type=int, default=0)
     ap.add_argument("--math", type=int, default=0)
+    ap.add_argument("--nsub", type=int, default=0)
+    ap.add_argument("--gemv", type=int, default=1)
     ap.add_argument("--gemm", type=int, default=1)
     ap.add_argument("--zero", type=int, default=0, help="1: all-zero packed weights (data-dependent clock check)")
     ap.add_argument("--hot", type=int, default=0, help="1: a single weight buffer (stays in L2 / Infinity Cache)")
@@ -90,17 +92,19 @@ def main():
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DEPTH, args.depth))
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_RPT, args.rpt))
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_MATH, args.math))
+    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMM_NSUB, args.nsub))
     shapes = [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096)]
     if args.quick:
         shapes = shapes[:2]
-    for n, k in shapes:
-        for bits in (4, 3, 2):
-            print(json.dumps(bench_case(n, k, bits, 1, args.iters)), flush=True)
-    for m in (2, 4, 8):
-        print(json.dumps(bench_case(4096, 4096, 4, m, args.iters)), flush=True)
+    if args.gemv:
+        for n, k in shapes:
+            for bits in (4, 3, 2):
+                print(json.dumps(bench_case(n, k, bits, 1, args.iters)), flush=True)
+        for m in (2, 4, 8):
+            print(json.dumps(bench_case(4096, 4096, 4, m, args.iters)), flush=True)
     if not args.gemm:
         return
-    for m in (64, 512, 4096):
+    for m in (64, 512, 4096, 16384):
         for bits in (4, 3, 2):
             r = bench_case(5120, 5120, bits, m, max(20, args.iters // 10), "gemm")
             r["TFLOPs"] = round(2.0 * m * 5120 * 5120 / r["us"] / 1e6, 1)
