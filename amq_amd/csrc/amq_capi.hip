@@ -192,6 +192,68 @@ int amq_linear_f16(int bits, int mode, const void* x, const void* qn, const void
     return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
 }
 
+// ---- reference-FFI-shaped entry points ---------------------------------------------------------------
+namespace {
+struct CompatWs { void* qn; void* mn; void* ytmp; };
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+CompatWs carve(void* ws, int bits, int M, int N, int K) {
+    char* p = (char*)ws;
+    CompatWs c;
+    c.qn = p; p += align256(amq::native_qweight_bytes(bits, N, K));
+    c.mn = p; p += align256(amq::native_meta_bytes(N, K));
+    c.ytmp = p;
+    (void)M;
+    return c;
+}
+}  // namespace
+
+size_t amq_compat_workspace_bytes(int bits, int M, int N, int K) {
+    if (N <= 0 || K <= 0 || M <= 0) return 0;
+    return align256(amq::native_qweight_bytes(bits, N, K)) + align256(amq::native_meta_bytes(N, K)) + align256((size_t)M * N * 2);
+}
+
+int amq_vecquantmatmul_faster_old(int bits, const void* vec, const void* mat, void* mul, const void* scales,
+                                  const void* zeros, int groupsize, int vec_height, int batch, int height, int width,
+                                  void* workspace, size_t workspace_bytes, int workspace_valid, void* stream) {
+    if (bits != 2 && bits != 3 && bits != 4) return fail(AMQ_EINVAL, "bits must be 2, 3 or 4 (got %d)", bits);
+    if (height <= 0 || (height * 32) % bits) return fail(AMQ_ESHAPE, "mat height %d is not K/32*bits", height);
+    const int K = height * 32 / bits, N = width, M = batch;
+    if (int rc = check_shape(bits, N, K, groupsize)) return rc;
+    if (vec_height != K / 2) return fail(AMQ_ESHAPE, "vec_height must be K/2 = %d (got %d)", K / 2, vec_height);
+    if (!vec || !mat || !mul || !scales || !zeros || !workspace) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1) return fail(AMQ_ESHAPE, "batch must be >= 1");
+    if (workspace_bytes < amq_compat_workspace_bytes(bits, M, N, K)) return fail(AMQ_EINVAL, "workspace too small");
+    const CompatWs w = carve(workspace, bits, M, N, K);
+    if (!workspace_valid)
+        if (int rc = amq_repack_from_gptq(bits, mat, scales, zeros, N, K, groupsize, w.qn, w.mn, stream)) return rc;
+    if (int rc = amq_linear_f16(bits, AMQ_MODE_FMA, vec, w.qn, w.mn, nullptr, w.ytmp, M, N, K, groupsize, stream)) return rc;
+    return check_hip(amq::launch_accumulate_f32(mul, w.ytmp, (size_t)M * N, (hipStream_t)stream), "accumulate");
+}
+
+static int compat_awq(const void* x, const void* kernel, const void* scales, const void* scaled_zeros, void* y,
+                      int m, int n, int k, int group_size, void* workspace, size_t workspace_bytes, int workspace_valid,
+                      void* stream, bool gemm) {
+    if (int rc = check_shape(4, n, k, group_size)) return rc;
+    if (!x || !kernel || !scales || !scaled_zeros || !y || !workspace) return fail(AMQ_EINVAL, "null pointer");
+    if (m < 1) return fail(AMQ_ESHAPE, "m must be >= 1");
+    if (workspace_bytes < amq_compat_workspace_bytes(4, 1, n, k)) return fail(AMQ_EINVAL, "workspace too small");
+    const CompatWs w = carve(workspace, 4, 1, n, k);
+    if (!workspace_valid)
+        if (int rc = amq_repack_from_awq(kernel, scales, scaled_zeros, n, k, group_size, w.qn, w.mn, stream)) return rc;
+    if (gemm) return amq_gemm_f16(4, AMQ_MODE_FMA, x, w.qn, w.mn, nullptr, y, m, n, k, group_size, 0, 0, stream);
+    return amq_linear_f16(4, AMQ_MODE_FMA, x, w.qn, w.mn, nullptr, y, m, n, k, group_size, stream);
+}
+
+int amq_gemv_4bit(const void* x, const void* kernel, const void* scales, const void* scaled_zeros, void* y,
+                  int m, int n, int k, int group_size, void* workspace, size_t workspace_bytes, int workspace_valid, void* stream) {
+    return compat_awq(x, kernel, scales, scaled_zeros, y, m, n, k, group_size, workspace, workspace_bytes, workspace_valid, stream, false);
+}
+
+int amq_gemm_4bit(const void* x, const void* kernel, const void* scales, const void* scaled_zeros, void* y,
+                  int m, int n, int k, int group_size, void* workspace, size_t workspace_bytes, int workspace_valid, void* stream) {
+    return compat_awq(x, kernel, scales, scaled_zeros, y, m, n, k, group_size, workspace, workspace_bytes, workspace_valid, stream, true);
+}
+
 int amq_rmsnorm_f16(const void* x, const void* gamma, void* y, int M, int K, float eps, void* stream) {
     if (!x || !gamma || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1 || K < 8 || (K % 8) != 0) return fail(AMQ_ESHAPE, "need M >= 1 and K %% 8 == 0 (got M=%d K=%d)", M, K);

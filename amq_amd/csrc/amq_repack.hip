@@ -158,6 +158,17 @@ __global__ __launch_bounds__(256) void dequant_hqq_kernel(const void* wq, const 
     *(h8*)(out + e0) = v;
 }
 
+// mul[i] += (float)y[i]  -- the in-place fp32 accumulation of vecquant*matmul_faster_old (auto_gptq_kernel.cu:224)
+__global__ __launch_bounds__(256) void accumulate_f32_kernel(float* mul, const _Float16* y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) mul[i] += (float)y[i];
+}
+
+hipError_t launch_accumulate_f32(void* mul, const void* y, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(accumulate_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float*)mul, (const _Float16*)y, n);
+    return hipGetLastError();
+}
+
 template <int FMT>
 static hipError_t repack_bits(int bits, const void* q, const void* s, const void* z, int N, int K,
                               void* qn, void* mn, hipStream_t st) {

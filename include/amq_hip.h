@@ -135,6 +135,31 @@ int amq_gemv_grouped_f16(const amq_segment* segments /* host */, int nseg,
                          const void* x, const void* x2, const void* gamma, float eps, int prologue,
                          int M, int K, int group, int x_stride, void* stream);
 
+/* ---- entry points shaped like the reference's pybind functions ------------------------------------
+ * They take the reference's own buffers (Format B / Format C) unchanged.  The HIP kernels read the native layout,
+ * so each call needs a caller-owned `workspace` of at least amq_compat_workspace_bytes(bits, M, N, K) bytes; the
+ * native copy of the weights is (re)built into it unless `workspace_valid` != 0 (pass 0 on the first call for a given
+ * weight, 1 afterwards: the repack is then skipped and the call costs the same as amq_linear_f16).
+ *
+ * amq_vecquantmatmul_faster_old  <->  auto_gptq.vecquant{2,3,4}matmul_faster_old(vec, mat, mul, scales, zeros,
+ *     groupsize, vec_height)                (auto_gptq_kernel.cu:129-158, 227-256, 345-374, 443-467)
+ *     vec fp16 [batch, K], mat int32 [K/32*bits, N], mul fp32 [batch, N] ACCUMULATED IN PLACE (mul += vec . W),
+ *     scales / zeros fp32 [K/groupsize, N]; height = mat rows, width = N; vec_height (= K/2) is accepted and checked.
+ * amq_gemv_4bit  <->  faster_transformer.gemv_4bit(x, kernel, scales, scaled_zeros, m, n, k, group_size) -> y
+ *     (gemv_cuda.cu:358-437); the reference throws for m outside 1..7, here any m >= 1 works.
+ * amq_gemm_4bit  <->  faster_transformer.gemm_4bit(x, kernel, scales, scaled_zeros) -> y   (gemm_cuda.cu:929-1033)
+ *     x fp16 [m, k], kernel int16 [n/4, k], scales / scaled_zeros fp16 [k/group, n], y fp16 [m, n] (caller-allocated). */
+size_t amq_compat_workspace_bytes(int bits, int M, int N, int K);
+int amq_vecquantmatmul_faster_old(int bits, const void* vec, const void* mat, void* mul, const void* scales,
+                                  const void* zeros, int groupsize, int vec_height, int batch, int height, int width,
+                                  void* workspace, size_t workspace_bytes, int workspace_valid, void* stream);
+int amq_gemv_4bit(const void* x, const void* kernel, const void* scales, const void* scaled_zeros, void* y,
+                  int m, int n, int k, int group_size,
+                  void* workspace, size_t workspace_bytes, int workspace_valid, void* stream);
+int amq_gemm_4bit(const void* x, const void* kernel, const void* scales, const void* scaled_zeros, void* y,
+                  int m, int n, int k, int group_size,
+                  void* workspace, size_t workspace_bytes, int workspace_valid, void* stream);
+
 /* ---- decode-step surroundings (next tier: what sits between the linears in one token step) ---- */
 /* y = gamma * fp16(x * rsqrt(mean(x^2) + eps)), rows of K; replaces FT layernorm_forward_cuda (ft/layernorm/layernorm.cu:25-77) */
 int amq_rmsnorm_f16(const void* x, const void* gamma, void* y, int M, int K, float eps, void* stream);

@@ -113,3 +113,42 @@ def test_pack_and_reference_buffer_imports(path):
     if bits == 4:
         q = mods["model.layers.0.self_attn.q_proj"]
         assert torch.equal(q.qweight, up.qweight)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "hqq_b*_128x512.npz"))), ids=os.path.basename)
+def test_reference_ffi_shaped_entry_points(path):
+    """amq_vecquantmatmul_faster_old / amq_gemv_4bit / amq_gemm_4bit take the reference's own Format B / C buffers
+    (captured from GPTQLinear / FT_QuantLinear) and behave like the pybind functions they replace."""
+    import ctypes
+    from amq_amd import _lib
+    from oracle import gptq_ref, awq_ref
+    lib = _lib.load()
+    g = {k: v for k, v in np.load(path).items()}
+    bits, (n, k) = int(g["nbits"]), tuple(int(v) for v in g["shape"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+    vp = lambda x: ctypes.c_void_p(x.data_ptr())
+    st = _lib.current_stream()
+    for m in (1, 5, 128):
+        x = t(g["gptq_x"][:m])
+        ws = torch.empty(lib.amq_compat_workspace_bytes(bits, m, n, k), dtype=torch.uint8, device=_dev())
+        mul = torch.full((m, n), 0.5, dtype=torch.float32, device=_dev())          # accumulated in place
+        qw, sc, zr = t(g["gptq_qweight"]), t(g["gptq_scales"]), t(g["gptq_zeros"])
+        for valid in (0, 1):                                                         # second call reuses the native copy
+            _lib.check(lib.amq_vecquantmatmul_faster_old(bits, vp(x), vp(qw), vp(mul), vp(sc), vp(zr), 128, k // 2, m,
+                                                         qw.shape[0], n, vp(ws), ws.numel(), valid, st))
+        w = gptq_ref.dequant_kernel(g["gptq_qweight"], g["gptq_scales"], g["gptq_zeros"], bits)
+        ref = linear_ref.linear_f16(g["gptq_x"][:m], w).astype(np.float32)
+        got = mul.cpu().numpy()
+        assert np.all(np.abs(got - (0.5 + 2 * ref)) <= 2e-3 * np.abs(ref) + 2e-3 * np.sqrt(np.mean(ref ** 2)))
+    assert lib.amq_vecquantmatmul_faster_old(bits, vp(x), vp(qw), vp(mul), vp(sc), vp(zr), 128, k, 1, qw.shape[0], n,
+                                             vp(ws), ws.numel(), 0, st) == -2        # wrong vec_height
+    if bits == 4:
+        kq, sc, sz = t(g["awq_qweight"]), t(g["awq_scales"]), t(g["awq_scaled_zeros"])
+        w = awq_ref.dequant_kernel(g["awq_qweight"], g["awq_scales"], g["awq_scaled_zeros"])
+        ws = torch.empty(lib.amq_compat_workspace_bytes(4, 1, n, k), dtype=torch.uint8, device=_dev())
+        for fn, m in ((lib.amq_gemv_4bit, 3), (lib.amq_gemv_4bit, 9), (lib.amq_gemm_4bit, 64)):
+            x = t(g["gptq_x"][:m])
+            y = torch.empty(m, n, dtype=torch.float16, device=_dev())
+            _lib.check(fn(vp(x), vp(kq), vp(sc), vp(sz), vp(y), m, n, k, 128, vp(ws), ws.numel(), 0, st))
+            ref = linear_ref.linear_f16(g["gptq_x"][:m], w).astype(np.float32)
+            assert np.all(np.abs(y.float().cpu().numpy() - ref) <= 1e-3 * np.abs(ref) + 1e-3 * np.sqrt(np.mean(ref ** 2)))
