@@ -37,6 +37,42 @@
 namespace amq {
 
 constexpr int XPAD = 8;              // halves of padding per staged x row (16 B)
+
+// Kernel argument block.  Everything a wave needs before its first weight load ("hot") sits at
+// static offsets in the first 168 bytes, structure-of-arrays over the segments, so the compiler
+// fetches it with ONE batch of scalar loads (one kernarg round trip, measured ~0.3 us each, instead of the
+// three dependent ones of an array-of-structs with a dynamic segment index); the epilogue-only fields follow.
+struct GemvKArgs {
+    const void* x; const void* x2; const void* gamma;
+    int M, K, x_stride, nseg;
+    float eps; int rpt, lin_mask, lin_copies;
+    int wg_begin[GEMV_MAX_SEG];
+    int n_rt[GEMV_MAX_SEG];
+    int key[GEMV_MAX_SEG];                 // bits * 2 + mode
+    const void* qweight[GEMV_MAX_SEG];
+    const void* meta[GEMV_MAX_SEG];
+    // ---- cold: epilogue only
+    const void* bias[GEMV_MAX_SEG];
+    const void* residual[GEMV_MAX_SEG];
+    void* y[GEMV_MAX_SEG];
+    int y_stride[GEMV_MAX_SEG];
+#ifdef AMQ_STAMP
+    unsigned long long* stamps;
+#endif
+};
+
+struct SegOut { const _Float16* bias; const _Float16* residual; _Float16* y; int y_stride; };
+
+#ifdef AMQ_STAMP
+// diagnostic build: slot i of this workgroup's 32-entry record <- 100 MHz realtime counter (comparable across CUs)
+#define AMQ_STAMP_AT(a_, slot_)                                                                  \
+    do {                                                                                         \
+        if ((a_).stamps && (threadIdx.x & 63) == 0)                                              \
+            (a_).stamps[(size_t)blockIdx.x * 128 + (slot_)] = __builtin_amdgcn_s_memrealtime();   \
+    } while (0)
+#else
+#define AMQ_STAMP_AT(a_, slot_) do { } while (0)
+#endif
 enum { MATH_EXACT = 0, MATH_DOT = 1, MATH_LINEAR = 2 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -63,7 +99,7 @@ __device__ __forceinline__ int lin_shift(int bits, int t, int p) {
 //   linear      : for every bit-width b in lin_mask a copy xl_b[m][xs] pre-scaled by 2^-shift, and
 //                 xg[G][16] = per-group sums of x per row (fp32; rows >= M are zero)
 template <int PRO, int NW, bool LIN>
-__device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* xg, float* red, int xs) {
+__device__ __forceinline__ void stage_x(const GemvKArgs& a, _Float16* xl, float* xg, float* red, int xs) {
     constexpr int THREADS = NW * 64;
     const int tid = threadIdx.x;
     const int K = a.K;
@@ -137,12 +173,78 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, _Float16* xl, float* 
     }
 }
 
+// Single-row (decode) staging, split in two so that the activation loads are the OLDEST entries of the wave's
+// vector-memory queue: x_issue() runs before the weight ring is primed, x_finish() after it.  vmcnt waits are
+// in issue order, so staging behind the primed weight tiles (the previous arrangement) made every workgroup wait
+// for its first tiles -- 2-4 us under load (profiles/r01b_gemv_stamps.txt) -- before x could be written to LDS.
+constexpr int XC_MAX = 2;            // 16-byte chunks of x per thread held in registers (K <= 16 * threads)
+struct XRegs { h8 v[XC_MAX]; h8 w[XC_MAX]; };   // w: up (SiLU*mul) or gamma (RMSNorm)
+
+// No branches around the loads (indices are clamped instead): the compiler can only emit a COUNTED vmcnt for the
+// later uses when every path between a load and its use issues the same vector-memory operations.
+template <int PRO, int NW>
+__device__ __forceinline__ void x_issue(const GemvKArgs& a, XRegs& xr) {
+    constexpr int THREADS = NW * 64;
+    const int last = (a.K >> 3) - 1;
+#pragma unroll
+    for (int i = 0; i < XC_MAX; ++i) {
+        int c = (int)threadIdx.x + i * THREADS;
+        c = c < last ? c : last;                                  // clamp: every lane loads, tail lanes discard
+        xr.v[i] = *(const h8*)((const _Float16*)a.x + 8 * c);
+        if (PRO == PRO_SILU_MUL) xr.w[i] = *(const h8*)((const _Float16*)a.x2 + 8 * c);
+        if (PRO == PRO_RMSNORM) xr.w[i] = *(const h8*)((const _Float16*)a.gamma + 8 * c);
+    }
+}
+
+template <int PRO, int NW>
+__device__ __forceinline__ void x_finish(const GemvKArgs& a, const XRegs& xr, _Float16* xl, float* red) {
+    constexpr int THREADS = NW * 64;
+    const int tid = threadIdx.x;
+    const int chunks = a.K >> 3;
+    float rstd = 1.0f;
+    if (PRO == PRO_RMSNORM) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < XC_MAX; ++i) {
+            if (tid + i * THREADS < chunks) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float f = (float)xr.v[i][e]; ss += f * f; }
+            }
+        }
+        ss = wave_sum(ss);
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[w];
+        rstd = rsqrtf(tot / (float)a.K + a.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < XC_MAX; ++i) {
+        const int c = tid + i * THREADS;
+        if (c < chunks) {
+            h8 r;
+            if (PRO == PRO_NONE) {
+                r = xr.v[i];
+            } else if (PRO == PRO_SILU_MUL) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { _Float16 sg = (_Float16)silu_f((float)xr.v[i][e]); r[e] = sg * xr.w[i][e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { _Float16 nrm = (_Float16)((float)xr.v[i][e] * rstd); r[e] = xr.w[i][e] * nrm; }
+            }
+            *(h8*)(xl + 8 * c) = r;
+        }
+    }
+    // (the caller's barrier publishes xl; red[] is next written only after that barrier)
+}
+
 // ---------------------------------------------------------------- epilogue
-__device__ __forceinline__ void store_out(const GemvSeg& s, int m, int n, float acc) {
+__device__ __forceinline__ void store_out(const SegOut& s, int m, int n, float acc) {
     _Float16 y = (_Float16)acc;                                   // fp16(matmul)
-    if (s.bias) y = y + ((const _Float16*)s.bias)[n];             // out + bias      (fp16 add)
-    if (s.residual) y = ((const _Float16*)s.residual)[(size_t)m * s.y_stride + n] + y;  // residual + out
-    ((_Float16*)s.y)[(size_t)m * s.y_stride + n] = y;
+    if (s.bias) y = y + s.bias[n];                                // out + bias      (fp16 add)
+    if (s.residual) y = s.residual[(size_t)m * s.y_stride + n] + y;  // residual + out
+    s.y[(size_t)m * s.y_stride + n] = y;
 }
 
 // and-only unpack for MATH_LINEAR: out[4t+p] = packed fp16 subnormals q * 2^(shift-24)
@@ -186,18 +288,19 @@ __device__ __forceinline__ void unpack_lane_sub(const uint32_t* w, h2* out) {
 
 // ---------------------------------------------------------------- body
 template <int BITS, int MODE, int PRO, int NW, int U, int MATH>
-__device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, int local, _Float16* lds_x,
-                                          const _Float16* xl, float* xg, float* red, int xs) {
+__device__ __forceinline__ void gemv_body(const GemvKArgs& a, int sidx, const void* qweight, const void* meta_base,
+                                          int seg_n_rt, int local, _Float16* lds_x, const _Float16* xl, float* xg,
+                                          float* red, int xs, bool fastx, const XRegs& xr) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = a.K >> 7;
     const int r = lane & 15, o = lane >> 4;
-    const int wgc = s.wg_count;
     const int nt = (G - wave + NW - 1) / NW;                      // tiles of one row-tile owned by this wave: g = wave + i*NW
-    const int n_my = (s.n_rt - local + wgc - 1) / wgc;            // row-tiles of this workgroup: rt = local + j*wgc
+    const int rt0 = local * a.rpt;                                // this workgroup's row-tiles: rt0 .. rt0 + n_my - 1 (contiguous bytes)
+    const int n_my = (seg_n_rt - rt0) < a.rpt ? (seg_n_rt - rt0) : a.rpt;
     const int total = n_my * nt;
-    const uint32_t* qw = (const uint32_t*)s.qweight;
-    const h2* mt = (const h2*)s.meta + r;
+    const uint32_t* qw = (const uint32_t*)qweight;
+    const h2* mt = (const h2*)meta_base + r;
 
 #ifdef AMQ_ABL_NOMETA      /* ablation: no scale/zero traffic */
 #define AMQ_META_LOAD(slot, tile_) meta[slot] = as_h2(0x40003c00u + (uint32_t)(tile_ & 1))
@@ -219,23 +322,55 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
         if (++ii == nt) { ii = 0; ++ij; }                                                        \
     } while (0)
 #else
-#define AMQ_ISSUE(slot)                                                                          \
+#define AMQ_ISSUE_AT(slot, clamp_)                                                               \
     do {                                                                                         \
-        const size_t tile_ = (size_t)(local + ij * wgc) * G + (wave + ii * NW);                  \
+        size_t tile_ = (size_t)(rt0 + ij) * G + (wave + ii * NW);                                \
+        if (clamp_) tile_ = tile_ < last_tile ? tile_ : last_tile;                               \
         pay[slot] = load_payload<BITS>(qw + tile_ * (64 * BITS), lane);                           \
         AMQ_META_LOAD(slot, tile_);                                                              \
         if (++ii == nt) { ii = 0; ++ij; }                                                        \
     } while (0)
+#define AMQ_ISSUE(slot) AMQ_ISSUE_AT(slot, false)
 #endif
 
+    // prime the ring: unconditional (a wave with fewer than U tiles re-reads the workgroup's last tile and never
+    // consumes it) so that the staging code below sees a fixed number of younger loads -> counted vmcnt for x
+    const size_t last_tile = (size_t)(rt0 + n_my) * G - 1;
+#ifdef AMQ_ABL_NOLOAD
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (u < total) AMQ_ISSUE(u);                               // HBM requests leave before x is staged
+    for (int u = 0; u < U; ++u) AMQ_ISSUE(u);
+#else
+#pragma unroll
+    for (int u = 0; u < U; ++u) AMQ_ISSUE_AT(u, true);
+#endif
+    if (wave == 0) AMQ_STAMP_AT(a, 1);
 
+    // epilogue-only fields: fetched behind the primed ring (their latency hides under the first tiles)
+    SegOut so;
+    so.bias = (const _Float16*)a.bias[sidx];
+    so.residual = (const _Float16*)a.residual[sidx];
+    so.y = (_Float16*)a.y[sidx];
+    so.y_stride = a.y_stride[sidx];
 #ifndef AMQ_ABL_NOSTAGE
-    stage_x<PRO, NW, MATH == MATH_LINEAR>(a, lds_x, xg, red, xs);
+    if (fastx) x_finish<PRO, NW>(a, xr, lds_x, red);
+    else stage_x<PRO, NW, MATH == MATH_LINEAR>(a, lds_x, xg, red, xs);
 #endif
     __syncthreads();
+    if (wave == 0) AMQ_STAMP_AT(a, 2);
+
+    // bias / residual of the row-tile being accumulated, fetched a whole row-tile ahead: loaded inside the epilogue
+    // they are the youngest entries of the vector-memory queue and the wait for them drains the weight ring
+    _Float16 pf_bias = (_Float16)0.f, pf_res = (_Float16)0.f;
+    const int e_m = (int)threadIdx.x >> 4, e_c = (int)threadIdx.x & 15;
+    const bool e_on = (int)threadIdx.x < a.M * 16;
+#define AMQ_EPI_PREFETCH(rt_)                                                                    \
+    do {                                                                                         \
+        if (e_on) {                                                                              \
+            if (so.bias) pf_bias = so.bias[(rt_) * 16 + e_c];                                    \
+            if (so.residual) pf_res = so.residual[(size_t)e_m * so.y_stride + (rt_) * 16 + e_c]; \
+        }                                                                                        \
+    } while (0)
+    AMQ_EPI_PREFETCH(rt0);
 
     float acc1[4] = {0.f, 0.f, 0.f, 0.f};
     f4 accm = (f4){0.f, 0.f, 0.f, 0.f};
@@ -259,12 +394,16 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
             accm = (f4){0.f, 0.f, 0.f, 0.f};                                                     \
         }                                                                                        \
         __syncthreads();                                                                         \
-        const int rt_ = local + cj * wgc;                                                        \
-        for (int e_ = threadIdx.x; e_ < a.M * 16; e_ += NW * 64) {                               \
+        const int rt_ = rt0 + cj;                                                                \
+        if (e_on) {                                           /* M * 16 <= 256 <= threads */     \
             float tot_ = 0.f;                                                                    \
-            _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) tot_ += rp_[w_ * 256 + e_];        \
-            store_out(s, e_ >> 4, rt_ * 16 + (e_ & 15), tot_);                                   \
+            _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) tot_ += rp_[w_ * 256 + threadIdx.x]; \
+            _Float16 y_ = (_Float16)tot_;                     /* fp16(matmul) */                 \
+            if (so.bias) y_ = y_ + pf_bias;                   /* out + bias      (fp16 add) */   \
+            if (so.residual) y_ = pf_res + y_;                /* residual + out */               \
+            so.y[(size_t)e_m * so.y_stride + rt_ * 16 + e_c] = y_;                               \
         }                                                                                        \
+        if (cj + 1 < n_my) AMQ_EPI_PREFETCH(rt_ + 1);                                            \
         par ^= 1;                                                                                \
     } while (0)
 
@@ -275,7 +414,6 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
         uint32_t x_ = 0;                                                                         \
         _Pragma("unroll") for (int d_ = 0; d_ < BITS; ++d_) x_ ^= pay[slot].w[d_];               \
         accm[0] += (float)(x_ & 1u) + (float)meta[slot].x;                                       \
-        if (++ci == nt) { AMQ_FINISH(); ci = 0; ++cj; }                                          \
     } while (0)
 #else
 #define AMQ_COMPUTE(slot)                                                                        \
@@ -316,9 +454,14 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
                 accm = c_;                                                                       \
             }                                                                                    \
         }                                                                                        \
-        if (++ci == nt) { AMQ_FINISH(); ci = 0; ++cj; }                                          \
     } while (0)
 #endif
+    // end of this wave's share of a row-tile?  (runs AFTER the slot has been re-issued: the ring stays full
+    // while the wave sits in the row-tile barrier)
+#define AMQ_ROWEND()                                                                             \
+    do {                                                                                         \
+        if (++ci == nt) { AMQ_FINISH(); ci = 0; ++cj; }                                          \
+    } while (0)
 
     if (nt == 0) {                                                // K < 128 * NW: this wave owns no tile
         for (int j = 0; j < n_my; ++j) { AMQ_FINISH(); ++cj; }
@@ -330,6 +473,35 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
     // into temporaries + a vmcnt(0)/v_mov rotation -- what a naive ring compiles to); the
     // main loop refills unconditionally so its waits stay counted, the tail drains.
     int idx = 0;
+#ifdef AMQ_STAMP
+    // diagnostic build: shader-clock cycles this wave spends (a) waiting for its next tile, (b) in unpack + MFMA,
+    // (c) in the row-tile epilogue incl. its barrier.  The explicit wait is the one the compiler would insert itself.
+    unsigned long long c_wait = 0, c_math = 0, c_row = 0;
+    constexpr int OPS_PER_TILE = (BITS == 3) ? 4 : 2;
+#define AMQ_T() __builtin_amdgcn_s_memtime()
+    for (; idx + 2 * U <= total; idx += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long t0 = AMQ_T();
+            __builtin_amdgcn_s_waitcnt(0x0F70 | ((U - 1) * OPS_PER_TILE));      /* vmcnt((U-1)*ops) [hi bits 0], lgkm/exp untouched */
+            const unsigned long long t1 = AMQ_T();
+            AMQ_COMPUTE(u);
+            __builtin_amdgcn_sched_barrier(0);
+            AMQ_ISSUE(u);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t2 = AMQ_T();
+            AMQ_ROWEND();
+            const unsigned long long t3 = AMQ_T();
+            c_wait += t1 - t0; c_math += t2 - t1; c_row += t3 - t2;
+        }
+    }
+    if (a.stamps && lane == 0) {
+        a.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 0] = c_wait;
+        a.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 1] = c_math;
+        a.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 2] = c_row;
+        a.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 3] = (unsigned long long)idx;
+    }
+#else
     for (; idx + 2 * U <= total; idx += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -337,22 +509,29 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
             __builtin_amdgcn_sched_barrier(0);
             AMQ_ISSUE(u);
             __builtin_amdgcn_sched_barrier(0);
+            AMQ_ROWEND();
         }
     }
+#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (idx + u < total) {
             AMQ_COMPUTE(u);
             __builtin_amdgcn_sched_barrier(0);
             if (idx + u + U < total) AMQ_ISSUE(u);
+            AMQ_ROWEND();
         }
     }
     idx += U;
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        if (idx + u < total) AMQ_COMPUTE(u);
+        if (idx + u < total) { AMQ_COMPUTE(u); AMQ_ROWEND(); }
+    AMQ_STAMP_AT(a, 8 + wave);                                    // per-wave end of stream
 #undef AMQ_ISSUE
+#undef AMQ_ISSUE_AT
 #undef AMQ_COMPUTE
+#undef AMQ_ROWEND
+#undef AMQ_EPI_PREFETCH
 #undef AMQ_FINISH
 }
 
@@ -360,7 +539,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const GemvSeg& s, i
 #define AMQ_LB_WAVES 1
 #endif
 template <int PRO, int NW, int U, int MATH>
-__global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES) void gemv_kernel(GemvArgs a) {
+__global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES) void gemv_kernel(GemvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xs = a.K + XPAD;
     _Float16* xl = (_Float16*)smem;
@@ -369,29 +548,66 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES) void gemv_kernel(GemvArgs a)
     const size_t xgbytes = (MATH == MATH_LINEAR) ? (size_t)(a.K >> 7) * 64 : 0;
     float* red = (float*)(smem + xbytes + xgbytes);                             // [2][NW][16][16]
 
+    // All hot kernel arguments are forced into SGPRs here, by one clause of scalar loads and a single wait: left to
+    // itself the compiler sinks each s_load next to its first use, which makes 3-4 DEPENDENT kernarg round trips
+    // (cold at every launch) before the first weight load can be issued.
+    asm volatile("" ::"s"(a.x), "s"(a.x2), "s"(a.gamma), "s"(a.M), "s"(a.K), "s"(a.x_stride), "s"(a.nseg), "s"(a.eps),
+                 "s"(a.rpt), "s"(a.wg_begin[1]), "s"(a.wg_begin[2]), "s"(a.wg_begin[3]), "s"(a.n_rt[0]), "s"(a.n_rt[1]),
+                 "s"(a.n_rt[2]), "s"(a.n_rt[3]), "s"(a.key[0]), "s"(a.key[1]), "s"(a.key[2]), "s"(a.key[3]),
+                 "s"(a.qweight[0]), "s"(a.qweight[1]), "s"(a.qweight[2]), "s"(a.qweight[3]), "s"(a.meta[0]),
+                 "s"(a.meta[1]), "s"(a.meta[2]), "s"(a.meta[3]));
+    // segment of this workgroup: static-offset loads + selects (no dependent kernarg round trip)
+    const int bid = (int)blockIdx.x;
     int sidx = 0;
+    int wgb = 0, nrt = a.n_rt[0], key = a.key[0];
+    const void* qwp = a.qweight[0];
+    const void* mtp = a.meta[0];
 #pragma unroll
-    for (int i = 1; i < GEMV_MAX_SEG; ++i)
-        if (i < a.nseg && (int)blockIdx.x >= a.seg[i].wg_begin) sidx = i;
-    const GemvSeg& s = a.seg[sidx];
-    const int local = (int)blockIdx.x - s.wg_begin;
+    for (int i = 1; i < GEMV_MAX_SEG; ++i) {
+        const bool take = i < a.nseg && bid >= a.wg_begin[i];
+        sidx = take ? i : sidx;
+        wgb = take ? a.wg_begin[i] : wgb;
+        nrt = take ? a.n_rt[i] : nrt;
+        key = take ? a.key[i] : key;
+        qwp = take ? a.qweight[i] : qwp;
+        mtp = take ? a.meta[i] : mtp;
+    }
+    const int local = bid - wgb;
+#ifdef AMQ_STAMP
+    if (threadIdx.x == 0 && a.stamps) {
+        a.stamps[(size_t)blockIdx.x * 128 + 0] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[(size_t)blockIdx.x * 128 + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
+    }
+#endif
+
+    // decode fast path: one activation row whose chunks fit the per-thread registers -> loads leave first
+    XRegs xr;
+    const bool fastx = MATH != MATH_LINEAR && a.M == 1 && (a.K >> 3) <= XC_MAX * NW * 64;
+    if (fastx) x_issue<PRO, NW>(a, xr);
 
     const _Float16* xuse = xl;
     if (MATH == MATH_LINEAR) {
+        const int bits = key >> 1;
         int slot = 0;
-        for (int b = 2; b < s.bits; ++b) slot += (a.lin_mask >> b) & 1;
+        for (int b = 2; b < bits; ++b) slot += (a.lin_mask >> b) & 1;
         xuse = xl + (size_t)slot * a.M * xs;
     }
-    const int key = s.bits * 2 + s.mode;
     switch (key) {
-        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
-        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
-        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
-        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
-        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
-        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH>(a, s, local, xl, xuse, xg, red, xs); break;
+        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
     }
+    if (threadIdx.x < 64) AMQ_STAMP_AT(a, 4);
 }
+
+#ifdef AMQ_STAMP
+unsigned long long* g_stamp_ptr = nullptr;
+extern "C" int amq_debug_set_stamps(void* p) { g_stamp_ptr = (unsigned long long*)p; return 0; }
+#endif
 
 size_t gemv_lds_bytes(int M, int K, int copies) {
     const size_t xbytes = (((size_t)M * (K + XPAD) * 2 * copies) + 15) & ~(size_t)15;
@@ -411,7 +627,7 @@ int gemv_pick_waves(int total_rt, int K) {
 }
 
 template <int PRO, int NW, int U, int MATH>
-static hipError_t launch_one(const GemvArgs& a, int total_wg, size_t lds, hipStream_t st) {
+static hipError_t launch_one(const GemvKArgs& a, int total_wg, size_t lds, hipStream_t st) {
     auto kern = gemv_kernel<PRO, NW, U, MATH>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -422,10 +638,10 @@ static hipError_t launch_one(const GemvArgs& a, int total_wg, size_t lds, hipStr
 }
 
 template <int PRO, int NW>
-static hipError_t launch_nw(const GemvArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    const int u = a.force_depth ? a.force_depth : 2;
-    if ((a.flags & GEMV_FLAG_DOT) && a.M == 1) return launch_one<PRO, NW, 2, MATH_DOT>(a, total_wg, lds, st);
-    if (a.flags & GEMV_FLAG_LINEAR) {
+static hipError_t launch_nw(const GemvKArgs& a, int flags, int depth, int total_wg, size_t lds, hipStream_t st) {
+    const int u = depth ? depth : 2;
+    if ((flags & GEMV_FLAG_DOT) && a.M == 1) return launch_one<PRO, NW, 2, MATH_DOT>(a, total_wg, lds, st);
+    if (flags & GEMV_FLAG_LINEAR) {
         if (u == 4) return launch_one<PRO, NW, 4, MATH_LINEAR>(a, total_wg, lds, st);
         return launch_one<PRO, NW, 2, MATH_LINEAR>(a, total_wg, lds, st);
     }
@@ -434,10 +650,10 @@ static hipError_t launch_nw(const GemvArgs& a, int total_wg, size_t lds, hipStre
 }
 
 template <int PRO>
-static hipError_t launch_pro(const GemvArgs& a, int nw, int total_wg, size_t lds, hipStream_t st) {
-    if (nw == 4) return launch_nw<PRO, 4>(a, total_wg, lds, st);
-    if (nw == 16) return launch_nw<PRO, 16>(a, total_wg, lds, st);
-    return launch_nw<PRO, 8>(a, total_wg, lds, st);
+static hipError_t launch_pro(const GemvKArgs& a, int flags, int depth, int nw, int total_wg, size_t lds, hipStream_t st) {
+    if (nw == 4) return launch_nw<PRO, 4>(a, flags, depth, total_wg, lds, st);
+    if (nw == 16) return launch_nw<PRO, 16>(a, flags, depth, total_wg, lds, st);
+    return launch_nw<PRO, 8>(a, flags, depth, total_wg, lds, st);
 }
 
 // Fills the per-segment workgroup ranges and launches.  rpt = row-tiles per workgroup.
@@ -463,10 +679,23 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     a.lin_mask = lin ? mask : 0;
     a.lin_copies = lin ? __builtin_popcount(mask) : 1;
     const size_t lds = gemv_lds_bytes(a.M, a.K, a.lin_copies);
+    GemvKArgs k{};
+    k.x = a.x; k.x2 = a.x2; k.gamma = a.gamma;
+    k.M = a.M; k.K = a.K; k.x_stride = a.x_stride; k.nseg = a.nseg;
+    k.eps = a.eps; k.rpt = rpt; k.lin_mask = a.lin_mask; k.lin_copies = a.lin_copies;
+    for (int i = 0; i < a.nseg; ++i) {
+        const GemvSeg& s = a.seg[i];
+        k.wg_begin[i] = s.wg_begin; k.n_rt[i] = s.n_rt; k.key[i] = s.bits * 2 + s.mode;
+        k.qweight[i] = s.qweight; k.meta[i] = s.meta;
+        k.bias[i] = s.bias; k.residual[i] = s.residual; k.y[i] = s.y; k.y_stride[i] = s.y_stride;
+    }
+#ifdef AMQ_STAMP
+    k.stamps = g_stamp_ptr;
+#endif
     switch (a.prologue) {
-        case PRO_NONE: return launch_pro<PRO_NONE>(a, nw, wg, lds, st);
-        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(a, nw, wg, lds, st);
-        default: return launch_pro<PRO_SILU_MUL>(a, nw, wg, lds, st);
+        case PRO_NONE: return launch_pro<PRO_NONE>(k, a.flags, a.force_depth, nw, wg, lds, st);
+        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(k, a.flags, a.force_depth, nw, wg, lds, st);
+        default: return launch_pro<PRO_SILU_MUL>(k, a.flags, a.force_depth, nw, wg, lds, st);
     }
 }
 

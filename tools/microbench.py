@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--gemm", type=int, default=1)
     ap.add_argument("--zero", type=int, default=0, help="1: all-zero packed weights (data-dependent clock check)")
     ap.add_argument("--hot", type=int, default=0, help="1: a single weight buffer (stays in L2 / Infinity Cache)")
+    ap.add_argument("--only", default="", help="N,K: just this shape")
     args = ap.parse_args()
     global HOT, ZERO
     HOT = bool(args.hot)
@@ -96,11 +97,13 @@ def main():
     shapes = [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096)]
     if args.quick:
         shapes = shapes[:2]
+    if args.only:
+        shapes = [tuple(int(v) for v in args.only.split(","))]
     if args.gemv:
         for n, k in shapes:
             for bits in (4, 3, 2):
                 print(json.dumps(bench_case(n, k, bits, 1, args.iters)), flush=True)
-        for m in (2, 4, 8):
+        for m in (() if args.only else (2, 4, 8)):
             print(json.dumps(bench_case(4096, 4096, 4, m, args.iters)), flush=True)
     if not args.gemm:
         return
