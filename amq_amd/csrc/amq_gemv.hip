@@ -63,6 +63,14 @@ struct GemvKArgs {
 
 struct SegOut { const _Float16* bias; const _Float16* residual; _Float16* y; int y_stride; };
 
+// register-resident view of the launch-wide arguments (built from the preloaded kernel arguments)
+struct GemvHot {
+    const void* x; const void* x2; const void* gamma;
+    int M, K, x_stride, rpt;
+    float eps;
+    int lin_mask, lin_copies;
+};
+
 #ifdef AMQ_STAMP
 // diagnostic build: slot i of this workgroup's 32-entry record <- 100 MHz realtime counter (comparable across CUs)
 #define AMQ_STAMP_AT(a_, slot_)                                                                  \
@@ -99,7 +107,7 @@ __device__ __forceinline__ int lin_shift(int bits, int t, int p) {
 //   linear      : for every bit-width b in lin_mask a copy xl_b[m][xs] pre-scaled by 2^-shift, and
 //                 xg[G][16] = per-group sums of x per row (fp32; rows >= M are zero)
 template <int PRO, int NW, bool LIN>
-__device__ __forceinline__ void stage_x(const GemvKArgs& a, _Float16* xl, float* xg, float* red, int xs) {
+__device__ __forceinline__ void stage_x(const GemvHot& a, _Float16* xl, float* xg, float* red, int xs) {
     constexpr int THREADS = NW * 64;
     const int tid = threadIdx.x;
     const int K = a.K;
@@ -179,15 +187,18 @@ __device__ __forceinline__ void stage_x(const GemvKArgs& a, _Float16* xl, float*
 // for its first tiles -- 2-4 us under load (profiles/r01b_gemv_stamps.txt) -- before x could be written to LDS.
 constexpr int XC_MAX = 2;            // 16-byte chunks of x per thread held in registers (K <= 16 * threads)
 struct XRegs { h8 v[XC_MAX]; h8 w[XC_MAX]; };   // w: up (SiLU*mul) or gamma (RMSNorm)
+// chunks actually held: two only in the 16-wave workgroups (one per CU, 128 VGPRs available); the 8-wave ones must
+// stay under 80 VGPRs for three workgroups per CU, and K <= 4096 needs one chunk per thread there
+template <int NW> struct XCfg { static constexpr int XC = NW == 16 ? 2 : 1; };
 
 // No branches around the loads (indices are clamped instead): the compiler can only emit a COUNTED vmcnt for the
 // later uses when every path between a load and its use issues the same vector-memory operations.
 template <int PRO, int NW>
-__device__ __forceinline__ void x_issue(const GemvKArgs& a, XRegs& xr) {
+__device__ __forceinline__ void x_issue(const GemvHot& a, XRegs& xr) {
     constexpr int THREADS = NW * 64;
     const int last = (a.K >> 3) - 1;
 #pragma unroll
-    for (int i = 0; i < XC_MAX; ++i) {
+    for (int i = 0; i < XCfg<NW>::XC; ++i) {
         int c = (int)threadIdx.x + i * THREADS;
         c = c < last ? c : last;                                  // clamp: every lane loads, tail lanes discard
         xr.v[i] = *(const h8*)((const _Float16*)a.x + 8 * c);
@@ -197,7 +208,7 @@ __device__ __forceinline__ void x_issue(const GemvKArgs& a, XRegs& xr) {
 }
 
 template <int PRO, int NW>
-__device__ __forceinline__ void x_finish(const GemvKArgs& a, const XRegs& xr, _Float16* xl, float* red) {
+__device__ __forceinline__ void x_finish(const GemvHot& a, const XRegs& xr, _Float16* xl, float* red) {
     constexpr int THREADS = NW * 64;
     const int tid = threadIdx.x;
     const int chunks = a.K >> 3;
@@ -205,7 +216,7 @@ __device__ __forceinline__ void x_finish(const GemvKArgs& a, const XRegs& xr, _F
     if (PRO == PRO_RMSNORM) {
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < XC_MAX; ++i) {
+        for (int i = 0; i < XCfg<NW>::XC; ++i) {
             if (tid + i * THREADS < chunks) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { float f = (float)xr.v[i][e]; ss += f * f; }
@@ -220,7 +231,7 @@ __device__ __forceinline__ void x_finish(const GemvKArgs& a, const XRegs& xr, _F
         rstd = rsqrtf(tot / (float)a.K + a.eps);
     }
 #pragma unroll
-    for (int i = 0; i < XC_MAX; ++i) {
+    for (int i = 0; i < XCfg<NW>::XC; ++i) {
         const int c = tid + i * THREADS;
         if (c < chunks) {
             h8 r;
@@ -288,7 +299,7 @@ __device__ __forceinline__ void unpack_lane_sub(const uint32_t* w, h2* out) {
 
 // ---------------------------------------------------------------- body
 template <int BITS, int MODE, int PRO, int NW, int U, int MATH>
-__device__ __forceinline__ void gemv_body(const GemvKArgs& a, int sidx, const void* qweight, const void* meta_base,
+__device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk, int sidx, const void* qweight, const void* meta_base,
                                           int seg_n_rt, int local, _Float16* lds_x, const _Float16* xl, float* xg,
                                           float* red, int xs, bool fastx, const XRegs& xr) {
     const int lane = threadIdx.x & 63;
@@ -318,7 +329,8 @@ __device__ __forceinline__ void gemv_body(const GemvKArgs& a, int sidx, const vo
 #ifdef AMQ_ABL_NOLOAD      /* ablation build: no weight traffic, compute on whatever is in the registers */
 #define AMQ_ISSUE(slot)                                                                          \
     do {                                                                                         \
-        asm volatile("" : "+v"(pay[slot].w[0]), "+v"(meta[slot]));                               \
+        _Pragma("unroll") for (int d_ = 0; d_ < BITS; ++d_) asm volatile("" : "+v"(pay[slot].w[d_]));   \
+        asm volatile("" : "+v"(meta[slot]));                                                     \
         if (++ii == nt) { ii = 0; ++ij; }                                                        \
     } while (0)
 #else
@@ -343,20 +355,20 @@ __device__ __forceinline__ void gemv_body(const GemvKArgs& a, int sidx, const vo
 #pragma unroll
     for (int u = 0; u < U; ++u) AMQ_ISSUE_AT(u, true);
 #endif
-    if (wave == 0) AMQ_STAMP_AT(a, 1);
+    if (wave == 0) AMQ_STAMP_AT(blk, 1);
 
     // epilogue-only fields: fetched behind the primed ring (their latency hides under the first tiles)
     SegOut so;
-    so.bias = (const _Float16*)a.bias[sidx];
-    so.residual = (const _Float16*)a.residual[sidx];
-    so.y = (_Float16*)a.y[sidx];
-    so.y_stride = a.y_stride[sidx];
+    so.bias = (const _Float16*)blk.bias[sidx];
+    so.residual = (const _Float16*)blk.residual[sidx];
+    so.y = (_Float16*)blk.y[sidx];
+    so.y_stride = blk.y_stride[sidx];
 #ifndef AMQ_ABL_NOSTAGE
     if (fastx) x_finish<PRO, NW>(a, xr, lds_x, red);
     else stage_x<PRO, NW, MATH == MATH_LINEAR>(a, lds_x, xg, red, xs);
 #endif
     __syncthreads();
-    if (wave == 0) AMQ_STAMP_AT(a, 2);
+    if (wave == 0) AMQ_STAMP_AT(blk, 2);
 
     // bias / residual of the row-tile being accumulated, fetched a whole row-tile ahead: loaded inside the epilogue
     // they are the youngest entries of the vector-memory queue and the wait for them drains the weight ring
@@ -458,10 +470,14 @@ __device__ __forceinline__ void gemv_body(const GemvKArgs& a, int sidx, const vo
 #endif
     // end of this wave's share of a row-tile?  (runs AFTER the slot has been re-issued: the ring stays full
     // while the wave sits in the row-tile barrier)
+#ifdef AMQ_ABL_NOFINISH    /* ablation: no row-tile barrier / reduction / store (timing only, results wrong) */
+#define AMQ_ROWEND() do { if (++ci == nt) { ci = 0; ++cj; } } while (0)
+#else
 #define AMQ_ROWEND()                                                                             \
     do {                                                                                         \
         if (++ci == nt) { AMQ_FINISH(); ci = 0; ++cj; }                                          \
     } while (0)
+#endif
 
     if (nt == 0) {                                                // K < 128 * NW: this wave owns no tile
         for (int j = 0; j < n_my; ++j) { AMQ_FINISH(); ++cj; }
@@ -495,11 +511,11 @@ __device__ __forceinline__ void gemv_body(const GemvKArgs& a, int sidx, const vo
             c_wait += t1 - t0; c_math += t2 - t1; c_row += t3 - t2;
         }
     }
-    if (a.stamps && lane == 0) {
-        a.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 0] = c_wait;
-        a.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 1] = c_math;
-        a.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 2] = c_row;
-        a.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 3] = (unsigned long long)idx;
+    if (blk.stamps && lane == 0) {
+        blk.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 0] = c_wait;
+        blk.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 1] = c_math;
+        blk.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 2] = c_row;
+        blk.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 3] = (unsigned long long)idx;
     }
 #else
     for (; idx + 2 * U <= total; idx += U) {
@@ -526,7 +542,11 @@ __device__ __forceinline__ void gemv_body(const GemvKArgs& a, int sidx, const vo
 #pragma unroll
     for (int u = 0; u < U; ++u)
         if (idx + u < total) { AMQ_COMPUTE(u); AMQ_ROWEND(); }
-    AMQ_STAMP_AT(a, 8 + wave);                                    // per-wave end of stream
+#ifdef AMQ_ABL_NOFINISH
+    cj = 0;
+    AMQ_FINISH();                                                 // keep the accumulators alive: one epilogue at the end
+#endif
+    AMQ_STAMP_AT(blk, 8 + wave);                                    // per-wave end of stream
 #undef AMQ_ISSUE
 #undef AMQ_ISSUE_AT
 #undef AMQ_COMPUTE
@@ -535,12 +555,34 @@ __device__ __forceinline__ void gemv_body(const GemvKArgs& a, int sidx, const vo
 #undef AMQ_FINISH
 }
 
-#ifndef AMQ_LB_WAVES       /* A/B builds: minimum waves per SIMD the register allocator must leave room for */
-#define AMQ_LB_WAVES 1
+// minimum waves per SIMD the register allocator must leave room for: three 8-wave workgroups per CU (6 per SIMD,
+// <= 80 VGPRs), one or two 16-wave workgroups (4, <= 128), six 4-wave ones (6).  Without the bound the decode-prologue
+// variants allocate 90 VGPRs and only two workgroups fit a CU.
+#ifndef AMQ_LB_WAVES
+#define AMQ_LB_WAVES(NW_) 1
 #endif
+// Kernel-argument preload (gfx950): the first 14 dwords of explicit arguments are delivered in SGPRs by the command
+// processor at wave launch (`-mllvm -amdgpu-kernarg-preload-count=14`, csrc/Makefile), so they cost no memory round
+// trip.  They carry everything a single-segment launch -- and segment 0 of a grouped one -- needs to issue its
+// activation and weight loads; the other segments take ONE clause of static-offset scalar loads from the block.
+struct GemvPre {            // not a kernel parameter type: just names the 14 dwords
+    const void* x; const void* xw; const void* qw0; const void* mt0;
+    int K, m_nseg, rpt, n_rt0, key0; float eps;
+};
+
 template <int PRO, int NW, int U, int MATH>
-__global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES) void gemv_kernel(GemvKArgs a) {
+__global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const void* p_x, const void* p_xw, const void* p_qw0,
+                                                                     const void* p_mt0, int p_K, int p_m_nseg, int p_rpt,
+                                                                     int p_n_rt0, int p_key0, float p_eps, GemvKArgs blk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GemvHot a;
+    a.x = p_x; a.x2 = p_xw; a.gamma = p_xw;
+    a.K = p_K; a.M = p_m_nseg & 0xFFFF; a.rpt = p_rpt; a.eps = p_eps;
+    const int nseg = p_m_nseg >> 16;
+    const bool slow_x = MATH == MATH_LINEAR || a.M != 1 || (a.K >> 3) > XCfg<NW>::XC * NW * 64;   // generic staging path
+    a.x_stride = slow_x ? blk.x_stride : a.K;
+    a.lin_mask = MATH == MATH_LINEAR ? blk.lin_mask : 0;
+    a.lin_copies = MATH == MATH_LINEAR ? blk.lin_copies : 1;
     const int xs = a.K + XPAD;
     _Float16* xl = (_Float16*)smem;
     const size_t xbytes = ((size_t)a.M * xs * 2 * (MATH == MATH_LINEAR ? a.lin_copies : 1) + 15) & ~(size_t)15;
@@ -548,42 +590,43 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES) void gemv_kernel(GemvKArgs a
     const size_t xgbytes = (MATH == MATH_LINEAR) ? (size_t)(a.K >> 7) * 64 : 0;
     float* red = (float*)(smem + xbytes + xgbytes);                             // [2][NW][16][16]
 
-    // All hot kernel arguments are forced into SGPRs here, by one clause of scalar loads and a single wait: left to
-    // itself the compiler sinks each s_load next to its first use, which makes 3-4 DEPENDENT kernarg round trips
-    // (cold at every launch) before the first weight load can be issued.
-    asm volatile("" ::"s"(a.x), "s"(a.x2), "s"(a.gamma), "s"(a.M), "s"(a.K), "s"(a.x_stride), "s"(a.nseg), "s"(a.eps),
-                 "s"(a.rpt), "s"(a.wg_begin[1]), "s"(a.wg_begin[2]), "s"(a.wg_begin[3]), "s"(a.n_rt[0]), "s"(a.n_rt[1]),
-                 "s"(a.n_rt[2]), "s"(a.n_rt[3]), "s"(a.key[0]), "s"(a.key[1]), "s"(a.key[2]), "s"(a.key[3]),
-                 "s"(a.qweight[0]), "s"(a.qweight[1]), "s"(a.qweight[2]), "s"(a.qweight[3]), "s"(a.meta[0]),
-                 "s"(a.meta[1]), "s"(a.meta[2]), "s"(a.meta[3]));
-    // segment of this workgroup: static-offset loads + selects (no dependent kernarg round trip)
     const int bid = (int)blockIdx.x;
     int sidx = 0;
-    int wgb = 0, nrt = a.n_rt[0], key = a.key[0];
-    const void* qwp = a.qweight[0];
-    const void* mtp = a.meta[0];
+    int wgb = 0, nrt = p_n_rt0, key = p_key0;
+    const void* qwp = p_qw0;
+    const void* mtp = p_mt0;
+    if (nseg > 1) {
+        // All hot per-segment arguments are forced into SGPRs here, by one clause of scalar loads and a single wait: left
+        // to itself the compiler sinks each s_load next to its first use, which makes 3-4 DEPENDENT kernarg round trips
+        // (cold at every launch, ~0.3 us each) before the first weight load can be issued.
+        asm volatile("" ::"s"(blk.wg_begin[1]), "s"(blk.wg_begin[2]), "s"(blk.wg_begin[3]), "s"(blk.n_rt[1]),
+                     "s"(blk.n_rt[2]), "s"(blk.n_rt[3]), "s"(blk.key[1]), "s"(blk.key[2]), "s"(blk.key[3]),
+                     "s"(blk.qweight[1]), "s"(blk.qweight[2]), "s"(blk.qweight[3]), "s"(blk.meta[1]), "s"(blk.meta[2]),
+                     "s"(blk.meta[3]));
 #pragma unroll
-    for (int i = 1; i < GEMV_MAX_SEG; ++i) {
-        const bool take = i < a.nseg && bid >= a.wg_begin[i];
-        sidx = take ? i : sidx;
-        wgb = take ? a.wg_begin[i] : wgb;
-        nrt = take ? a.n_rt[i] : nrt;
-        key = take ? a.key[i] : key;
-        qwp = take ? a.qweight[i] : qwp;
-        mtp = take ? a.meta[i] : mtp;
+        for (int i = 1; i < GEMV_MAX_SEG; ++i) {
+            const bool take = i < nseg && bid >= blk.wg_begin[i];
+            sidx = take ? i : sidx;
+            wgb = take ? blk.wg_begin[i] : wgb;
+            nrt = take ? blk.n_rt[i] : nrt;
+            key = take ? blk.key[i] : key;
+            qwp = take ? blk.qweight[i] : qwp;
+            mtp = take ? blk.meta[i] : mtp;
+        }
     }
     const int local = bid - wgb;
 #ifdef AMQ_STAMP
-    if (threadIdx.x == 0 && a.stamps) {
-        a.stamps[(size_t)blockIdx.x * 128 + 0] = __builtin_amdgcn_s_memrealtime();
-        a.stamps[(size_t)blockIdx.x * 128 + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+    if (threadIdx.x == 0 && blk.stamps) {
+        blk.stamps[(size_t)blockIdx.x * 128 + 0] = __builtin_amdgcn_s_memrealtime();
+        blk.stamps[(size_t)blockIdx.x * 128 + 5] = __builtin_amdgcn_s_memtime();
+        blk.stamps[(size_t)blockIdx.x * 128 + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                                 (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID, HW_ID
     }
 #endif
 
     // decode fast path: one activation row whose chunks fit the per-thread registers -> loads leave first
     XRegs xr;
-    const bool fastx = MATH != MATH_LINEAR && a.M == 1 && (a.K >> 3) <= XC_MAX * NW * 64;
+    const bool fastx = !slow_x;
     if (fastx) x_issue<PRO, NW>(a, xr);
 
     const _Float16* xuse = xl;
@@ -594,14 +637,17 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES) void gemv_kernel(GemvKArgs a
         xuse = xl + (size_t)slot * a.M * xs;
     }
     switch (key) {
-        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH>(a, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
     }
-    if (threadIdx.x < 64) AMQ_STAMP_AT(a, 4);
+    if (threadIdx.x < 64) AMQ_STAMP_AT(blk, 4);
+#ifdef AMQ_STAMP
+    if (threadIdx.x == 0 && blk.stamps) blk.stamps[(size_t)blockIdx.x * 128 + 6] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 #ifdef AMQ_STAMP
@@ -633,7 +679,9 @@ static hipError_t launch_one(const GemvKArgs& a, int total_wg, size_t lds, hipSt
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(total_wg), dim3(NW * 64), lds, st, a);
+    const void* xw = PRO == PRO_SILU_MUL ? a.x2 : a.gamma;
+    hipLaunchKernelGGL(kern, dim3(total_wg), dim3(NW * 64), lds, st, a.x, xw, a.qweight[0], a.meta[0], a.K,
+                       a.M | (a.nseg << 16), a.rpt, a.n_rt[0], a.key[0], a.eps, a);
     return hipGetLastError();
 }
 

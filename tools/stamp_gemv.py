@@ -90,6 +90,9 @@ def main():
         last = np.zeros(ncu)
         np.maximum.at(last, order, ex)
         print("  per-CU last exit", q(last))
+        if (s[:, 6] != 0).all():
+            clk = (s[:, 6] - s[:, 5]) / np.maximum(s[:, 4] - s[:, 0], 1) * 100.0   # shader ticks per 10 ns -> MHz
+            print("  shader clock MHz (memtime / memrealtime per WG)", q(clk))
         ph = s[:, 32:96].reshape(len(s), 16, 4).astype(np.float64)
         act = ph[:, :, 3] > 0
         if act.any():

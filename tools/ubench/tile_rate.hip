@@ -1,0 +1,113 @@
+// Compute-only cost of one AMQ-T16 tile (16 rows x 128 k): the unpack/dequant arithmetic of amq_common.cuh plus the four
+// v_mfma_f32_16x16x32_f16, on register-resident payloads (no HBM traffic), at 1..8 waves per SIMD.
+// Prints shader cycles per tile per SIMD.   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tile_rate tile_rate.hip
+#include "../../amq_amd/csrc/amq_common.cuh"
+#include <stdio.h>
+#include <vector>
+using namespace amq;
+
+enum { V_FULL = 0, V_FULL_LDS = 1, V_DEQ = 2, V_MFMA = 3, V_LIN = 4 };
+
+template <int BITS>
+__device__ __forceinline__ void unpack_sub(const uint32_t* w, h2* out) {   // and-only (linear math)
+    if (BITS == 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const uint32_t u = w[t], v = u >> 8;
+            out[4*t+0] = as_h2(u & 0x000F000Fu); out[4*t+1] = as_h2(u & 0x00F000F0u); out[4*t+2] = as_h2(v & 0x000F000Fu); out[4*t+3] = as_h2(v & 0x00F000F0u); }
+    } else if (BITS == 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) { const uint32_t u = w[d], v = u >> 10;
+            out[8*d+0] = as_h2(u & 0x00030003u); out[8*d+1] = as_h2(u & 0x000C000Cu); out[8*d+2] = as_h2(u & 0x00300030u); out[8*d+3] = as_h2(u & 0x00C000C0u);
+            out[8*d+4] = as_h2(u & 0x03000300u); out[8*d+5] = as_h2(v & 0x00030003u); out[8*d+6] = as_h2(v & 0x000C000Cu); out[8*d+7] = as_h2(v & 0x00300030u); }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { const uint32_t u = w[d], v = u >> 9;
+            out[5*d+0] = as_h2(u & 0x00070007u); out[5*d+1] = as_h2(u & 0x00380038u); out[5*d+2] = as_h2(u & 0x01C001C0u); out[5*d+3] = as_h2(v & 0x00070007u); out[5*d+4] = as_h2(v & 0x00380038u); }
+        out[15] = as_h2(((w[0] >> 15) & 0x00010001u) | ((w[1] >> 14) & 0x00020002u) | ((w[2] >> 13) & 0x00040004u));
+    }
+}
+
+template <int BITS, int VAR>
+__global__ void tile_kernel(uint64_t* out, uint32_t seed, int iters) {
+    __shared__ __attribute__((aligned(16))) _Float16 xl[4096 + 8];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) xl[i] = (_Float16)(float)((i * 7 + seed) & 3);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, o = lane >> 4;
+    uint32_t w[4];
+    for (int j = 0; j < 4; ++j) w[j] = seed * 2654435761u + threadIdx.x * 97 + j * 1234567u;
+    h2 meta = as_h2(0x40003c00u + (seed & 1));
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    h8 areg;
+    for (int i = 0; i < 8; ++i) areg[i] = (_Float16)(float)((lane + i) & 3);
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(meta));   // payload "arrives": nothing hoistable
+        h2 wv[16];
+        if (VAR == V_LIN) unpack_sub<BITS>(w, wv);
+        else if (VAR != V_MFMA) dequant_lane_sd<BITS, MODE_HQQ>(w, meta, wv);
+        else { for (int p = 0; p < 16; ++p) wv[p] = as_h2(w[p & 3]); }
+        if (VAR == V_DEQ) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) asm volatile("" ::"v"(wv[p]));
+        } else {
+            const int kbase = (it & 31) << 7;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                h8 b;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { b[2 * p] = wv[4 * t + p].x; b[2 * p + 1] = wv[4 * t + p].y; }
+                const h8 av = (VAR == V_FULL_LDS || VAR == V_LIN) ? *(const h8*)(xl + kbase + 8 * o + 32 * t) : areg;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, acc, 0, 0, 0);
+            }
+            if (VAR == V_LIN) {   // per-group fp32 fix-up of the linear-math body
+                const float sf = (float)meta.x, zf = (float)meta.y;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(sf, acc[i], zf * acc[i]);
+            }
+        }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345f) out[0] = 0;
+}
+
+template <int BITS, int VAR>
+static void run(const char* name, uint64_t* d_out) {
+    printf("%-28s", name);
+    for (int wps : {1, 2, 4, 6, 8}) {
+        // waves per CU = 4 * wps, as blocks of <= 1024 threads
+        const int waves_cu = 4 * wps;
+        const int bpc = waves_cu > 16 ? 2 : 1;
+        const int threads = waves_cu / bpc * 64;
+        const int grid = 256 * bpc;
+        const int iters = 400;
+        hipLaunchKernelGGL((tile_kernel<BITS, VAR>), dim3(grid), dim3(threads), 0, 0, d_out, 1u, iters);
+        hipLaunchKernelGGL((tile_kernel<BITS, VAR>), dim3(grid), dim3(threads), 0, 0, d_out, 2u, iters);
+        hipDeviceSynchronize();
+        std::vector<uint64_t> h(grid * threads / 64);
+        hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
+        double s = 0, mx = 0;
+        for (auto v : h) { s += (double)v; if ((double)v > mx) mx = (double)v; }
+        s /= h.size();
+        printf("  %dw %6.1f/%6.1f", wps, s / iters / wps, mx / iters / wps);
+    }
+    printf("\n");
+}
+
+int main() {
+    uint64_t* d_out;
+    hipMalloc(&d_out, 1 << 20);
+    printf("shader cycles per tile per SIMD: mean / max over waves of (wave wall cycles for N tiles) / N / waves-per-SIMD\n");
+    run<4, V_FULL>("b4 dequant+mfma (A regs)", d_out);
+    run<4, V_FULL_LDS>("b4 dequant+mfma (A LDS)", d_out);
+    run<4, V_DEQ>("b4 dequant only", d_out);
+    run<4, V_MFMA>("b4 mfma only", d_out);
+    run<4, V_LIN>("b4 linear (and+mfma+fix)", d_out);
+    run<3, V_FULL_LDS>("b3 dequant+mfma (A LDS)", d_out);
+    run<3, V_DEQ>("b3 dequant only", d_out);
+    run<3, V_LIN>("b3 linear", d_out);
+    run<2, V_FULL_LDS>("b2 dequant+mfma (A LDS)", d_out);
+    run<2, V_DEQ>("b2 dequant only", d_out);
+    run<2, V_LIN>("b2 linear", d_out);
+    return 0;
+}
