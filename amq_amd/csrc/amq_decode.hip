@@ -146,7 +146,7 @@ hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void
 }
 
 // ------------------------------------------ RoPE + KV append + attention
-// grid = (n_heads, batch); 256 threads; head_dim == 128.
+// grid = (n_heads, batch); 512 threads; head_dim == 128.
 // KV cache layout: [batch][kv_head][max_seq][128] fp16 (keys already rotated).
 // HF Llama numerics: cos/sin computed in fp32, cast to fp16; q' = q*cos + rotate_half(q)*sin in fp16;
 // scores and softmax in fp32; probabilities cast to fp16 before P.V (eager attention path).
@@ -162,50 +162,79 @@ __device__ __forceinline__ void rope_cs(float theta, int pos, int i, _Float16* c
     *s16 = (_Float16)sn;
 }
 
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+// 16-lane (DPP row) all-reduce: after it every lane of a row holds the row's sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
+}
+
+// One workgroup of 512 threads per (head, sequence) = 32 groups of 16 lanes; a group owns the cached keys / values
+// t = group + 32 i and a lane the 16-byte slice [8 lane, 8 lane + 8) of each 256-byte row, so every wave-load is four
+// whole contiguous rows (the first version gave each thread one key row: 64 different cache lines per load
+// instruction).  A single CU pulls its head's K/V rows at what it keeps in flight, so ALL rows of contexts up to
+// 32 * ATT_PF = 384 tokens are requested before anything is computed (the first 128 keys even before the position
+// has arrived); longer contexts continue with a plain loop.  The leading arguments are kernarg-preloaded (Makefile).
+constexpr int ATT_THREADS = 512;
+constexpr int ATT_GROUPS = ATT_THREADS / 16;
+constexpr int ATT_PF = 12;             // rows of K and of V per group held in registers
+constexpr int ATT_SPEC = 4;            // of those, K rows requested before the position is known
+
+struct AttnRest { void* out; const void* rope_table; int pos; float rope_theta; };
+
+__global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, void* p_vc, const int* p_pos_dev, int p_heads,
+                                                                   int p_max_seq, const void* p_q, const void* p_k,
+                                                                   const void* p_v, AttnRest rest) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* qs = (_Float16*)smem;                 // [128] rotated q
     _Float16* ks = (_Float16*)smem + ATT_D;         // [128] rotated new key (also what is appended)
     float* sc = (float*)(smem + 4 * ATT_D);         // [T] scores / probabilities
-    __shared__ float red[8];
-    __shared__ float part[16][ATT_D];
+    __shared__ float red[2 * ATT_THREADS / 64];
+    __shared__ float part[ATT_GROUPS][ATT_D];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int pos = a.pos_dev ? *a.pos_dev : a.pos;
-    const int T = pos + 1;
-    const int group = a.n_heads / a.n_kv_heads;
+    const int n_heads = p_heads & 0xFFFF, n_kv_heads = p_heads >> 16, max_seq = p_max_seq;
+    const int group = n_heads / n_kv_heads;
     const int kvh = h / group;
-    const _Float16* q = (const _Float16*)a.q + ((size_t)b * a.n_heads + h) * ATT_D;
-    const _Float16* kn = (const _Float16*)a.k + ((size_t)b * a.n_kv_heads + kvh) * ATT_D;
-    const _Float16* vn = (const _Float16*)a.v + ((size_t)b * a.n_kv_heads + kvh) * ATT_D;
-    _Float16* kc = (_Float16*)a.kcache + ((size_t)b * a.n_kv_heads + kvh) * (size_t)a.max_seq * ATT_D;
-    _Float16* vc = (_Float16*)a.vcache + ((size_t)b * a.n_kv_heads + kvh) * (size_t)a.max_seq * ATT_D;
+    const int grp = tid >> 4, l16 = tid & 15;
+    const _Float16* q = (const _Float16*)p_q + ((size_t)b * n_heads + h) * ATT_D;
+    const _Float16* kn = (const _Float16*)p_k + ((size_t)b * n_kv_heads + kvh) * ATT_D;
+    const _Float16* vn = (const _Float16*)p_v + ((size_t)b * n_kv_heads + kvh) * ATT_D;
+    _Float16* kc = (_Float16*)p_kc + ((size_t)b * n_kv_heads + kvh) * (size_t)max_seq * ATT_D;
+    _Float16* vc = (_Float16*)p_vc + ((size_t)b * n_kv_heads + kvh) * (size_t)max_seq * ATT_D;
 
-    // every thread fetches its cached key row while wave 0 rotates q / k: one key per thread per pass
-    h8 krow[16];
-    const int t_own = tid;
-    if (t_own < pos) {
+    // speculative: the first ATT_SPEC * 32 key rows (clamped to the cache; rows >= pos are discarded later)
+    h8 krow[ATT_PF], vrow[ATT_PF];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) krow[j] = *(const h8*)(kc + (size_t)t_own * ATT_D + 8 * j);
+    for (int i = 0; i < ATT_SPEC; ++i) {
+        int t = grp + ATT_GROUPS * i;
+        t = t < max_seq - 1 ? t : max_seq - 1;
+        krow[i] = *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
     }
-    // ... and the first 8 value rows of its (key group, 8-dim slice): the K and V HBM round trips overlap
-    constexpr int VPRE = 8;
-    h8 vpre[VPRE];
-    {
-        const int kg0 = tid >> 4, l0 = tid & 15;
+    const int pos = p_pos_dev ? *p_pos_dev : rest.pos;
+    const int T = pos + 1;
+    const int last_old = pos > 0 ? pos - 1 : 0;      // rows >= pos are never used; clamp keeps every load inside rows already written
 #pragma unroll
-        for (int i = 0; i < VPRE; ++i) {
-            const int t = kg0 + 16 * i;
-            if (t < pos) vpre[i] = *(const h8*)(vc + (size_t)t * ATT_D + 8 * l0);
-        }
+    for (int i = ATT_SPEC; i < ATT_PF; ++i) {
+        int t = grp + ATT_GROUPS * i;
+        t = t < last_old ? t : last_old;
+        krow[i] = *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
+    }
+#pragma unroll
+    for (int i = 0; i < ATT_PF; ++i) {
+        int t = grp + ATT_GROUPS * i;
+        t = t < last_old ? t : last_old;
+        vrow[i] = *(const h8*)(vc + (size_t)t * ATT_D + 8 * l16);
     }
     if (tid < 64) {
         const int i = tid;                          // rotary pair (i, i + 64)
         _Float16 c16, s16;
-        if (a.rope_table) {
-            const h2 cs2 = ((const h2*)a.rope_table)[(size_t)pos * 64 + i];
+        if (rest.rope_table) {
+            const h2 cs2 = ((const h2*)rest.rope_table)[(size_t)pos * 64 + i];
             c16 = cs2.x; s16 = cs2.y;
         } else {
-            rope_cs(a.rope_theta, pos, i, &c16, &s16);
+            rope_cs(rest.rope_theta, pos, i, &c16, &s16);
         }
         const _Float16 q0 = q[i], q1 = q[i + 64];
         qs[i] = q0 * c16 + (-q1) * s16;             // q*cos + rotate_half(q)*sin  (fp16 ops, HF apply_rotary_pos_emb)
@@ -223,70 +252,81 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     }
     __syncthreads();
 
-    // scores: one key per thread (the new key comes from LDS)
+    // scores: 16 lanes x 8 dims per key, DPP row reduction; the new key comes from LDS (its cache row may still be in flight)
     const float scale = rsqrtf((float)ATT_D);
-    float lmax = -INFINITY;
-    for (int t = tid; t < T; t += 256) {
+    const h8 qv = *(const h8*)(qs + 8 * l16);
+    const h8 knew = *(const h8*)(ks + 8 * l16);
+    auto score = [&](const h8& kv) {
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            h8 kv;
-            if (t == pos) kv = *(const h8*)(ks + 8 * j);
-            else if (t == t_own) kv = krow[j];
-            else kv = *(const h8*)(kc + (size_t)t * ATT_D + 8 * j);
-            const h8 qv = *(const h8*)(qs + 8 * j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                s = __builtin_amdgcn_fdot2((h2){qv[2 * e], qv[2 * e + 1]}, (h2){kv[2 * e], kv[2 * e + 1]}, s, false);
-        }
+        for (int e = 0; e < 4; ++e)
+            s = __builtin_amdgcn_fdot2((h2){qv[2 * e], qv[2 * e + 1]}, (h2){kv[2 * e], kv[2 * e + 1]}, s, false);
+        s = row16_sum(s);
         // HF eager attention: matmul(q, k^T) -> fp16, * scaling -> fp16, softmax in fp32
-        const float sv = (float)(_Float16)((float)(_Float16)s * scale);
-        sc[t] = sv;
-        lmax = fmaxf(lmax, sv);
+        return (float)(_Float16)((float)(_Float16)s * scale);
+    };
+#pragma unroll
+    for (int i = 0; i < ATT_PF; ++i) {
+        const int t = grp + ATT_GROUPS * i;
+        const float sv = score(t == pos ? knew : krow[i]);
+        if (t < T && l16 == 0) sc[t] = sv;
     }
+    for (int t = grp + ATT_GROUPS * ATT_PF; t < T; t += ATT_GROUPS) {       // contexts beyond the register prefetch
+        const h8 kv = (t == pos) ? knew : *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
+        const float sv = score(kv);
+        if (l16 == 0) sc[t] = sv;
+    }
+    __syncthreads();
+    float lmax = -INFINITY;
+    for (int t = tid; t < T; t += ATT_THREADS) lmax = fmaxf(lmax, sc[t]);
     lmax = wave_max_f(lmax);
     if ((tid & 63) == 0) red[tid >> 6] = lmax;
     __syncthreads();
-    const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float gmax = red[0];
+#pragma unroll
+    for (int w = 1; w < ATT_THREADS / 64; ++w) gmax = fmaxf(gmax, red[w]);
     float lsum = 0.f;
-    for (int t = tid; t < T; t += 256) {
+    for (int t = tid; t < T; t += ATT_THREADS) {
         const float e = __expf(sc[t] - gmax);
         sc[t] = e;
         lsum += e;
     }
     lsum = wave_sum_f(lsum);
-    if ((tid & 63) == 0) red[4 + (tid >> 6)] = lsum;
+    if ((tid & 63) == 0) red[ATT_THREADS / 64 + (tid >> 6)] = lsum;
     __syncthreads();
-    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-
-    // out = sum_t p_t * V[t]: 16 key groups x 16 lanes, 8 dims (16 B) per lane
-    const int kg = tid >> 4, l = tid & 15;
-    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPRE; ++i) {
-        const int t = kg + 16 * i;
+    for (int w = 0; w < ATT_THREADS / 64; ++w) tot += red[ATT_THREADS / 64 + w];
+    const float inv = 1.0f / tot;
+
+    // out = sum_t p_t * V[t]: 32 key groups x 16 lanes, 8 dims (16 B) per lane
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const h8 vnew = *(const h8*)(vn + 8 * l16);
+#pragma unroll
+    for (int i = 0; i < ATT_PF; ++i) {
+        const int t = grp + ATT_GROUPS * i;
         if (t < T) {
             const _Float16 p16 = (_Float16)(sc[t] * inv);        // softmax(...).to(fp16)
-            const h8 vv = (t == pos) ? *(const h8*)(vn + 8 * l) : vpre[i];
+            const h8 vv = (t == pos) ? vnew : vrow[i];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += (float)p16 * (float)vv[e];
         }
     }
-    for (int t = kg + 16 * VPRE; t < T; t += 16) {
+    for (int t = grp + ATT_GROUPS * ATT_PF; t < T; t += ATT_GROUPS) {
         const _Float16 p16 = (_Float16)(sc[t] * inv);
-        const h8 vv = (t == pos) ? *(const h8*)(vn + 8 * l) : *(const h8*)(vc + (size_t)t * ATT_D + 8 * l);
+        const h8 vv = (t == pos) ? vnew : *(const h8*)(vc + (size_t)t * ATT_D + 8 * l16);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += (float)p16 * (float)vv[e];
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[kg][8 * l + e] = o[e];
+    for (int e = 0; e < 8; ++e) part[grp][8 * l16 + e] = o[e];
     __syncthreads();
     if (tid < ATT_D) {
-        float tot = 0.f;
+        float acc = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) tot += part[g][tid];
-        _Float16* out = (_Float16*)a.out + ((size_t)b * a.n_heads + h) * ATT_D;
-        out[tid] = (_Float16)tot;
+        for (int g = 0; g < ATT_GROUPS; ++g) acc += part[g][tid];
+        _Float16* out = (_Float16*)rest.out + ((size_t)b * n_heads + h) * ATT_D;
+        out[tid] = (_Float16)acc;
     }
 }
 
@@ -311,7 +351,9 @@ hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.n_heads, batch), dim3(256), lds, st, a);
+    AttnRest rest{a.out, a.rope_table, a.pos, a.rope_theta};
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.n_heads, batch), dim3(ATT_THREADS), lds, st, a.kcache, a.vcache, a.pos_dev,
+                       a.n_heads | (a.n_kv_heads << 16), a.max_seq, a.q, a.k, a.v, rest);
     return hipGetLastError();
 }
 

@@ -84,6 +84,40 @@ def test_attn_decode_sequence(nh, nkv):
         assert torch.equal(kc[0, :, pos], ks[-1]) and torch.equal(vc[0, :, pos], vs[-1])
 
 
+@pytest.mark.parametrize("pos", [0, 1, 31, 127, 128, 383, 384, 385, 700, 1023])
+def test_attn_decode_long_context(pos):
+    """one step at a given position over a pre-filled cache: covers the speculative prefetch (first 128 keys), the
+    register-prefetch limit (384 keys), the remainder loop beyond it, and the last row of the cache"""
+    from amq_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(100 + pos)
+    nh, nkv, max_seq = 8, 4, 1024
+    kc = torch.zeros(1, nkv, max_seq, 128, dtype=torch.float16, device=dev)
+    vc = torch.zeros_like(kc)
+    if pos:
+        kc[0, :, :pos] = torch.randn(nkv, pos, 128, generator=g).half().to(dev)
+        vc[0, :, :pos] = torch.randn(nkv, pos, 128, generator=g).half().to(dev)
+    # poison the rows that must never contribute
+    kc[0, :, pos + 1:] = 1000.0
+    vc[0, :, pos + 1:] = 1000.0
+    q = torch.randn(1, nh, 128, generator=g).half().to(dev)
+    k = torch.randn(1, nkv, 128, generator=g).half().to(dev)
+    v = torch.randn(1, nkv, 128, generator=g).half().to(dev)
+    out = torch.zeros(1, nh * 128, dtype=torch.float16, device=dev)
+    posd = torch.full((1,), pos, dtype=torch.int32, device=dev)
+    ops.attn_decode(q.reshape(1, -1), k.reshape(1, -1), v.reshape(1, -1), kc, vc, out, posd, nh, nkv,
+                    table=ops.rope_table(max_seq, 10000.0, dev))
+    kr = _rope_ref(k[0], pos)
+    assert torch.equal(kc[0, :, pos], kr) and torch.equal(vc[0, :, pos], v[0])
+    K = kc[0, :, :pos + 1].repeat_interleave(nh // nkv, 0)
+    V = vc[0, :, :pos + 1].repeat_interleave(nh // nkv, 0)
+    qr = _rope_ref(q[0], pos)
+    w = torch.matmul(qr[:, None, :], K.transpose(1, 2)) * (128 ** -0.5)
+    p_ = torch.softmax(w.float(), -1).half()
+    ref = torch.matmul(p_, V)[:, 0, :].reshape(-1)
+    assert torch.allclose(out[0].float(), ref.float(), rtol=1e-2, atol=3e-3), (out[0].float() - ref.float()).abs().max()
+
+
 def _ref_model(m):
     """dense fp16 torch mirror of a QuantLlama (weights dequantized by the bit-exact dequantize kernel)"""
     from amq_amd import ops
