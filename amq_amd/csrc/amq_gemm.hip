@@ -92,12 +92,27 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     store_a(abuf(0));
     __syncthreads();
 
+#ifdef AMQ_GABL_NODEQ      /* ablation: unpack once, outside the K loop */
+    h2 wv[NSUB][16];
+#pragma unroll
+    for (int nb = 0; nb < NSUB; ++nb) dequant_lane_sd<BITS, MODE>(pay[nb].w, meta[nb], wv[nb]);
+#endif
     for (int kt = 0; kt < G; ++kt) {
+#ifdef AMQ_GABL_NOLOADA
+        const _Float16* ab = abuf(0);
+#else
         const _Float16* ab = abuf(kt);
+#endif
+#ifndef AMQ_GABL_NODEQ
         h2 wv[NSUB][16];
 #pragma unroll
         for (int nb = 0; nb < NSUB; ++nb) dequant_lane_sd<BITS, MODE>(pay[nb].w, meta[nb], wv[nb]);
+#endif
+#ifdef AMQ_GABL_NOLOADA    /* ablation: the x tile is staged once; the K loop re-reads the same LDS image */
+        if (kt + 1 < G) { load_b(kt + 1); }
+#else
         if (kt + 1 < G) { load_a(kt + 1); load_b(kt + 1); }      // issue early
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             h8 b[NSUB];
@@ -113,8 +128,12 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b[nb], acc[mb][nb], 0, 0, 0);
             }
         }
+#ifndef AMQ_GABL_NOLOADA
         if (kt + 1 < G) store_a(abuf(kt + 1));              // write late
+#endif
+#ifndef AMQ_GABL_NOBAR
         __syncthreads();
+#endif
     }
 
     // epilogue: acc[mb][nb][i] = D[m = mb*16 + 4*o + i][n = nb*16 + r]

@@ -555,9 +555,9 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
 #undef AMQ_FINISH
 }
 
-// minimum waves per SIMD the register allocator must leave room for: three 8-wave workgroups per CU (6 per SIMD,
-// <= 80 VGPRs), one or two 16-wave workgroups (4, <= 128), six 4-wave ones (6).  Without the bound the decode-prologue
-// variants allocate 90 VGPRs and only two workgroups fit a CU.
+// minimum waves per SIMD for the register allocator (A/B builds only).  The product kernels need <= 80 VGPRs so that three
+// 8-wave workgroups fit a CU (6 waves per SIMD); they get there without a bound (76-78) by holding one activation chunk
+// per thread (XCfg).  Forcing 64 (8 waves per SIMD) spills 27-38 registers into the main loop.
 #ifndef AMQ_LB_WAVES
 #define AMQ_LB_WAVES(NW_) 1
 #endif
@@ -663,12 +663,13 @@ size_t gemv_lds_bytes(int M, int K, int copies) {
 }
 
 int gemv_pick_waves(int total_rt, int K) {
-    // measured on MI355X (tools/microbench.py / tools/abl3.sh sweeps, profiles/): 8 waves x 2 tiles in flight is the
-    // best or within 3% of it for every Llama shape with > 1 workgroup per CU; with <= 256 row-tiles (o_proj, down_proj:
-    // one workgroup per CU) 16 waves are 2-8% faster; tiny K falls back to 4 waves (>= 2 tiles per wave).
+    // measured on MI355X (tools/sweep1.sh, profiles/r01b_gemv_sweep.txt): 8 waves x 2 tiles in flight is the best or
+    // within 3% of it whenever a wave gets >= 4 tiles of a row-tile or there is more than one workgroup per CU; one
+    // 16-wave workgroup per CU wins (3-6%) only for long rows (K >= 8192: down_proj) on <= 256 row-tiles; for K = 4096
+    // on 256 row-tiles (o_proj) 8 waves are ~10% faster (16-wave workgroups dispatch later); tiny K: 4 waves.
     const int G = K >> 7;
     if (G < 16) return 4;
-    if (total_rt <= 256 && G >= 32) return 16;
+    if (total_rt <= 256 && G >= 64) return 16;
     return 8;
 }
 
