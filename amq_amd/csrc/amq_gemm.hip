@@ -7,10 +7,12 @@
 // for 2/3/4-bit alike, over the native AMQ-T16 layout.
 //
 // Structure: workgroup tile BM x (64*NSUB) (BM = 128 or 64, NSUB = 2 or 4), BK = 128 (one quant group), 4 waves side by
-// side along N (wave tile BM x 16*NSUB).  x tiles are double-buffered through LDS
-// (register-staged: issue-early / write-late); the packed W tile never
-// touches LDS -- each lane's 16/12/8-byte payload unpacks (v_and_or +
-// v_pk_*_f16) directly into the B operand of v_mfma_f32_16x16x32_f16 and is
+// side along N (wave tile BM x 16*NSUB).  x tiles are double-buffered through LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR staging, no ds_write pass -- the register-staged first version spent 30% of
+// its time there, profiles/r01b_gemm_ablations.txt); the LDS image is lane-linear per wave-instruction (four whole
+// 256-byte rows), so the bank swizzle is applied on the SOURCE address: 16-byte slot s of row r lives at slot s ^ (r & 15).
+// The packed W tile never touches LDS -- each lane's 16/12/8-byte payload unpacks
+// directly into the B operand of v_mfma_f32_16x16x32_f16 and is
 // reused across all BM/16 row blocks, so the unpack VALU work is amortised BM/16x.
 // fp32 accumulate; split-K is not used (K/128 steps stay inside one workgroup,
 // results are deterministic).
@@ -20,8 +22,8 @@
 namespace amq {
 
 constexpr int GM_THREADS = 256;
-constexpr int GM_LDA = 128 + 16;    // halves per staged x row: 288 B = 18 sixteen-byte slots -> slot (2r + o + 4t) mod 16 is
-                                    // distinct inside every ds_read_b128 lane group (272 B measured 2-way conflicts)
+constexpr int GM_LDA = 128;         // halves per staged x row: 256 B = 16 sixteen-byte slots, XOR-swizzled by the row (see above):
+                                    // slot ((4t + o) ^ r) is distinct inside every ds_read_b128 lane group
 
 // NSUB = 16-column sub-tiles per wave: every A fragment read from LDS feeds NSUB MFMAs (LDS read traffic per
 // MFMA falls as 1/NSUB; accumulators grow as BM/16 * NSUB * 4 VGPRs).  Workgroup tile = BM x (4 waves * 16 * NSUB).
@@ -29,7 +31,7 @@ template <int BITS, int MODE, int BM, int NSUB>
 __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     constexpr int GM_BN = 4 * 16 * NSUB;
     constexpr int MBLK = BM / 16;              // 16-row blocks per wave tile
-    constexpr int ACH = BM * 16 / GM_THREADS;  // 16-byte chunks of the x tile per thread
+    constexpr int ACH = BM * 16 / GM_THREADS;  // LDS-DMA instructions per wave and x tile (= 16-byte chunks per thread)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* const abase = (_Float16*)smem;
     auto abuf = [&](int i) { return abase + (i & 1) * (BM * GM_LDA); };
@@ -53,24 +55,22 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < NSUB; ++j) acc[i][j] = (f4){0, 0, 0, 0};
 
-    h8 areg[ACH];
     LanePayload<BITS> pay[NSUB];
     h2 meta[NSUB];
-    auto load_a = [&](int kt) {
+    // LDS-DMA of one BM x 128 x tile: wave-instruction i (0 .. BM/4-1) fills rows 4i .. 4i+3; wave w issues i = w + 4j.
+    // Lane l supplies row 4i + (l >> 4), LDS slot l & 15  <-  global slot (l & 15) ^ (row & 15).
+    // Rows past M re-read row M-1 (computed, never stored).
+    auto issue_a = [&](int kt, _Float16* buf) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
-            const int c = threadIdx.x + GM_THREADS * j;
-            const int row = c >> 4, col = (c & 15) * 8;
-            const int m = m0 + row;
-            areg[j] = (m < a.M) ? *(const h8*)(x + (size_t)m * a.x_stride + kt * 128 + col) : (h8)(_Float16)0;
-        }
-    };
-    auto store_a = [&](_Float16* buf) {
-#pragma unroll
-        for (int j = 0; j < ACH; ++j) {
-            const int c = threadIdx.x + GM_THREADS * j;
-            const int row = c >> 4, col = (c & 15) * 8;
-            *(h8*)(buf + row * GM_LDA + col) = areg[j];
+            const int i = wave + 4 * j;
+            const int row = 4 * i + (lane >> 4);
+            const int slot = (lane & 15) ^ (row & 15);
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            const _Float16* src = x + (size_t)m * a.x_stride + kt * 128 + slot * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(buf + i * 512), 16, 0, 0);
         }
     };
     auto load_b = [&](int kt) {
@@ -87,10 +87,9 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
         }
     };
 
-    load_a(0);
+    issue_a(0, abuf(0));
     load_b(0);
-    store_a(abuf(0));
-    __syncthreads();
+    __syncthreads();            // (emits vmcnt(0): the DMA has landed before anyone reads)
 
 #ifdef AMQ_GABL_NODEQ      /* ablation: unpack once, outside the K loop */
     h2 wv[NSUB][16];
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 #ifdef AMQ_GABL_NOLOADA    /* ablation: the x tile is staged once; the K loop re-reads the same LDS image */
         if (kt + 1 < G) { load_b(kt + 1); }
 #else
-        if (kt + 1 < G) { load_a(kt + 1); load_b(kt + 1); }      // issue early
+        if (kt + 1 < G) { issue_a(kt + 1, abuf(kt + 1)); load_b(kt + 1); }      // next tile: DMA + packed W, in flight under the MFMAs
 #endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -122,17 +121,14 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
                 for (int p = 0; p < 4; ++p) { b[nb][2 * p] = wv[nb][4 * t + p].x; b[nb][2 * p + 1] = wv[nb][4 * t + p].y; }
 #pragma unroll
             for (int mb = 0; mb < MBLK; ++mb) {
-                const h8 av = *(const h8*)(ab + (mb * 16 + r) * GM_LDA + 32 * t + 8 * o);
+                const h8 av = *(const h8*)(ab + (mb * 16 + r) * GM_LDA + (((4 * t + o) ^ r) << 3));
 #pragma unroll
                 for (int nb = 0; nb < NSUB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b[nb], acc[mb][nb], 0, 0, 0);
             }
         }
-#ifndef AMQ_GABL_NOLOADA
-        if (kt + 1 < G) store_a(abuf(kt + 1));              // write late
-#endif
 #ifndef AMQ_GABL_NOBAR
-        __syncthreads();
+        __syncthreads();        // vmcnt(0) + barrier: tile kt+1 has landed and nobody still reads tile kt's buffer
 #endif
     }
 
