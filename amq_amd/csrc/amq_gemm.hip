@@ -169,7 +169,9 @@ static hipError_t gemm_launch_cfg(const GemmArgs& a, hipStream_t st) {
 
 template <int BITS, int MODE>
 static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
-    if (a.M <= 64) return gemm_launch_cfg<BITS, MODE, 64, 2>(a, st);
+    // 64-row tiles while 128-row tiles would leave the chip under-filled (< 1.5 workgroups per CU)
+    const long wg128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.M <= 64 || wg128 < 384) return gemm_launch_cfg<BITS, MODE, 64, 2>(a, st);
     // measured (5120x5120, M = 4096 / 16384): NSUB = 2 -> 0.81 / 0.89-0.92 PFLOP/s; NSUB = 4 needs ~390 VGPRs
     // (one wave per SIMD) and drops to 0.68 / 0.76 -- kept only as an A/B knob
     const bool wide = (g_gemm_nsub == 4);

@@ -107,7 +107,7 @@ def main():
             print(json.dumps(bench_case(4096, 4096, 4, m, args.iters)), flush=True)
     if not args.gemm:
         return
-    for m in (64, 512, 4096, 16384):
+    for m in (64, 256, 512, 1024, 4096, 16384):
         for bits in (4, 3, 2):
             r = bench_case(5120, 5120, bits, m, max(20, args.iters // 10), "gemm")
             r["TFLOPs"] = round(2.0 * m * 5120 * 5120 / r["us"] / 1e6, 1)
