@@ -276,7 +276,7 @@ int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcach
     if (batch < 1 || n_heads < 1 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0)
         return fail(AMQ_ESHAPE, "bad head configuration (%d q heads, %d kv heads)", n_heads, n_kv_heads);
     if (max_seq < 1 || (!pos_dev && (pos < 0 || pos >= max_seq))) return fail(AMQ_ESHAPE, "position %d outside the cache (max_seq=%d)", pos, max_seq);
-    if (4 * 128 + (size_t)max_seq * 4 > LDS_LIMIT) return fail(AMQ_ESHAPE, "max_seq=%d too long for the single-pass decode attention", max_seq);
+    if (6 * 128 + (size_t)max_seq * 4 + 17 * 1024 > LDS_LIMIT) return fail(AMQ_ESHAPE, "max_seq=%d too long for the single-pass decode attention", max_seq);
     amq::AttnArgs a{q, k, v, kcache, vcache, out, pos_dev, pos, n_heads, n_kv_heads, max_seq, rope_theta, rope_table};
     return check_hip(amq::launch_attn_decode(a, batch, (hipStream_t)stream), "attn_decode");
 }

@@ -171,6 +171,30 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)));
+    return v;
+}
+// whole-wave reductions without LDS-crossbar shuffles (6 dependent ds_bpermute round trips cost ~0.35 us each):
+// DPP inside the four 16-lane rows, then four v_readlane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = row16_sum(v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48)));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16))),
+                 fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48))));
+}
+
 // One workgroup of 512 threads per (head, sequence) = 32 groups of 16 lanes; a group owns the cached keys / values
 // t = group + 32 i and a lane the 16-byte slice [8 lane, 8 lane + 8) of each 256-byte row, so every wave-load is four
 // whole contiguous rows (the first version gave each thread one key row: 64 different cache lines per load
@@ -180,9 +204,20 @@ __device__ __forceinline__ float row16_sum(float v) {
 constexpr int ATT_THREADS = 512;
 constexpr int ATT_GROUPS = ATT_THREADS / 16;
 constexpr int ATT_PF = 12;             // rows of K and of V per group held in registers
-constexpr int ATT_SPEC = 4;            // of those, K rows requested before the position is known
+constexpr int ATT_SPEC = 8;            // of those, K rows requested before the position is known (256 keys)
 
-struct AttnRest { void* out; const void* rope_table; int pos; float rope_theta; };
+struct AttnRest {
+    void* out; const void* rope_table; int pos; float rope_theta;
+#ifdef AMQ_STAMP
+    unsigned long long* stamps;     // diagnostic build: [heads][16] s_memrealtime phase stamps
+#endif
+};
+#ifdef AMQ_STAMP
+extern unsigned long long* g_stamp_ptr;
+#define ATT_STAMP(slot_) do { if (rest.stamps && threadIdx.x == 0) rest.stamps[(size_t)blockIdx.x * 16 + (slot_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ATT_STAMP(slot_) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, void* p_vc, const int* p_pos_dev, int p_heads,
                                                                    int p_max_seq, const void* p_q, const void* p_k,
@@ -190,7 +225,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* qs = (_Float16*)smem;                 // [128] rotated q
     _Float16* ks = (_Float16*)smem + ATT_D;         // [128] rotated new key (also what is appended)
-    float* sc = (float*)(smem + 4 * ATT_D);         // [T] scores / probabilities
+    _Float16* vs = (_Float16*)smem + 2 * ATT_D;     // [128] new value
+    float* sc = (float*)(smem + 6 * ATT_D);         // [T] scores / probabilities
     __shared__ float red[2 * ATT_THREADS / 64];
     __shared__ float part[ATT_GROUPS][ATT_D];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -204,6 +240,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
     _Float16* kc = (_Float16*)p_kc + ((size_t)b * n_kv_heads + kvh) * (size_t)max_seq * ATT_D;
     _Float16* vc = (_Float16*)p_vc + ((size_t)b * n_kv_heads + kvh) * (size_t)max_seq * ATT_D;
 
+    ATT_STAMP(0);
+    // vmcnt waits are in issue order: what the rotation needs (raw q / k / v of the new token, later the cos/sin pair) is
+    // requested BEFORE the wave's share of the cache rows, or wave 0 would sit behind its 24 row loads (measured 2.5-3.4 us
+    // from position to barrier, profiles/r01b_attn_stamps.txt)
+    _Float16 q0 = 0, q1 = 0, k0 = 0, k1 = 0, v0 = 0, v1 = 0;
+    if (tid < 64) {
+        q0 = q[tid]; q1 = q[tid + 64];
+        k0 = kn[tid]; k1 = kn[tid + 64];
+        v0 = vn[tid]; v1 = vn[tid + 64];
+    }
     // speculative: the first ATT_SPEC * 32 key rows (clamped to the cache; rows >= pos are discarded later)
     h8 krow[ATT_PF], vrow[ATT_PF];
 #pragma unroll
@@ -214,6 +260,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
     }
     const int pos = p_pos_dev ? *p_pos_dev : rest.pos;
     const int T = pos + 1;
+    ATT_STAMP(1);
+    h2 cs2 = {(_Float16)1.f, (_Float16)0.f};
+    if (tid < 64 && rest.rope_table) cs2 = ((const h2*)rest.rope_table)[(size_t)pos * 64 + tid];
     const int last_old = pos > 0 ? pos - 1 : 0;      // rows >= pos are never used; clamp keeps every load inside rows already written
 #pragma unroll
     for (int i = ATT_SPEC; i < ATT_PF; ++i) {
@@ -229,28 +278,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
     }
     if (tid < 64) {
         const int i = tid;                          // rotary pair (i, i + 64)
-        _Float16 c16, s16;
-        if (rest.rope_table) {
-            const h2 cs2 = ((const h2*)rest.rope_table)[(size_t)pos * 64 + i];
-            c16 = cs2.x; s16 = cs2.y;
-        } else {
-            rope_cs(rest.rope_theta, pos, i, &c16, &s16);
-        }
-        const _Float16 q0 = q[i], q1 = q[i + 64];
+        _Float16 c16 = cs2.x, s16 = cs2.y;
+        if (!rest.rope_table) rope_cs(rest.rope_theta, pos, i, &c16, &s16);
         qs[i] = q0 * c16 + (-q1) * s16;             // q*cos + rotate_half(q)*sin  (fp16 ops, HF apply_rotary_pos_emb)
         qs[i + 64] = q1 * c16 + q0 * s16;
-        const _Float16 k0 = kn[i], k1 = kn[i + 64];
         const _Float16 r0 = k0 * c16 + (-k1) * s16, r1 = k1 * c16 + k0 * s16;
         ks[i] = r0;
         ks[i + 64] = r1;
+        vs[i] = v0;
+        vs[i + 64] = v1;
         if (h % group == 0) {                       // one query head per kv group appends to the cache
             kc[(size_t)pos * ATT_D + i] = r0;
             kc[(size_t)pos * ATT_D + i + 64] = r1;
-            vc[(size_t)pos * ATT_D + i] = vn[i];
-            vc[(size_t)pos * ATT_D + i + 64] = vn[i + 64];
+            vc[(size_t)pos * ATT_D + i] = v0;
+            vc[(size_t)pos * ATT_D + i + 64] = v1;
         }
     }
     __syncthreads();
+    ATT_STAMP(2);
 
     // scores: 16 lanes x 8 dims per key, DPP row reduction; the new key comes from LDS (its cache row may still be in flight)
     const float scale = rsqrtf((float)ATT_D);
@@ -277,9 +322,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
         if (l16 == 0) sc[t] = sv;
     }
     __syncthreads();
+    ATT_STAMP(3);
     float lmax = -INFINITY;
     for (int t = tid; t < T; t += ATT_THREADS) lmax = fmaxf(lmax, sc[t]);
-    lmax = wave_max_f(lmax);
+    lmax = wave_max_dpp(lmax);
     if ((tid & 63) == 0) red[tid >> 6] = lmax;
     __syncthreads();
     float gmax = red[0];
@@ -291,17 +337,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
         sc[t] = e;
         lsum += e;
     }
-    lsum = wave_sum_f(lsum);
+    lsum = wave_sum_dpp(lsum);
     if ((tid & 63) == 0) red[ATT_THREADS / 64 + (tid >> 6)] = lsum;
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
     for (int w = 0; w < ATT_THREADS / 64; ++w) tot += red[ATT_THREADS / 64 + w];
     const float inv = 1.0f / tot;
+    ATT_STAMP(4);
 
     // out = sum_t p_t * V[t]: 32 key groups x 16 lanes, 8 dims (16 B) per lane
     float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const h8 vnew = *(const h8*)(vn + 8 * l16);
+    const h8 vnew = *(const h8*)(vs + 8 * l16);
 #pragma unroll
     for (int i = 0; i < ATT_PF; ++i) {
         const int t = grp + ATT_GROUPS * i;
@@ -321,6 +368,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
 #pragma unroll
     for (int e = 0; e < 8; ++e) part[grp][8 * l16 + e] = o[e];
     __syncthreads();
+    ATT_STAMP(5);
     if (tid < ATT_D) {
         float acc = 0.f;
 #pragma unroll
@@ -328,6 +376,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
         _Float16* out = (_Float16*)rest.out + ((size_t)b * n_heads + h) * ATT_D;
         out[tid] = (_Float16)acc;
     }
+    ATT_STAMP(6);
 }
 
 // cos/sin table for positions 0..max_seq-1 (HF LlamaRotaryEmbedding values, fp32 math, fp16 storage)
@@ -346,12 +395,15 @@ hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st
 }
 
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st) {
-    const size_t lds = 4 * ATT_D + (size_t)a.max_seq * 4;
+    const size_t lds = 6 * ATT_D + (size_t)a.max_seq * 4;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     AttnRest rest{a.out, a.rope_table, a.pos, a.rope_theta};
+#ifdef AMQ_STAMP
+    rest.stamps = g_stamp_ptr;
+#endif
     hipLaunchKernelGGL(attn_decode_kernel, dim3(a.n_heads, batch), dim3(ATT_THREADS), lds, st, a.kcache, a.vcache, a.pos_dev,
                        a.n_heads | (a.n_kv_heads << 16), a.max_seq, a.q, a.k, a.v, rest);
     return hipGetLastError();
