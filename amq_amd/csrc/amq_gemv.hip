@@ -667,9 +667,12 @@ int gemv_pick_waves(int total_rt, int K) {
     // within 3% of it whenever a wave gets >= 4 tiles of a row-tile or there is more than one workgroup per CU; one
     // 16-wave workgroup per CU wins (3-6%) only for long rows (K >= 8192: down_proj) on <= 256 row-tiles; for K = 4096
     // on 256 row-tiles (o_proj) 8 waves are ~10% faster (16-wave workgroups dispatch later); tiny K: 4 waves.
+    // K > 4096 always takes 16 waves: the register-held activation staging of the decode prologue covers
+    // K <= 8 * XC * threads (4096 for 8 waves, 16384 for 16), and one 16-wave workgroup per CU is within 5% of the
+    // 8-wave grids on every shape measured.
     const int G = K >> 7;
     if (G < 16) return 4;
-    if (total_rt <= 256 && G >= 64) return 16;
+    if (G > 32) return 16;
     return 8;
 }
 
@@ -710,10 +713,12 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     int total_rt = 0;
     for (int i = 0; i < a.nseg; ++i) { a.seg[i].n_rt = a.seg[i].N / 16; total_rt += a.seg[i].n_rt; }
     const int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_rt, a.K);
-    // persistent-style grid: about 24 waves per CU (256 CUs); a workgroup walks `rpt` row-tiles
+    // persistent-style grid: about 24 waves per CU (256 CUs) -- three 8-wave workgroups, but ONE 16-wave workgroup (two do
+    // not fit the register file at 78 VGPRs, a second round of workgroups would run on an empty chip); a workgroup walks
+    // `rpt` row-tiles
     int rpt = a.force_rpt;
     if (rpt <= 0) {
-        const int target = 256 * 24 / nw;
+        const int target = nw == 16 ? 256 : 256 * 24 / nw;
         rpt = (total_rt + target - 1) / target;
         if (rpt < 1) rpt = 1;
     }

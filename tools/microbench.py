@@ -98,7 +98,7 @@ def main():
     if args.quick:
         shapes = shapes[:2]
     if args.only:
-        shapes = [tuple(int(v) for v in args.only.split(","))]
+        shapes = [tuple(int(v) for v in sh.split(",")) for sh in args.only.split(";")]
     if args.gemv:
         for n, k in shapes:
             for bits in (4, 3, 2):
