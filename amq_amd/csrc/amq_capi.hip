@@ -281,6 +281,13 @@ int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcach
     return check_hip(amq::launch_attn_decode(a, batch, (hipStream_t)stream), "attn_decode");
 }
 
+int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
+                        void* stream) {
+    if (!logits || !embed || !token || !pos || !x) return fail(AMQ_EINVAL, "null pointer");
+    if (vocab < 1 || hidden < 8 || (hidden % 8) != 0) return fail(AMQ_ESHAPE, "need vocab >= 1 and hidden %% 8 == 0 (got %d, %d)", vocab, hidden);
+    return check_hip(amq::launch_decode_tail(logits, vocab, embed, hidden, token, pos, x, (hipStream_t)stream), "decode_tail");
+}
+
 int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream) {
     if (!table || max_seq < 1) return fail(AMQ_EINVAL, "bad rope table request");
     return check_hip(amq::launch_rope_table(table, max_seq, rope_theta, (hipStream_t)stream), "rope_table");

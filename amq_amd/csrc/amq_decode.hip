@@ -145,6 +145,61 @@ hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void
     return hipGetLastError();
 }
 
+// ------------------------------------------------ end of a token step
+// greedy next token + what the next step needs, in ONE single-workgroup launch (replaces argmax, position increment and
+// embedding gather = three framework kernels and their boundaries): token = argmax(logits) (first maximum, like
+// torch.argmax), pos += 1, x = embed[token].
+__global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logits, int vocab, const _Float16* embed, int hidden,
+                                                            long long* token, int* pos, _Float16* x) {
+    __shared__ float smax[16];
+    __shared__ int sidx[16];
+    __shared__ int stok;
+    const int tid = threadIdx.x;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    const int chunks = vocab >> 3;
+    for (int c = tid; c < chunks; c += 1024) {
+        const h8 v = *(const h8*)(logits + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            if (f > best) { best = f; bi = 8 * c + e; }          // ascending index inside a thread: first maximum kept
+        }
+    }
+    for (int i = 8 * chunks + tid; i < vocab; i += 1024) {       // vocab % 8 tail
+        const float f = (float)logits[i];
+        if (f > best || (f == best && i < bi)) { best = f; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((tid & 63) == 0) { smax[tid >> 6] = best; sidx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float b = smax[0];
+        int ix = sidx[0];
+        for (int w = 1; w < 16; ++w)
+            if (smax[w] > b || (smax[w] == b && sidx[w] < ix)) { b = smax[w]; ix = sidx[w]; }
+        if (ix == 0x7fffffff) ix = 0;                            // all NaN / empty: torch returns 0-ish; keep it in range
+        stok = ix;
+        token[0] = (long long)ix;
+        pos[0] = pos[0] + 1;
+    }
+    __syncthreads();
+    const _Float16* row = embed + (size_t)stok * hidden;
+    for (int c = tid; c < (hidden >> 3); c += 1024) *(h8*)(x + 8 * c) = *(const h8*)(row + 8 * c);
+}
+
+hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, int hidden, void* token, void* pos, void* x,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(decode_tail_kernel, dim3(1), dim3(1024), 0, st, (const _Float16*)logits, vocab, (const _Float16*)embed, hidden,
+                       (long long*)token, (int*)pos, (_Float16*)x);
+    return hipGetLastError();
+}
+
 // ------------------------------------------ RoPE + KV append + attention
 // grid = (n_heads, batch); 512 threads; head_dim == 128.
 // KV cache layout: [batch][kv_head][max_seq][128] fp16 (keys already rotated).

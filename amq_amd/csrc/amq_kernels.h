@@ -74,6 +74,8 @@ struct AttnArgs {
 hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st);
 hipError_t launch_rmsnorm(const void* x, const void* gamma, void* y, int M, int K, float eps, hipStream_t st);
+hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, int hidden, void* token, void* pos, void* x,
+                              hipStream_t st);
 hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                             int N, int K, hipStream_t st);
 

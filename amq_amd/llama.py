@@ -141,9 +141,9 @@ class QuantLlama:
 
     # ----------------------------------------------------------------- decode
     def _step(self):
-        """one token: reads self.token / self.pos (device), writes self.logits, self.token, self.pos"""
+        """one token: reads self.x (= embed[self.token], kept in step by set_token / the step's own tail) and self.pos
+        (device), writes self.logits, self.token, self.pos and the next step's self.x"""
         H = self.H
-        torch.index_select(self.embed, 0, self.token, out=self.x)
         for blk in self.blocks:
             ops.gemv_grouped(self.x, [blk["self_attn.q_proj"].seg(self.q), blk["self_attn.k_proj"].seg(self.k),
                                       blk["self_attn.v_proj"].seg(self.v)], H, prologue=ops.PRO_RMSNORM,
@@ -156,8 +156,15 @@ class QuantLlama:
             ops.gemv_grouped(self.gate, [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I,
                              prologue=ops.PRO_SILU_MUL, x2=self.up)
         ops.gemv_f16w(self.x.reshape(-1), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
-        self.pos.add_(1)
+        ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x)     # argmax, pos += 1, x = embed[token]
+
+    def set_token(self, token):
+        """make ``token`` (int or 1-element tensor) the input of the next decode step"""
+        if isinstance(token, torch.Tensor):
+            self.token.copy_(token.reshape(1))
+        else:
+            self.token.fill_(int(token))
+        torch.index_select(self.embed, 0, self.token, out=self.x)
 
     def capture(self):
         """capture one token step into a hipGraph (replayed by decode_step)"""
@@ -169,13 +176,13 @@ class QuantLlama:
         with torch.cuda.stream(side):
             self._step()                       # warm-up outside capture (allocator, lazy init)
             side.synchronize()
-            self.token.copy_(saved[0]); self.pos.copy_(saved[1])
+            self.set_token(saved[0]); self.pos.copy_(saved[1])
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 self._step()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
-        self.token.copy_(saved[0]); self.pos.copy_(saved[1])
+        self.set_token(saved[0]); self.pos.copy_(saved[1])
         self.graph = g
 
     def decode_step(self, use_graph=True):
@@ -229,13 +236,13 @@ class QuantLlama:
             x = x + lin(blk["mlp.down_proj"], torch.nn.functional.silu(g) * u)
         last = x[S - 1].contiguous()
         ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
+        self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
         self.pos.fill_(S)
         return self.logits
 
     def reset(self):
         self.pos.zero_()
-        self.token.zero_()
+        self.set_token(0)
 
     def generate(self, ids, gen_len, use_graph=True):
         """greedy: prefill + gen_len tokens (min_new_tokens = max_new_tokens = gen_len,
@@ -301,7 +308,6 @@ class DenseLlama(QuantLlama):
 
     def _step(self):
         F = torch.nn.functional
-        torch.index_select(self.embed, 0, self.token, out=self.x)
         x = self.x
         for blk in self.blocks:
             h = ops.rmsnorm(x, blk["ln1"], self.eps)
@@ -314,8 +320,7 @@ class DenseLlama(QuantLlama):
             x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]),
                              blk["mlp.down_proj"])
         ops.gemv_f16w(x.reshape(-1).contiguous(), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
-        self.pos.add_(1)
+        ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x)
 
     def prefill(self, ids):
         F = torch.nn.functional
@@ -344,7 +349,7 @@ class DenseLlama(QuantLlama):
             x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]), blk["mlp.down_proj"])
         last = x[S - 1].contiguous()
         ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        torch.argmax(self.logits, dim=0, keepdim=True, out=self.token)
+        self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
         self.pos.fill_(S)
         return self.logits
 

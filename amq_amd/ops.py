@@ -233,6 +233,18 @@ def gemv_f16w(x, W, bias=None, gamma=None, eps=0.0, out=None):
     return y
 
 
+def decode_tail(logits, embed, token, pos, x):
+    """token = argmax(logits), pos += 1, x = embed[token] -- one launch (graph-capturable)"""
+    vocab, hidden = embed.shape
+    _need(logits, torch.float16, "logits", vocab)
+    _need(embed, torch.float16, "embed", vocab * hidden)
+    _need(token, torch.int64, "token", 1)
+    _need(pos, torch.int32, "pos", 1)
+    _need(x, torch.float16, "x", hidden)
+    _lib.check(_lib.load().amq_decode_tail_f16(_lib.ptr(logits), vocab, _lib.ptr(embed), hidden, _lib.ptr(token), _lib.ptr(pos),
+                                               _lib.ptr(x), _lib.current_stream()))
+
+
 def rope_table(max_seq, rope_theta, device):
     tab = torch.empty(max_seq, 64, 2, dtype=torch.float16, device=device)
     _lib.check(_lib.load().amq_rope_table_f16(_lib.ptr(tab), max_seq, ctypes.c_float(rope_theta), _lib.current_stream()))

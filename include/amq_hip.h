@@ -175,6 +175,13 @@ int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcach
 /* optional: fp16 [max_seq][64][2] (cos, sin) table for amq_attn_decode_f16 (NULL there = computed in-kernel, same values) */
 int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream);
 
+/* End of a greedy token step in one launch: token[0] = argmax(logits[0..vocab)) (first maximum), pos[0] += 1,
+ * x[0..hidden) = embed[token][0..hidden).  Replaces the `torch.argmax` / position increment / embedding gather that follow
+ * the lm_head in the reference's generation loop (amq/utils/speed.py:70-76, HF `_sample`) when the step is replayed from
+ * a hipGraph.  logits, embed, x: fp16; token: int64; pos: int32; all device pointers. */
+int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

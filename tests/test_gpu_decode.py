@@ -41,6 +41,25 @@ def test_gemv_f16w(norm):
     assert torch.all(err <= 1e-3 * ref.abs() + 1e-3 * ref.pow(2).mean().sqrt())
 
 
+def test_decode_tail():
+    """argmax (first maximum) + position increment + embedding gather in one launch"""
+    from amq_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    for vocab, hidden in ((32000, 4096), (1003, 256)):
+        embed = torch.randn(vocab, hidden, generator=g).half().to(dev)
+        logits = torch.randn(vocab, generator=g).half().to(dev)
+        logits[vocab // 3] = 9.0
+        logits[vocab // 3 + 7] = 9.0                    # tie: the first one wins
+        token = torch.zeros(1, dtype=torch.int64, device=dev)
+        pos = torch.full((1,), 41, dtype=torch.int32, device=dev)
+        x = torch.zeros(1, hidden, dtype=torch.float16, device=dev)
+        ops.decode_tail(logits, embed, token, pos, x)
+        assert int(token.item()) == vocab // 3 == int(torch.argmax(logits.float().cpu()).item())
+        assert int(pos.item()) == 42
+        assert torch.equal(x[0], embed[vocab // 3])
+
+
 def _rope_ref(t, pos):
     inv = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32, device=t.device) / 128.0))
     fr = torch.tensor([float(pos)], device=t.device)[:, None] * inv[None, :]
@@ -241,7 +260,7 @@ def test_reference_checkpoints_mixed_arch_logits():
     toks = [int(m.token.item())]
     for step in range(1, 5):
         # feed the REFERENCE's greedy token so both see the same prefix even if an argmax tie flips
-        m.token.fill_(int(exp["tokens"][step - 1]))
+        m.set_token(int(exp["tokens"][step - 1]))
         m.decode_step(use_graph=(step >= 2))
         lg = m.logits.float().cpu().numpy()
         assert np.abs(lg - ref[step]).max() <= 2e-2 * scale, step
