@@ -495,11 +495,14 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     unsigned long long c_wait = 0, c_math = 0, c_row = 0;
     constexpr int OPS_PER_TILE = (BITS == 3) ? 4 : 2;
 #define AMQ_T() __builtin_amdgcn_s_memtime()
+    AMQ_STAMP_AT(blk, 96 + wave);                                  // realtime: about to wait for the first tile
+    bool first_ = true;
     for (; idx + 2 * U <= total; idx += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned long long t0 = AMQ_T();
             __builtin_amdgcn_s_waitcnt(0x0F70 | ((U - 1) * OPS_PER_TILE));      /* vmcnt((U-1)*ops) [hi bits 0], lgkm/exp untouched */
+            if (first_) { AMQ_STAMP_AT(blk, 112 + wave); first_ = false; }       // realtime: first tile has arrived
             const unsigned long long t1 = AMQ_T();
             AMQ_COMPUTE(u);
             __builtin_amdgcn_sched_barrier(0);

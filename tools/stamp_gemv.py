@@ -93,6 +93,12 @@ def main():
         if (s[:, 6] != 0).all():
             clk = (s[:, 6] - s[:, 5]) / np.maximum(s[:, 4] - s[:, 0], 1) * 100.0   # shader ticks per 10 ns -> MHz
             print("  shader clock MHz (memtime / memrealtime per WG)", q(clk))
+        fw = np.where(s[:, 96:112] != 0, us(s[:, 96:112].astype(np.int64)), np.nan)
+        fa = np.where(s[:, 112:128] != 0, us(s[:, 112:128].astype(np.int64)), np.nan)
+        if np.isfinite(fa).any():
+            print("  loop entry (wave) - staged   ", q(fw - staged[:, None]))
+            print("  first tile arrived - primed  ", q(fa - primed[:, None]))
+            print("  first tile arrived - staged  ", q(fa - staged[:, None]))
         ph = s[:, 32:96].reshape(len(s), 16, 4).astype(np.float64)
         act = ph[:, :, 3] > 0
         if act.any():
