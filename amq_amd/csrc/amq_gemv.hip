@@ -521,6 +521,13 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
         blk.stamps[(size_t)blockIdx.x * 128 + 32 + wave * 4 + 3] = (unsigned long long)idx;
     }
 #else
+#ifndef AMQ_NO_PRIO_PROGRESS
+    // Issue priority falls with the wave's progress (quartiles of its tile count).  The SIMD arbiter is oldest-first: a CU's
+    // three workgroups -- and the waves of one workgroup that share a SIMD -- otherwise complete one after the other, and
+    // the SIMD runs at its two-wave efficiency (335-394 cycles per tile) instead of the six-wave one (242); with laggards
+    // preferred all resident waves stay interleaved (profiles/r01b_gemv_prio.txt: 2-10% per launch).
+    const int q1_ = total >> 2, q2_ = total >> 1, q3_ = q1_ + q2_;
+#endif
     for (; idx + 2 * U <= total; idx += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -530,6 +537,11 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
             __builtin_amdgcn_sched_barrier(0);
             AMQ_ROWEND();
         }
+#ifndef AMQ_NO_PRIO_PROGRESS
+        if (idx + U >= q3_) __builtin_amdgcn_s_setprio(0);
+        else if (idx + U >= q2_) __builtin_amdgcn_s_setprio(1);
+        else if (idx + U >= q1_) __builtin_amdgcn_s_setprio(2);
+#endif
     }
 #endif
 #pragma unroll
@@ -578,6 +590,9 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const v
                                                                      const void* p_mt0, int p_K, int p_m_nseg, int p_rpt,
                                                                      int p_n_rt0, int p_key0, float p_eps, GemvKArgs blk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifndef AMQ_NO_PRIO_PROGRESS
+    __builtin_amdgcn_s_setprio(3);          // prologue and first quarter of the stream at top priority (see the main loop)
+#endif
     GemvHot a;
     a.x = p_x; a.x2 = p_xw; a.gamma = p_xw;
     a.K = p_K; a.M = p_m_nseg & 0xFFFF; a.rpt = p_rpt; a.eps = p_eps;
