@@ -82,6 +82,11 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    # A/B knobs from the environment (tools/, bench experiments): AMQ_GEMV_WAVES / _DEPTH / _RPT / _MATH
+    for env, opt in (("AMQ_GEMV_WAVES", OPT_GEMV_WAVES), ("AMQ_GEMV_DEPTH", OPT_GEMV_DEPTH), ("AMQ_GEMV_RPT", OPT_GEMV_RPT),
+                     ("AMQ_GEMV_MATH", OPT_GEMV_MATH)):
+        if os.environ.get(env):
+            check(lib.amq_set_option(opt, int(os.environ[env])))
     return lib
 
 

@@ -390,6 +390,14 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     const _Float16* xrow = xl + (size_t)mrow * xs + 8 * o;
     int ci = 0, cj = 0, par = 0;                                  // compute cursor, red[] parity
 
+    int plevel_ = 3;
+#define AMQ_SETPRIO_LEVEL()                                                                      \
+    do {                                                                                         \
+        if (plevel_ == 3) __builtin_amdgcn_s_setprio(3);                                         \
+        else if (plevel_ == 2) __builtin_amdgcn_s_setprio(2);                                    \
+        else if (plevel_ == 1) __builtin_amdgcn_s_setprio(1);                                    \
+        else __builtin_amdgcn_s_setprio(0);                                                      \
+    } while (0)
     // end of a row-tile for this wave: publish partials, one barrier, fixed-order sum by the first M*16 threads
 #define AMQ_FINISH()                                                                             \
     do {                                                                                         \
@@ -538,9 +546,15 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
             AMQ_ROWEND();
         }
 #ifndef AMQ_NO_PRIO_PROGRESS
-        if (idx + U >= q3_) __builtin_amdgcn_s_setprio(0);
-        else if (idx + U >= q2_) __builtin_amdgcn_s_setprio(1);
-        else if (idx + U >= q1_) __builtin_amdgcn_s_setprio(2);
+#if defined(AMQ_PRIO_VARIANT) && AMQ_PRIO_VARIANT == 1      /* B: only the prologue is boosted */
+        __builtin_amdgcn_s_setprio(1);
+#elif defined(AMQ_PRIO_VARIANT) && AMQ_PRIO_VARIANT == 2    /* C: two levels, switch at half */
+        if (idx + U >= q2_) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(2);
+#else
+        plevel_ = idx + U >= q3_ ? 0 : idx + U >= q2_ ? 1 : idx + U >= q1_ ? 2 : 3;
+        AMQ_SETPRIO_LEVEL();
+#endif
 #endif
     }
 #endif
@@ -567,6 +581,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
 #undef AMQ_COMPUTE
 #undef AMQ_ROWEND
 #undef AMQ_EPI_PREFETCH
+#undef AMQ_SETPRIO_LEVEL
 #undef AMQ_FINISH
 }
 
