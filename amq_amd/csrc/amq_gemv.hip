@@ -546,15 +546,8 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
             AMQ_ROWEND();
         }
 #ifndef AMQ_NO_PRIO_PROGRESS
-#if defined(AMQ_PRIO_VARIANT) && AMQ_PRIO_VARIANT == 1      /* B: only the prologue is boosted */
-        __builtin_amdgcn_s_setprio(1);
-#elif defined(AMQ_PRIO_VARIANT) && AMQ_PRIO_VARIANT == 2    /* C: two levels, switch at half */
-        if (idx + U >= q2_) __builtin_amdgcn_s_setprio(0);
-        else __builtin_amdgcn_s_setprio(2);
-#else
         plevel_ = idx + U >= q3_ ? 0 : idx + U >= q2_ ? 1 : idx + U >= q1_ ? 2 : 3;
         AMQ_SETPRIO_LEVEL();
-#endif
 #endif
     }
 #endif

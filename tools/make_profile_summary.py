@@ -9,7 +9,8 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "r01")
-dst = os.path.join(ROOT, "profiles")
+import sys
+dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles")   # on the GPU box: a directory under gpurun_out/
 os.makedirs(dst, exist_ok=True)
 
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "r01_bench.json"))
