@@ -44,6 +44,8 @@ SIGNATURES = {
     "amq_gemv_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_gemm_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_linear_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "amq_gemm_splitk_workspace_bytes": (_sz, [_i, _i, _i]),
+    "amq_gemm_splitk_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "amq_compat_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "amq_vecquantmatmul_faster_old": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp]),
     "amq_gemv_4bit": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _i, _vp]),

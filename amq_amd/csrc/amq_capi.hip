@@ -180,8 +180,28 @@ int amq_gemm_f16(int bits, int mode, const void* x, const void* qn, const void* 
     if (int rc = check_mode(mode)) return rc;
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
-    amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N};
+    amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N, nullptr, 1};
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream), "gemm");
+}
+
+size_t amq_gemm_splitk_workspace_bytes(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < 128) return 0;
+    const int s = amq::gemm_pick_splits(M, N, K);
+    return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
+                        int M, int N, int K, int group, int x_stride, int y_stride, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    const size_t need = amq_gemm_splitk_workspace_bytes(M, N, K);
+    if (need == 0) return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, x_stride, y_stride, stream);
+    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (int rc = check_mode(mode)) return rc;
+    if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
+    if (!workspace || workspace_bytes < need) return fail(AMQ_EINVAL, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N,
+                    (float*)workspace, amq::gemm_pick_splits(M, N, K)};
+    return check_hip(amq::launch_gemm(a, (hipStream_t)stream), "gemm_splitk");
 }
 
 int amq_linear_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,

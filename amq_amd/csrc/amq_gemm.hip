@@ -43,6 +43,10 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     // consecutive workgroups walk M for a fixed N panel: the packed W panel
     // (tiny) stays in L2 while x tiles stream
     const int bn = (int)blockIdx.x % ntn, bm = (int)blockIdx.x / ntn;
+    // split-K (few-row launches that would leave most CUs idle): blockIdx.y owns K steps [k0, k1) and writes fp32
+    // partials to its own workspace slice; splitk_reduce_kernel sums the slices in a fixed order (deterministic)
+    const int sp = (int)blockIdx.y;
+    const int k0 = (int)((long)sp * G / a.splits), k1 = (int)((long)(sp + 1) * G / a.splits);
     const int m0 = bm * BM, n0 = bn * GM_BN + wave * (16 * NSUB);
 
     const _Float16* x = (const _Float16*)a.x;
@@ -87,8 +91,8 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
         }
     };
 
-    issue_a(0, abuf(0));
-    load_b(0);
+    issue_a(k0, abuf(0));
+    load_b(k0);
     __syncthreads();            // (emits vmcnt(0): the DMA has landed before anyone reads)
 
 #ifdef AMQ_GABL_NODEQ      /* ablation: unpack once, outside the K loop */
@@ -96,11 +100,11 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 #pragma unroll
     for (int nb = 0; nb < NSUB; ++nb) dequant_lane_sd<BITS, MODE>(pay[nb].w, meta[nb], wv[nb]);
 #endif
-    for (int kt = 0; kt < G; ++kt) {
+    for (int kt = k0; kt < k1; ++kt) {
 #ifdef AMQ_GABL_NOLOADA
         const _Float16* ab = abuf(0);
 #else
-        const _Float16* ab = abuf(kt);
+        const _Float16* ab = abuf(kt - k0);
 #endif
 #ifndef AMQ_GABL_NODEQ
         h2 wv[NSUB][16];
@@ -108,9 +112,9 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
         for (int nb = 0; nb < NSUB; ++nb) dequant_lane_sd<BITS, MODE>(pay[nb].w, meta[nb], wv[nb]);
 #endif
 #ifdef AMQ_GABL_NOLOADA    /* ablation: the x tile is staged once; the K loop re-reads the same LDS image */
-        if (kt + 1 < G) { load_b(kt + 1); }
+        if (kt + 1 < k1) { load_b(kt + 1); }
 #else
-        if (kt + 1 < G) { issue_a(kt + 1, abuf(kt + 1)); load_b(kt + 1); }      // next tile: DMA + packed W, in flight under the MFMAs
+        if (kt + 1 < k1) { issue_a(kt + 1, abuf(kt + 1 - k0)); load_b(kt + 1); }      // next tile: DMA + packed W, in flight under the MFMAs
 #endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -144,11 +148,49 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
                 const int m = m0 + mb * 16 + 4 * o + i;
                 const int n = n0 + nb * 16 + r;
                 if (m < a.M && n < a.N) {
-                    _Float16 v = (_Float16)acc[mb][nb][i];
-                    if (bias) v = v + bias[n];
-                    y[(size_t)m * a.y_stride + n] = v;
+                    if (a.splits > 1) {
+                        a.ws[((size_t)sp * a.M + m) * a.N + n] = acc[mb][nb][i];
+                    } else {
+                        _Float16 v = (_Float16)acc[mb][nb][i];
+                        if (bias) v = v + bias[n];
+                        y[(size_t)m * a.y_stride + n] = v;
+                    }
                 }
             }
+}
+
+// y[m][n] = fp16(sum over splits, in order) (+ bias): 8 columns per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, const _Float16* bias, _Float16* y, int M, int N,
+                                                           int y_stride, int splits) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int nchunk = N >> 3;
+    if (idx >= (long)M * nchunk) return;
+    const int m = (int)(idx / nchunk), n = (int)(idx % nchunk) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < splits; ++s) {
+        const f4 lo = *(const f4*)(ws + ((size_t)s * M + m) * N + n);
+        const f4 hi = *(const f4*)(ws + ((size_t)s * M + m) * N + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += lo[e]; acc[4 + e] += hi[e]; }
+    }
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        _Float16 v = (_Float16)acc[e];
+        if (bias) v = v + bias[n + e];
+        o[e] = v;
+    }
+    *(h8*)(y + (size_t)m * y_stride + n) = o;
+}
+
+int gemm_pick_splits(int M, int N, int K) {
+    const long wg = (long)((M + 63) / 64) * ((N + 127) / 128);      // 64-row tiles (what such launches use)
+    const int G = K >> 7;
+    if (wg >= 192 || G < 4 || (N & 7)) return 1;
+    int s = (int)((256 + wg - 1) / wg);
+    if (s > 8) s = 8;
+    if (s > G / 2) s = G / 2;
+    return s < 1 ? 1 : s;
 }
 
 int g_gemm_nsub = 0;     // A/B knob: 0 = auto, 2 or 4
@@ -163,7 +205,12 @@ static hipError_t gemm_launch_cfg(const GemmArgs& a, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(GM_THREADS), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(ntm * ntn, a.splits), dim3(GM_THREADS), lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.splits <= 1) return e;
+    const long items = (long)a.M * (a.N >> 3);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (const float*)a.ws,
+                       (const _Float16*)a.bias, (_Float16*)a.y, a.M, a.N, a.y_stride, a.splits);
     return hipGetLastError();
 }
 
@@ -171,7 +218,7 @@ template <int BITS, int MODE>
 static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
     // 64-row tiles while 128-row tiles would leave the chip under-filled (< 1.5 workgroups per CU)
     const long wg128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (a.M <= 64 || wg128 < 384) return gemm_launch_cfg<BITS, MODE, 64, 2>(a, st);
+    if (a.M <= 64 || wg128 < 384 || a.splits > 1) return gemm_launch_cfg<BITS, MODE, 64, 2>(a, st);
     // measured (5120x5120, M = 4096 / 16384): NSUB = 2 -> 0.81 / 0.89-0.92 PFLOP/s; NSUB = 4 needs ~390 VGPRs
     // (one wave per SIMD) and drops to 0.68 / 0.76 -- kept only as an A/B knob
     const bool wide = (g_gemm_nsub == 4);

@@ -53,8 +53,11 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st);
 struct GemmArgs {
     const void* x; const void* qweight; const void* meta; const void* bias; void* y;
     int M, N, K, bits, mode, x_stride, y_stride;
+    float* ws;      // split-K partials [splits][M][N] fp32 (or null)
+    int splits;     // >= 1
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st);
+int gemm_pick_splits(int M, int N, int K);
 extern int g_gemm_nsub;
 
 // decode-step surroundings (amq_decode.hip)

@@ -144,8 +144,19 @@ def gemv(x, qn, mn, bits, mode, N, K, bias=None, out=None):
     return y.reshape(*x.shape[:-1], N)
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(device, nbytes):
+    """per-device scratch for split-K partials (grown on demand, reused by every launch on the stream)"""
+    ws = _SPLITK_WS.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _SPLITK_WS[device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None):
-    """y = x . W^T for any number of rows (MFMA tiles)."""
+    """y = x . W^T for any number of rows (MFMA tiles; split-K when few rows would leave the chip idle)."""
     _check_shape(bits, N, K)
     _check_native(qn, mn, bits, N, K)
     x2 = _prep_x(x, K)
@@ -154,8 +165,15 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None):
         _need(bias, torch.float16, "bias", N)
     y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=x.device)
     _need(y, torch.float16, "y", M * N)
-    _lib.check(_lib.load().amq_gemm_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
-                                        _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.current_stream()))
+    lib = _lib.load()
+    need = lib.amq_gemm_splitk_workspace_bytes(M, N, K)
+    if need:
+        ws = _splitk_workspace(x.device, need)
+        _lib.check(lib.amq_gemm_splitk_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias), _lib.ptr(y),
+                                           M, N, K, GROUP, 0, 0, _lib.ptr(ws), ws.numel() * 4, _lib.current_stream()))
+    else:
+        _lib.check(lib.amq_gemm_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
+                                    _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.current_stream()))
     return y.reshape(*x.shape[:-1], N)
 
 
@@ -167,6 +185,8 @@ def linear(x, qn, mn, bits, mode, N, K, bias=None):
     M = x2.shape[0]
     if bias is not None:
         _need(bias, torch.float16, "bias", N)
+    if M > 8:                       # tiled MFMA GEMM (split-K for few rows); amq_linear_f16 makes the same cut at 8 rows
+        return gemm(x, qn, mn, bits, mode, N, K, bias=bias)
     y = torch.empty(M, N, dtype=torch.float16, device=x.device)
     if M == 0:
         return y.reshape(*x.shape[:-1], N)

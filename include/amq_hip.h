@@ -117,6 +117,17 @@ int amq_gemm_f16(int bits, int mode, const void* x, const void* qweight_native, 
 int amq_linear_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
                    const void* bias, void* y, int M, int N, int K, int group, void* stream);
 
+/* Few-row GEMM (16 < M <= ~256: short prompts) with split-K: a launch whose M x N tiles would occupy fewer than 192
+ * workgroups splits the K loop over up to 8 workgroup layers; each layer writes fp32 partials into its own slice of a
+ * caller-owned workspace, a second kernel sums the slices in a fixed order (deterministic, no atomics).
+ * amq_gemm_splitk_workspace_bytes() returns the bytes required (0: the shape does not split and no workspace is
+ * needed; the call then forwards to amq_gemm_f16).  Replaces the reference's cross-CTA split-K of gemm_w4a16_T1
+ * (amq/kernel/ft/quantization_new/gemm/gemm_cuda.cu:514-584: semaphore + __hadd2 read-modify-write of C). */
+size_t amq_gemm_splitk_workspace_bytes(int M, int N, int K);
+int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
+                        const void* bias, void* y, int M, int N, int K, int group, int x_stride, int y_stride,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* several linears that consume the same x (q/k/v, gate/up), each with its own bit-width,
  * in ONE launch; optional fused prologue on x and residual add on y. */
 typedef struct amq_segment {

@@ -334,3 +334,33 @@ def test_error_paths_raise():
         ops.gemv(x, qn, mn, 5, ops.MODE_HQQ, 64, 256)                  # bits
     with pytest.raises(_lib.AmqError):
         ops.gemv(torch.randn(60, 256).half().to(_dev()), qn, mn, 4, 9, 64, 256)   # bad mode reaches the C ABI
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("m,n,k", [(17, 256, 1024), (64, 512, 4096), (100, 1280, 2048), (64, 4096, 11008)])
+def test_gemm_splitk_matches_single_pass(bits, m, n, k):
+    """few-row GEMMs take the split-K path (fp32 partial slices + ordered reduce): same result as the dequantized-weight
+    matmul, deterministic, and the C entry point rejects a short workspace"""
+    import ctypes
+    from amq_amd import _lib, ops
+    from amq_amd.hqq_format import random_hqq
+    dev = torch.device("cuda:0")
+    h = random_hqq(n, k, bits, seed=3 * bits + m).to(dev)
+    qn, mn = ops.repack_from_hqq(h.W_q, h.scale.reshape(-1), h.zero.reshape(-1), bits, n, k)
+    x = torch.randn(m, k, device=dev, generator=torch.Generator(device=dev).manual_seed(m)).half()
+    bias = torch.randn(n, device=dev).half()
+    lib = _lib.load()
+    need = lib.amq_gemm_splitk_workspace_bytes(m, n, k)
+    assert need > 0, "shape expected to split"
+    y = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias)
+    w = ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k)
+    ref = x.float() @ w.float().t()
+    rms = ref.pow(2).mean().sqrt()
+    yref = (ref.half() + bias).float()
+    # (the bias may cancel most of the product: the fp16 rounding that matters is the product's, so bound by |ref|)
+    assert torch.all((y.float() - yref).abs() <= 1e-3 * (ref.abs() + bias.float().abs()) + 1e-3 * rms)
+    assert torch.equal(ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias), y)
+    ws = torch.empty(need // 4 - 1, dtype=torch.float32, device=dev)
+    rc = lib.amq_gemm_splitk_f16(bits, ops.MODE_HQQ, _lib.ptr(x), _lib.ptr(qn), _lib.ptr(mn), None, _lib.ptr(y), m, n, k, 128, 0, 0,
+                                 _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
+    assert rc != 0 and b"workspace" in lib.amq_last_error()
