@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _seed_everything():
+    """every test draws the same inputs on every run (no tolerance check may depend on an unseeded generator)"""
+    import numpy as np
+    import torch
+    np.random.seed(0)
+    torch.manual_seed(0)        # seeds the default CPU and (when present) GPU generators
+    yield
