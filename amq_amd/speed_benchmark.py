@@ -100,8 +100,9 @@ def main(argv=None):
 
     result.update({"args": vars(args)})
     if args.file_name:
-        os.makedirs("benchmark/outputs", exist_ok=True)
-        with open(os.path.join("benchmark/outputs", args.file_name), "w") as f:
+        out_path = os.path.join("benchmark/outputs", args.file_name)      # amq_speed_benchmark.py:290-293
+        os.makedirs(os.path.dirname(out_path), exist_ok=True)
+        with open(out_path, "w") as f:
             json.dump(result, f, indent=4)
     print(json.dumps(result))
     return result
