@@ -7,8 +7,12 @@
 
     {"fp16": {"tps": {"1.64.128": ...}, ...}, "<bits>bit": {...}, "args": {...}}
 
-Differences forced by the offline environment: weights are synthetic payloads of the model's real layer
-shapes (``--save_path`` pointing at real HQQ checkpoints is not supported yet: SURVEY.md 8 f-2), ``--use_ft`` is
+``--save_path`` works as in the reference: the quantized row is assembled from the HQQ checkpoint directories
+``{save_path}/{model_name}_{n}bit_128gs_1axis`` (``config.json`` + ``qmodel.pt`` as written by
+``AutoHQQHFModel.save_quantized``; amq_speed_benchmark.py:129-131, 231-251) -- only the bit-widths the arch uses have to
+exist, and the model shape is taken from their ``config.json``.  Without it (no checkpoints ship with the reference and
+there is no network) the weights are synthetic payloads of the model's real layer shapes.  The fp16 row is always
+synthetic (the reference loads the HF fp16 checkpoint from ``--model_path``).  ``--use_ft`` is
 accepted and ignored (there is one attention path), and without ``--arch_path`` the arch is uniform
 ``--target_bits`` in {2,3,4} exactly as in the reference; ``--synthesize_arch`` draws an arch at
 ``--target_bits`` with the SearchSpace.sample recipe when no searched ``.stats`` file is at hand.
@@ -20,6 +24,7 @@ import os
 import torch
 
 from . import arch as arch_mod
+from . import checkpoint
 from .llama import DenseLlama, QuantLlama, get_memory_footprint
 from .speed import benchmark_speed, cleanup
 
@@ -46,9 +51,19 @@ def main(argv=None):
     p.add_argument("--skip_fp16", action="store_true", help="(extension) do not run the fp16 baseline row")
     args = p.parse_args(argv)
 
-    if args.model_name not in arch_mod.MODEL_CONFIGS:
-        raise SystemExit(f"unknown model {args.model_name}; known: {sorted(arch_mod.MODEL_CONFIGS)}")
-    cfg = arch_mod.MODEL_CONFIGS[args.model_name]
+    def ckpt_dir(bits):
+        return os.path.join(args.save_path, f"{args.model_name}_{bits}bit_128gs_1axis")     # amq_speed_benchmark.py:129-131
+
+    if args.save_path:
+        have = [b for b in (2, 3, 4) if os.path.isdir(ckpt_dir(b))]
+        if not have:
+            raise FileNotFoundError(f"no HQQ checkpoint directory {ckpt_dir('{2,3,4}')} found")
+        with open(os.path.join(ckpt_dir(have[0]), "config.json")) as f:
+            cfg = checkpoint.runner_config(json.load(f))
+    elif args.model_name in arch_mod.MODEL_CONFIGS:
+        cfg = arch_mod.MODEL_CONFIGS[args.model_name]
+    else:
+        raise SystemExit(f"unknown model {args.model_name}; known: {sorted(arch_mod.MODEL_CONFIGS)} (or pass --save_path)")
     sizes = [args.batch_size, args.seq_length, args.gen_length]
     gemm_iteration = 20
     gemv_iteration = 5 if args.gen_length < 1024 else 2          # amq_speed_benchmark.py:168-169
@@ -93,7 +108,14 @@ def main(argv=None):
         linear = arch_mod.uniform_arch(cfg, int(args.target_bits))["linear"]
 
     print(f"Get Speed of {args.target_bits}bit model...")
-    model = QuantLlama(cfg, linear, max_seq=max_seq)
+    if args.save_path:
+        used = sorted({int(b) for v in linear.values() for b in v})
+        missing = [ckpt_dir(b) for b in used if not os.path.isdir(ckpt_dir(b))]
+        if missing:
+            raise FileNotFoundError(f"the arch needs HQQ checkpoints that are not there: {missing}")
+        model = checkpoint.load_mixed({b: ckpt_dir(b) for b in used}, linear, max_seq=max_seq)
+    else:
+        model = QuantLlama(cfg, linear, max_seq=max_seq)
     run(model, f"{args.target_bits}bit")
     del model
     cleanup()

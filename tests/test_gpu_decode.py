@@ -266,3 +266,29 @@ def test_reference_checkpoints_mixed_arch_logits():
         assert np.abs(lg - ref[step]).max() <= 2e-2 * scale, step
         toks.append(int(m.token.item()))
     assert toks == [int(t) for t in exp["tokens"]]
+
+
+def test_speed_benchmark_cli_with_reference_checkpoints(tmp_path, monkeypatch):
+    """--save_path: the quantized row is assembled from HQQ checkpoint directories named like the reference's
+    ({save_path}/{model}_{n}bit_128gs_1axis); here they are the golden checkpoints the real reference wrote"""
+    import json, os, shutil
+    from amq_amd import speed_benchmark
+    root = os.path.join(os.path.dirname(__file__), "golden", "ckpt")
+    save = tmp_path / "hqq"
+    for b in (2, 3, 4):
+        shutil.copytree(os.path.join(root, f"{b}bit"), save / f"tiny-llama_{b}bit_128gs_1axis")
+    exp = np.load(os.path.join(root, "expected.npz"))
+    arch_linear = json.loads(str(exp["arch"]))
+    stats = tmp_path / "iter_0.stats"
+    with open(stats, "w") as f:
+        json.dump({"archive": [[{"linear": arch_linear}, 0.0, 3.0]], "candidates": []}, f)
+    monkeypatch.chdir(tmp_path)
+    res = speed_benchmark.main(["--model_name", "tiny-llama", "--save_path", str(save), "--gemv", "--ttft", "--memory", "--skip_fp16",
+                                "--seq_length", "8", "--gen_length", "4", "--target_bits", "3.0", "--arch_path", str(stats)])
+    row = "3.0bit"
+    assert res[row]["gemv"]["1.8.4"] > 0 and res[row]["ttft"]["1.8.4"] > 0 and res[row]["memory"] > 0
+    # a bit-width the arch needs but the directory lacks -> loud failure
+    shutil.rmtree(save / "tiny-llama_2bit_128gs_1axis")
+    with pytest.raises(FileNotFoundError):
+        speed_benchmark.main(["--model_name", "tiny-llama", "--save_path", str(save), "--gemv", "--skip_fp16",
+                              "--seq_length", "8", "--gen_length", "4", "--target_bits", "3.0", "--arch_path", str(stats)])
