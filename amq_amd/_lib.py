@@ -54,7 +54,8 @@ SIGNATURES = {
     "amq_gemv_f16w": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "amq_attn_decode_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "amq_rope_table_f16": (_i, [_vp, _i, _f, _vp]),
-    "amq_decode_tail_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "amq_decode_tail_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "amq_attn_decode_cur_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),
 }
 

@@ -293,19 +293,35 @@ int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcach
                         int max_seq, float rope_theta, const void* rope_table, void* stream) {
     if (!q || !k || !v || !kcache || !vcache || !out) return fail(AMQ_EINVAL, "null pointer");
     if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
-    if (batch < 1 || n_heads < 1 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0)
+    if (batch < 1 || n_heads < 1 || n_heads > 255 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0)
         return fail(AMQ_ESHAPE, "bad head configuration (%d q heads, %d kv heads)", n_heads, n_kv_heads);
     if (max_seq < 1 || (!pos_dev && (pos < 0 || pos >= max_seq))) return fail(AMQ_ESHAPE, "position %d outside the cache (max_seq=%d)", pos, max_seq);
     if (6 * 128 + (size_t)max_seq * 4 + 17 * 1024 > LDS_LIMIT) return fail(AMQ_ESHAPE, "max_seq=%d too long for the single-pass decode attention", max_seq);
-    amq::AttnArgs a{q, k, v, kcache, vcache, out, pos_dev, pos, n_heads, n_kv_heads, max_seq, rope_theta, rope_table};
+    amq::AttnArgs a{q, k, v, kcache, vcache, out, pos_dev, pos, n_heads, n_kv_heads, max_seq, rope_theta, rope_table, nullptr};
     return check_hip(amq::launch_attn_decode(a, batch, (hipStream_t)stream), "attn_decode");
 }
 
+int amq_attn_decode_cur_f16(const void* q, const void* k, const void* v, void* kcache, void* vcache, void* out,
+                            const void* step_state, int batch, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                            void* stream) {
+    if (!q || !k || !v || !kcache || !vcache || !out || !step_state) return fail(AMQ_EINVAL, "null pointer");
+    if (n_heads > 255) return fail(AMQ_ESHAPE, "at most 255 heads");
+    if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
+    if (batch < 1 || n_heads < 1 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0)
+        return fail(AMQ_ESHAPE, "bad head configuration (%d q heads, %d kv heads)", n_heads, n_kv_heads);
+    if (max_seq < 1) return fail(AMQ_ESHAPE, "bad max_seq %d", max_seq);
+    if (6 * 128 + (size_t)max_seq * 4 + 17 * 1024 > LDS_LIMIT) return fail(AMQ_ESHAPE, "max_seq=%d too long for the single-pass decode attention", max_seq);
+    amq::AttnArgs a{q, k, v, kcache, vcache, out, nullptr, 0, n_heads, n_kv_heads, max_seq, 10000.0f, nullptr, step_state};
+    return check_hip(amq::launch_attn_decode(a, batch, (hipStream_t)stream), "attn_decode_cur");
+}
+
 int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
-                        void* stream) {
+                        const void* rope_table, void* rope_cur, int rope_rows, void* stream) {
     if (!logits || !embed || !token || !pos || !x) return fail(AMQ_EINVAL, "null pointer");
+    if ((rope_table == nullptr) != (rope_cur == nullptr)) return fail(AMQ_EINVAL, "rope_table and rope_cur go together");
+    if (rope_cur && rope_rows < 1) return fail(AMQ_EINVAL, "rope_rows must be the number of rows of rope_table");
     if (vocab < 1 || hidden < 8 || (hidden % 8) != 0) return fail(AMQ_ESHAPE, "need vocab >= 1 and hidden %% 8 == 0 (got %d, %d)", vocab, hidden);
-    return check_hip(amq::launch_decode_tail(logits, vocab, embed, hidden, token, pos, x, (hipStream_t)stream), "decode_tail");
+    return check_hip(amq::launch_decode_tail(logits, vocab, embed, hidden, token, pos, x, rope_table, rope_cur, rope_rows, (hipStream_t)stream), "decode_tail");
 }
 
 int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream) {

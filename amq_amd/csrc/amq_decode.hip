@@ -150,10 +150,11 @@ hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void
 // embedding gather = three framework kernels and their boundaries): token = argmax(logits) (first maximum, like
 // torch.argmax), pos += 1, x = embed[token].
 __global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logits, int vocab, const _Float16* embed, int hidden,
-                                                            long long* token, int* pos, _Float16* x) {
+                                                            long long* token, int* pos, _Float16* x, const _Float16* rope_table,
+                                                            _Float16* rope_cur, int rope_rows) {
     __shared__ float smax[16];
     __shared__ int sidx[16];
-    __shared__ int stok;
+    __shared__ int stok, spos;
     const int tid = threadIdx.x;
     float best = -INFINITY;
     int bi = 0x7fffffff;
@@ -186,17 +187,22 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logit
         if (ix == 0x7fffffff) ix = 0;                            // all NaN / empty: torch returns 0-ish; keep it in range
         stok = ix;
         token[0] = (long long)ix;
-        pos[0] = pos[0] + 1;
+        spos = pos[0] + 1;
+        pos[0] = spos;
     }
     __syncthreads();
+    if (rope_cur && tid < 128) {                                      // cos/sin row of the new position (last row once the cache is full)
+        const int rr = spos < rope_rows ? spos : rope_rows - 1;
+        rope_cur[tid] = rope_table[(size_t)rr * 128 + tid];
+    }
     const _Float16* row = embed + (size_t)stok * hidden;
     for (int c = tid; c < (hidden >> 3); c += 1024) *(h8*)(x + 8 * c) = *(const h8*)(row + 8 * c);
 }
 
 hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, int hidden, void* token, void* pos, void* x,
-                              hipStream_t st) {
+                              const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st) {
     hipLaunchKernelGGL(decode_tail_kernel, dim3(1), dim3(1024), 0, st, (const _Float16*)logits, vocab, (const _Float16*)embed, hidden,
-                       (long long*)token, (int*)pos, (_Float16*)x);
+                       (long long*)token, (int*)pos, (_Float16*)x, (const _Float16*)rope_table, (_Float16*)rope_cur, rope_rows);
     return hipGetLastError();
 }
 
@@ -274,7 +280,10 @@ extern unsigned long long* g_stamp_ptr;
 #define ATT_STAMP(slot_) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, void* p_vc, const int* p_pos_dev, int p_heads,
+// p_state: mode 0 -> device int32 position (or null: rest.pos); mode 1 ("cur") -> the step-state block
+// {fp16 cos/sin [64][2] of the current position; int32 position at byte 256} that amq_decode_tail_f16 maintains: the
+// rotation inputs AND the position are then fetched by the first instructions of the kernel, with no dependent load.
+__global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, void* p_vc, const void* p_state, int p_heads,
                                                                    int p_max_seq, const void* p_q, const void* p_k,
                                                                    const void* p_v, AttnRest rest) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -285,7 +294,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
     __shared__ float red[2 * ATT_THREADS / 64];
     __shared__ float part[ATT_GROUPS][ATT_D];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int n_heads = p_heads & 0xFFFF, n_kv_heads = p_heads >> 16, max_seq = p_max_seq;
+    const int n_heads = p_heads & 0xFF, n_kv_heads = (p_heads >> 8) & 0xFF, max_seq = p_max_seq;
+    const bool cur_mode = (p_heads >> 16) & 1;
+    const void* p_cur = cur_mode ? p_state : nullptr;
+    // the position: a scalar load issued by the kernel's first instructions, first needed after the speculative rows.
+    // (`rest` is only touched on the paths that need it: a select that also reads rest.pos would put an lgkmcnt(0) wait --
+    // kernarg block AND position -- in front of every vector load)
+    int pos;
+    if (cur_mode) pos = *(const int*)((const char*)p_state + 256);
+    else if (p_state) pos = *(const int*)p_state;
+    else pos = rest.pos;
     const int group = n_heads / n_kv_heads;
     const int kvh = h / group;
     const int grp = tid >> 4, l16 = tid & 15;
@@ -299,10 +317,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
     // vmcnt waits are in issue order: what the rotation needs (raw q / k / v of the new token, later the cos/sin pair) is
     // requested BEFORE the wave's share of the cache rows, or wave 0 would sit behind its 24 row loads (measured 2.5-3.4 us
     // from position to barrier, profiles/r01b_attn_stamps.txt)
+    // p_cur (kernarg-preloaded): cos/sin of the CURRENT position, kept up to date by the step's tail kernel
+    // (amq_decode_tail_f16) -- the rotation then no longer waits for the position -> table-row chain
     _Float16 q0 = 0, q1 = 0, k0 = 0, k1 = 0, v0 = 0, v1 = 0;
+    // (two registers for the two possible sources of cos/sin: one variable with two defining loads makes the compiler wait
+    // for the LATER one -- issued behind the speculative rows -- on both paths)
+    h2 cs_cur = {(_Float16)1.f, (_Float16)0.f}, cs_tab = {(_Float16)1.f, (_Float16)0.f};
     if (tid < 64) {
         q0 = q[tid]; q1 = q[tid + 64];
         k0 = kn[tid]; k1 = kn[tid + 64];
+        if (p_cur) cs_cur = ((const h2*)p_cur)[tid];
         v0 = vn[tid]; v1 = vn[tid + 64];
     }
     // speculative: the first ATT_SPEC * 32 key rows (clamped to the cache; rows >= pos are discarded later)
@@ -313,11 +337,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
         t = t < max_seq - 1 ? t : max_seq - 1;
         krow[i] = *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
     }
-    const int pos = p_pos_dev ? *p_pos_dev : rest.pos;
     const int T = pos + 1;
     ATT_STAMP(1);
-    h2 cs2 = {(_Float16)1.f, (_Float16)0.f};
-    if (tid < 64 && rest.rope_table) cs2 = ((const h2*)rest.rope_table)[(size_t)pos * 64 + tid];
+    if (tid < 64 && !p_cur && rest.rope_table) cs_tab = ((const h2*)rest.rope_table)[(size_t)pos * 64 + tid];
     const int last_old = pos > 0 ? pos - 1 : 0;      // rows >= pos are never used; clamp keeps every load inside rows already written
 #pragma unroll
     for (int i = ATT_SPEC; i < ATT_PF; ++i) {
@@ -331,10 +353,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
         t = t < last_old ? t : last_old;
         vrow[i] = *(const h8*)(vc + (size_t)t * ATT_D + 8 * l16);
     }
-    if (tid < 64) {
+    auto rotate_and_append = [&](_Float16 c16, _Float16 s16) {
         const int i = tid;                          // rotary pair (i, i + 64)
-        _Float16 c16 = cs2.x, s16 = cs2.y;
-        if (!rest.rope_table) rope_cs(rest.rope_theta, pos, i, &c16, &s16);
         qs[i] = q0 * c16 + (-q1) * s16;             // q*cos + rotate_half(q)*sin  (fp16 ops, HF apply_rotary_pos_emb)
         qs[i + 64] = q1 * c16 + q0 * s16;
         const _Float16 r0 = k0 * c16 + (-k1) * s16, r1 = k1 * c16 + k0 * s16;
@@ -347,6 +367,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
             kc[(size_t)pos * ATT_D + i + 64] = r1;
             vc[(size_t)pos * ATT_D + i] = v0;
             vc[(size_t)pos * ATT_D + i + 64] = v1;
+        }
+    };
+    if (tid < 64) {
+        if (p_cur) {
+            rotate_and_append(cs_cur.x, cs_cur.y);
+        } else {
+            _Float16 c16 = cs_tab.x, s16 = cs_tab.y;
+            if (!rest.rope_table) rope_cs(rest.rope_theta, pos, tid, &c16, &s16);
+            rotate_and_append(c16, s16);
         }
     }
     __syncthreads();
@@ -459,8 +488,10 @@ hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st) {
 #ifdef AMQ_STAMP
     rest.stamps = g_stamp_ptr;
 #endif
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.n_heads, batch), dim3(ATT_THREADS), lds, st, a.kcache, a.vcache, a.pos_dev,
-                       a.n_heads | (a.n_kv_heads << 16), a.max_seq, a.q, a.k, a.v, rest);
+    const bool cur = a.rope_cur != nullptr;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.n_heads, batch), dim3(ATT_THREADS), lds, st, a.kcache, a.vcache,
+                       cur ? a.rope_cur : (const void*)a.pos_dev, a.n_heads | (a.n_kv_heads << 8) | ((int)cur << 16), a.max_seq,
+                       a.q, a.k, a.v, rest);
     return hipGetLastError();
 }
 

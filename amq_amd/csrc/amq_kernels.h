@@ -73,12 +73,14 @@ struct AttnArgs {
     int n_heads, n_kv_heads, max_seq;
     float rope_theta;
     const void* rope_table;   // fp16 [max_seq][64][2] (cos, sin) from launch_rope_table, or null -> computed in-kernel
+    const void* rope_cur;     // step-state block {fp16 [64][2] (cos, sin) of the CURRENT position; int32 position at byte 256}
+                              // maintained by launch_decode_tail, or null
 };
 hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st);
 hipError_t launch_rmsnorm(const void* x, const void* gamma, void* y, int M, int K, float eps, hipStream_t st);
 hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, int hidden, void* token, void* pos, void* x,
-                              hipStream_t st);
+                              const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st);
 hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                             int N, int K, hipStream_t st);
 

@@ -128,6 +128,9 @@ class QuantLlama:
         self.token = torch.zeros(1, dtype=torch.int64, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.rope_tab = ops.rope_table(max_seq, self.theta, dev)
+        # step state: cos/sin row of self.pos + the position itself in one block (set_token / the step's tail keep it)
+        self.rope_cur, self.pos = ops.new_step_state(dev)
+        self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
 
     # ----------------------------------------------------------------- sizes
@@ -149,22 +152,26 @@ class QuantLlama:
                                       blk["self_attn.v_proj"].seg(self.v)], H, prologue=ops.PRO_RMSNORM,
                              gamma=blk["ln1"], eps=self.eps)
             ops.attn_decode(self.q, self.k, self.v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, self.theta,
-                            table=self.rope_tab)
+                            cur=self.rope_cur)
             ops.gemv_grouped(self.att, [blk["self_attn.o_proj"].seg(self.x, residual=self.x)], H)
             ops.gemv_grouped(self.x, [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H,
                              prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=self.eps)
             ops.gemv_grouped(self.gate, [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I,
                              prologue=ops.PRO_SILU_MUL, x2=self.up)
         ops.gemv_f16w(self.x.reshape(-1), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x)     # argmax, pos += 1, x = embed[token]
+        # argmax, pos += 1, x = embed[token], rope_cur = cos/sin row of the new position
+        ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
 
     def set_token(self, token):
-        """make ``token`` (int or 1-element tensor) the input of the next decode step"""
+        """make ``token`` (int or 1-element tensor) the input of the next decode step; also re-derives what the step
+        reads besides the token (embedding row, cos/sin row of the current position) -- set self.pos first"""
         if isinstance(token, torch.Tensor):
             self.token.copy_(token.reshape(1))
         else:
             self.token.fill_(int(token))
         torch.index_select(self.embed, 0, self.token, out=self.x)
+        torch.index_select(self.rope_tab.view(self.max_seq, 128), 0, self.pos.to(torch.int64).clamp_(0, self.max_seq - 1),
+                           out=self.rope_cur.view(1, 128))
 
     def capture(self):
         """capture one token step into a hipGraph (replayed by decode_step)"""
@@ -176,13 +183,13 @@ class QuantLlama:
         with torch.cuda.stream(side):
             self._step()                       # warm-up outside capture (allocator, lazy init)
             side.synchronize()
-            self.set_token(saved[0]); self.pos.copy_(saved[1])
+            self.pos.copy_(saved[1]); self.set_token(saved[0])
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 self._step()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
-        self.set_token(saved[0]); self.pos.copy_(saved[1])
+        self.pos.copy_(saved[1]); self.set_token(saved[0])
         self.graph = g
 
     def decode_step(self, use_graph=True):
@@ -264,8 +271,8 @@ class QuantLlama:
             x = x + lin(blk["mlp.down_proj"], torch.nn.functional.silu(g) * u)
         last = x[S - 1].contiguous()
         ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
         self.pos.fill_(S)
+        self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
         return self.logits
 
     def reset(self):
@@ -329,6 +336,9 @@ class DenseLlama(QuantLlama):
         self.token = torch.zeros(1, dtype=torch.int64, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.rope_tab = ops.rope_table(max_seq, self.theta, dev)
+        # step state: cos/sin row of self.pos + the position itself in one block (set_token / the step's tail keep it)
+        self.rope_cur, self.pos = ops.new_step_state(dev)
+        self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
 
     def linear_bytes_per_token(self):
@@ -342,13 +352,13 @@ class DenseLlama(QuantLlama):
             q = F.linear(h, blk["self_attn.q_proj"])
             k = F.linear(h, blk["self_attn.k_proj"])
             v = F.linear(h, blk["self_attn.v_proj"])
-            ops.attn_decode(q, k, v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, self.theta, table=self.rope_tab)
+            ops.attn_decode(q, k, v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, self.theta, cur=self.rope_cur)
             x = x + F.linear(self.att, blk["self_attn.o_proj"])
             h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]),
                              blk["mlp.down_proj"])
         ops.gemv_f16w(x.reshape(-1).contiguous(), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x)
+        ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
 
     def _prefill_eager(self, ids):
         F = torch.nn.functional
@@ -377,8 +387,8 @@ class DenseLlama(QuantLlama):
             x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]), blk["mlp.down_proj"])
         last = x[S - 1].contiguous()
         ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
         self.pos.fill_(S)
+        self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
         return self.logits
 
 

@@ -253,16 +253,27 @@ def gemv_f16w(x, W, bias=None, gamma=None, eps=0.0, out=None):
     return y
 
 
-def decode_tail(logits, embed, token, pos, x):
-    """token = argmax(logits), pos += 1, x = embed[token] -- one launch (graph-capturable)"""
+def decode_tail(logits, embed, token, pos, x, table=None, cur=None):
+    """token = argmax(logits), pos += 1, x = embed[token] (and cur = table[pos], the next step's cos/sin row) -- one
+    launch (graph-capturable)"""
     vocab, hidden = embed.shape
     _need(logits, torch.float16, "logits", vocab)
     _need(embed, torch.float16, "embed", vocab * hidden)
     _need(token, torch.int64, "token", 1)
     _need(pos, torch.int32, "pos", 1)
     _need(x, torch.float16, "x", hidden)
+    if cur is not None:
+        _need(cur, torch.float16, "rope_cur", 128)
+        _need(table, torch.float16, "rope table")
     _lib.check(_lib.load().amq_decode_tail_f16(_lib.ptr(logits), vocab, _lib.ptr(embed), hidden, _lib.ptr(token), _lib.ptr(pos),
-                                               _lib.ptr(x), _lib.current_stream()))
+                                               _lib.ptr(x), _lib.ptr(table) if cur is not None else None, _lib.ptr(cur),
+                                               table.numel() // 128 if cur is not None else 0, _lib.current_stream()))
+
+
+def new_step_state(device):
+    """-> (rope_cur fp16 [128], pos int32 [1]): two views of one 260-byte block, the layout amq_attn_decode_cur_f16 reads"""
+    block = torch.zeros(65, dtype=torch.int32, device=device)
+    return block[:64].view(torch.float16), block[64:65]
 
 
 def rope_table(max_seq, rope_theta, device):
@@ -271,9 +282,10 @@ def rope_table(max_seq, rope_theta, device):
     return tab
 
 
-def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_theta=10000.0, table=None):
+def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_theta=10000.0, table=None, cur=None):
     """One new token per sequence.  q [B, n_heads*128], k/v [B, n_kv_heads*128],
-    caches [B, n_kv_heads, max_seq, 128]; ``pos`` is an int or a device int32 tensor."""
+    caches [B, n_kv_heads, max_seq, 128]; ``pos`` is an int or a device int32 tensor.  ``cur``: fp16 [128] cos/sin row
+    of the current position (maintained by decode_tail) -- needs ``pos`` as a device tensor."""
     B = kcache.shape[0]
     max_seq = kcache.shape[2]
     _need(q, torch.float16, "q", B * n_heads * 128)
@@ -289,6 +301,15 @@ def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_the
         pos_dev, pos_i = None, int(pos)
         if not 0 <= pos_i < max_seq:
             raise ValueError(f"pos {pos_i} outside the cache (max_seq={max_seq})")
+    if cur is not None:
+        # step-state block: cos/sin row (256 bytes) immediately followed by the int32 position (new_step_state())
+        _need(cur, torch.float16, "rope_cur", 128)
+        if pos_dev is None or pos.data_ptr() != cur.data_ptr() + 256:
+            raise ValueError("cur / pos must be the two views of one step-state block (ops.new_step_state)")
+        _lib.check(_lib.load().amq_attn_decode_cur_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(kcache), _lib.ptr(vcache),
+                                                       _lib.ptr(out), _lib.ptr(cur), B, n_heads, n_kv_heads, 128, max_seq,
+                                                       _lib.current_stream()))
+        return
     if table is not None:
         _need(table, torch.float16, "rope table", max_seq * 128)
     _lib.check(_lib.load().amq_attn_decode_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(kcache), _lib.ptr(vcache),

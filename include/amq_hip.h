@@ -186,12 +186,22 @@ int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcach
 /* optional: fp16 [max_seq][64][2] (cos, sin) table for amq_attn_decode_f16 (NULL there = computed in-kernel, same values) */
 int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream);
 
+/* Decode attention for graph-replayed token steps.  step_state is a 260-byte device block
+ *     { fp16 cos/sin [64][2] of the CURRENT position ; int32 position at byte offset 256 }
+ * that amq_decode_tail_f16 keeps up to date (pass rope_cur = step_state, pos = step_state + 256 there): position and
+ * rotation inputs are fetched by the kernel's first instructions instead of through the position -> table-row chain of
+ * dependent loads of amq_attn_decode_f16. */
+int amq_attn_decode_cur_f16(const void* q, const void* k, const void* v, void* kcache, void* vcache, void* out,
+                            const void* step_state, int batch, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                            void* stream);
+
 /* End of a greedy token step in one launch: token[0] = argmax(logits[0..vocab)) (first maximum), pos[0] += 1,
- * x[0..hidden) = embed[token][0..hidden).  Replaces the `torch.argmax` / position increment / embedding gather that follow
+ * x[0..hidden) = embed[token][0..hidden); when rope_table / rope_cur are given (both or neither) also
+ * rope_cur[0..128) = rope_table[min(pos, rope_rows - 1)][0..128), the cos/sin row amq_attn_decode_cur_f16 reads in the next step.  Replaces the `torch.argmax` / position increment / embedding gather that follow
  * the lm_head in the reference's generation loop (amq/utils/speed.py:70-76, HF `_sample`) when the step is replayed from
  * a hipGraph.  logits, embed, x: fp16; token: int64; pos: int32; all device pointers. */
 int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
-                        void* stream);
+                        const void* rope_table, void* rope_cur, int rope_rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,13 @@ def test_decode_tail():
         assert int(token.item()) == vocab // 3 == int(torch.argmax(logits.float().cpu()).item())
         assert int(pos.item()) == 42
         assert torch.equal(x[0], embed[vocab // 3])
+        # with the rope hand-off: cur = table row of the NEW position (clamped to the last row)
+        tab = ops.rope_table(44, 10000.0, dev)
+        cur = torch.zeros(128, dtype=torch.float16, device=dev)
+        for expect_row in (43, 43):
+            ops.decode_tail(logits, embed, token, pos, x, table=tab, cur=cur)
+            assert torch.equal(cur, tab.view(44, 128)[expect_row])
+        assert int(pos.item()) == 44
 
 
 def _rope_ref(t, pos):
@@ -124,8 +131,15 @@ def test_attn_decode_long_context(pos):
     v = torch.randn(1, nkv, 128, generator=g).half().to(dev)
     out = torch.zeros(1, nh * 128, dtype=torch.float16, device=dev)
     posd = torch.full((1,), pos, dtype=torch.int32, device=dev)
-    ops.attn_decode(q.reshape(1, -1), k.reshape(1, -1), v.reshape(1, -1), kc, vc, out, posd, nh, nkv,
-                    table=ops.rope_table(max_seq, 10000.0, dev))
+    tab = ops.rope_table(max_seq, 10000.0, dev)
+    ops.attn_decode(q.reshape(1, -1), k.reshape(1, -1), v.reshape(1, -1), kc, vc, out, posd, nh, nkv, table=tab)
+    # the graph-replay form (cos/sin row of the current position handed over by the previous step) gives the same bits
+    kc2, vc2, out2 = kc.clone(), vc.clone(), torch.zeros_like(out)
+    kc2[0, :, pos] = 1000.0
+    cur, pos_state = ops.new_step_state(dev)
+    cur.copy_(tab.view(max_seq, 128)[pos]); pos_state.fill_(pos)
+    ops.attn_decode(q.reshape(1, -1), k.reshape(1, -1), v.reshape(1, -1), kc2, vc2, out2, pos_state, nh, nkv, cur=cur)
+    assert torch.equal(out2, out) and torch.equal(kc2[0, :, pos], kc[0, :, pos])
     kr = _rope_ref(k[0], pos)
     assert torch.equal(kc[0, :, pos], kr) and torch.equal(vc[0, :, pos], v[0])
     K = kc[0, :, :pos + 1].repeat_interleave(nh // nkv, 0)
