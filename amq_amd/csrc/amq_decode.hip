@@ -341,17 +341,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
     ATT_STAMP(1);
     if (tid < 64 && !p_cur && rest.rope_table) cs_tab = ((const h2*)rest.rope_table)[(size_t)pos * 64 + tid];
     const int last_old = pos > 0 ? pos - 1 : 0;      // rows >= pos are never used; clamp keeps every load inside rows already written
+    // rows past the context are not requested at all (wave-uniform skip): every wave-load costs the CU's texture
+    // addresser >= 16 cycles whether or not its lanes point at the same clamped row, and at T ~ 200 half of the 24 loads
+    // per wave were such duplicates (2.2 us from position to barrier, profiles/r01b_attn_stamps.txt)
 #pragma unroll
     for (int i = ATT_SPEC; i < ATT_PF; ++i) {
-        int t = grp + ATT_GROUPS * i;
-        t = t < last_old ? t : last_old;
-        krow[i] = *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
+        if (ATT_GROUPS * i < pos) {
+            int t = grp + ATT_GROUPS * i;
+            t = t < last_old ? t : last_old;
+            krow[i] = *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
+        }
     }
 #pragma unroll
     for (int i = 0; i < ATT_PF; ++i) {
-        int t = grp + ATT_GROUPS * i;
-        t = t < last_old ? t : last_old;
-        vrow[i] = *(const h8*)(vc + (size_t)t * ATT_D + 8 * l16);
+        if (ATT_GROUPS * i < pos) {
+            int t = grp + ATT_GROUPS * i;
+            t = t < last_old ? t : last_old;
+            vrow[i] = *(const h8*)(vc + (size_t)t * ATT_D + 8 * l16);
+        }
     }
     auto rotate_and_append = [&](_Float16 c16, _Float16 s16) {
         const int i = tid;                          // rotary pair (i, i + 64)
@@ -396,9 +403,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
     };
 #pragma unroll
     for (int i = 0; i < ATT_PF; ++i) {
-        const int t = grp + ATT_GROUPS * i;
-        const float sv = score(t == pos ? knew : krow[i]);
-        if (t < T && l16 == 0) sc[t] = sv;
+        if (ATT_GROUPS * i < T) {                   // wave-uniform: iterations wholly past the context never touch their row
+            const int t = grp + ATT_GROUPS * i;
+            const float sv = score(t == pos ? knew : krow[i]);
+            if (t < T && l16 == 0) sc[t] = sv;
+        }
     }
     for (int t = grp + ATT_GROUPS * ATT_PF; t < T; t += ATT_GROUPS) {       // contexts beyond the register prefetch
         const h8 kv = (t == pos) ? knew : *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
 #pragma unroll
     for (int i = 0; i < ATT_PF; ++i) {
         const int t = grp + ATT_GROUPS * i;
-        if (t < T) {
+        if (ATT_GROUPS * i < T && t < T) {
             const _Float16 p16 = (_Float16)(sc[t] * inv);        // softmax(...).to(fp16)
             const h8 vv = (t == pos) ? vnew : vrow[i];
 #pragma unroll
