@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""decode tokens/s (graph replay, batch 1, 64-token prompt) for the model shapes of BASELINE.json's configs 2-5 on ONE GPU:
+uniform 4-bit 7B, avg-3 7B / 13B / 70B (synthetic weights).  usage: decode_models.py [steps]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from amq_amd import arch
+from amq_amd.llama import QuantLlama
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+dev = torch.device("cuda:0")
+cases = [("Llama-2-7b-hf", 4.0, True), ("Llama-2-7b-hf", 3.0, False), ("Llama-2-13b-hf", 3.0, False), ("Llama-2-70b-hf", 3.0, False)]
+for name, bits, uniform in cases:
+    cfg = arch.MODEL_CONFIGS[name]
+    if uniform:
+        a, usage = arch.uniform_arch(cfg, int(bits)), bits + 0.25
+    else:
+        a, usage = arch.synthesize_arch(cfg, bits, seed=0, pinned=arch.PINNED_7B if "7b" in name else ())
+    m = QuantLlama(cfg, a["linear"], device=dev, max_seq=64 + steps + 24, seed=0)
+    ids = torch.randint(0, m.vocab - 1, (64,), generator=torch.Generator().manual_seed(0)).to(dev)
+    m.prefill(ids, use_graph=False)
+    m.capture()
+    for _ in range(16):
+        m.decode_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.decode_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    gb = m.linear_bytes_per_token() / 1e9
+    print(f"{name} bits_usage {usage:.3f}: {1/dt:7.1f} tokens/s  {dt*1e3:.3f} ms/token  linears {gb:.2f} GB/token -> {gb/dt/1e3:.2f} TB/s", flush=True)
+    del m
+    torch.cuda.empty_cache()
