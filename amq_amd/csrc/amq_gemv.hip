@@ -192,20 +192,21 @@ __device__ __forceinline__ void stage_x(const GemvHot& a, _Float16* xl, float* x
 // vector-memory queue: x_issue() runs before the weight ring is primed, x_finish() after it.  vmcnt waits are
 // in issue order, so staging behind the primed weight tiles (the previous arrangement) made every workgroup wait
 // for its first tiles -- 2-4 us under load (profiles/r01b_gemv_stamps.txt) -- before x could be written to LDS.
-constexpr int XC_MAX = 2;            // 16-byte chunks of x per thread held in registers (K <= 16 * threads)
+constexpr int XC_MAX = 4;            // 16-byte chunks of x per thread held in registers at most (K <= 32 * threads)
 struct XRegs { h8 v[XC_MAX]; h8 w[XC_MAX]; };   // w: up (SiLU*mul) or gamma (RMSNorm)
 // chunks actually held: two only in the 16-wave workgroups (one per CU, 128 VGPRs available); the 8-wave ones must
 // stay under 80 VGPRs for three workgroups per CU, and K <= 4096 needs one chunk per thread there
 template <int NW> struct XCfg { static constexpr int XC = NW == 16 ? 2 : 1; };
+// (a third variant, XCH = 4 at 16 waves, covers 16384 < K <= 32768: the 70B down_proj, K = 28672)
 
 // No branches around the loads (indices are clamped instead): the compiler can only emit a COUNTED vmcnt for the
 // later uses when every path between a load and its use issues the same vector-memory operations.
-template <int PRO, int NW>
+template <int PRO, int NW, int XCH>
 __device__ __forceinline__ void x_issue(const GemvHot& a, XRegs& xr) {
     constexpr int THREADS = NW * 64;
     const int last = (a.K >> 3) - 1;
 #pragma unroll
-    for (int i = 0; i < XCfg<NW>::XC; ++i) {
+    for (int i = 0; i < XCH; ++i) {
         int c = (int)threadIdx.x + i * THREADS;
         c = c < last ? c : last;                                  // clamp: every lane loads, tail lanes discard
         xr.v[i] = *(const h8*)((const _Float16*)a.x + 8 * c);
@@ -214,7 +215,7 @@ __device__ __forceinline__ void x_issue(const GemvHot& a, XRegs& xr) {
     }
 }
 
-template <int PRO, int NW>
+template <int PRO, int NW, int XCH>
 __device__ __forceinline__ void x_finish(const GemvHot& a, const XRegs& xr, _Float16* xl, float* red) {
     constexpr int THREADS = NW * 64;
     const int tid = threadIdx.x;
@@ -223,7 +224,7 @@ __device__ __forceinline__ void x_finish(const GemvHot& a, const XRegs& xr, _Flo
     if (PRO == PRO_RMSNORM) {
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < XCfg<NW>::XC; ++i) {
+        for (int i = 0; i < XCH; ++i) {
             if (tid + i * THREADS < chunks) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { float f = (float)xr.v[i][e]; ss += f * f; }
@@ -238,7 +239,7 @@ __device__ __forceinline__ void x_finish(const GemvHot& a, const XRegs& xr, _Flo
         rstd = rsqrtf(tot / (float)a.K + a.eps);
     }
 #pragma unroll
-    for (int i = 0; i < XCfg<NW>::XC; ++i) {
+    for (int i = 0; i < XCH; ++i) {
         const int c = tid + i * THREADS;
         if (c < chunks) {
             h8 r;
@@ -305,7 +306,7 @@ __device__ __forceinline__ void unpack_lane_sub(const uint32_t* w, h2* out) {
 }
 
 // ---------------------------------------------------------------- body
-template <int BITS, int MODE, int PRO, int NW, int U, int MATH>
+template <int BITS, int MODE, int PRO, int NW, int U, int MATH, int XCH>
 __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk, int sidx, const void* qweight, const void* meta_base,
                                           int seg_n_rt, int local, _Float16* lds_x, const _Float16* xl, float* xg,
                                           float* red, int xs, bool fastx, const XRegs& xr) {
@@ -371,7 +372,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     so.y = (_Float16*)blk.y[sidx];
     so.y_stride = blk.y_stride[sidx];
 #ifndef AMQ_ABL_NOSTAGE
-    if (fastx) x_finish<PRO, NW>(a, xr, lds_x, red);
+    if (fastx) x_finish<PRO, NW, XCH>(a, xr, lds_x, red);
     else stage_x<PRO, NW, MATH == MATH_LINEAR>(a, lds_x, xg, red, xs);
 #endif
     __syncthreads();
@@ -600,7 +601,7 @@ struct GemvPre {            // not a kernel parameter type: just names the 14 dw
     int K, m_nseg, rpt, n_rt0, key0; float eps;
 };
 
-template <int PRO, int NW, int U, int MATH>
+template <int PRO, int NW, int U, int MATH, int XCH>
 __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const void* p_x, const void* p_xw, const void* p_qw0,
                                                                      const void* p_mt0, int p_K, int p_m_nseg, int p_rpt,
                                                                      int p_n_rt0, int p_key0, float p_eps, GemvKArgs blk) {
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const v
     a.x = p_x; a.x2 = p_xw; a.gamma = p_xw;
     a.K = p_K; a.M = p_m_nseg & 0xFFFF; a.rpt = p_rpt; a.eps = p_eps;
     const int nseg = p_m_nseg >> 16;
-    const bool slow_x = MATH == MATH_LINEAR || a.M != 1 || (a.K >> 3) > XCfg<NW>::XC * NW * 64;   // generic staging path
+    const bool slow_x = MATH == MATH_LINEAR || a.M != 1 || (a.K >> 3) > XCH * NW * 64;   // generic staging path
     a.x_stride = slow_x ? blk.x_stride : a.K;
     a.lin_mask = MATH == MATH_LINEAR ? blk.lin_mask : 0;
     a.lin_copies = MATH == MATH_LINEAR ? blk.lin_copies : 1;
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const v
     // decode fast path: one activation row whose chunks fit the per-thread registers -> loads leave first
     XRegs xr;
     const bool fastx = !slow_x;
-    if (fastx) x_issue<PRO, NW>(a, xr);
+    if (fastx) x_issue<PRO, NW, XCH>(a, xr);
 
     const _Float16* xuse = xl;
     if (MATH == MATH_LINEAR) {
@@ -670,12 +671,12 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const v
         xuse = xl + (size_t)slot * a.M * xs;
     }
     switch (key) {
-        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
     }
     if (threadIdx.x < 64) AMQ_STAMP_AT(blk, 4);
 #ifdef AMQ_STAMP
@@ -709,9 +710,9 @@ int gemv_pick_waves(int total_rt, int K) {
     return 8;
 }
 
-template <int PRO, int NW, int U, int MATH>
+template <int PRO, int NW, int U, int MATH, int XCH = XCfg<NW>::XC>
 static hipError_t launch_one(const GemvKArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    auto kern = gemv_kernel<PRO, NW, U, MATH>;
+    auto kern = gemv_kernel<PRO, NW, U, MATH, XCH>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -731,6 +732,8 @@ static hipError_t launch_nw(const GemvKArgs& a, int flags, int depth, int total_
         return launch_one<PRO, NW, 2, MATH_LINEAR>(a, total_wg, lds, st);
     }
     if (u == 4) return launch_one<PRO, NW, 4, MATH_EXACT>(a, total_wg, lds, st);
+    if (NW == 16 && a.M == 1 && (a.K >> 3) > XCfg<16>::XC * 1024 && (a.K >> 3) <= 4 * 1024)
+        return launch_one<PRO, 16, 2, MATH_EXACT, 4>(a, total_wg, lds, st);        // 16384 < K <= 32768 (70B down_proj)
     return launch_one<PRO, NW, 2, MATH_EXACT>(a, total_wg, lds, st);
 }
 
