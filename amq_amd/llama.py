@@ -185,7 +185,7 @@ class QuantLlama:
             side.synchronize()
             self.pos.copy_(saved[1]); self.set_token(saved[0])
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 self._step()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
@@ -231,7 +231,7 @@ class QuantLlama:
                 self._prefill_eager(static_ids)            # warm-up outside capture (allocator, lazy init)
                 side.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     self._prefill_eager(static_ids)
             torch.cuda.current_stream(self.dev).wait_stream(side)
             ent = cache[S] = (g, static_ids)

@@ -72,7 +72,7 @@ def gemv_roofline(m, reps=20):
     with torch.cuda.stream(side):
         launches()
         side.synchronize()
-        with torch.cuda.graph(g, stream=side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
             launches()
     torch.cuda.current_stream(dev).wait_stream(side)
     g.replay()
