@@ -143,8 +143,8 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     int bitmask = 0;
     for (int i = 0; i < nseg; ++i) bitmask |= 1 << (segs[i].bits & 7);
-    const int copies = g_opt_math == AMQ_MATH_LINEAR ? __builtin_popcount(bitmask) : 1;
-    if (M > amq::GEMV_MAX_M || amq::gemv_lds_bytes(M, K, copies) > LDS_LIMIT)
+    (void)bitmask;
+    if (M > amq::GEMV_MAX_M || amq::gemv_lds_bytes(M, K, 1) > LDS_LIMIT)
         return fail(AMQ_ESHAPE, "M=%d rows of K=%d do not fit LDS for the GEMV path; use amq_gemm_f16", M, K);
     amq::GemvArgs a{};
     for (int i = 0; i < nseg; ++i) {

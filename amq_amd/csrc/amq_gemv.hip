@@ -21,12 +21,11 @@
 //                 dequant, 12 VALU cycles per weight pair (amq_common.cuh).
 //     MATH_DOT    (A/B only, M == 1): same weights, v_dot2c_f32_f16 + wavefront-shuffle
 //                 reduction instead of MFMA.
-//     MATH_LINEAR (opt-in): the masked field is fed to the MFMA as the fp16 subnormal
-//                 q*2^(sh-24) (gfx950 MFMA honours fp16 subnormals -- measured), x is staged
-//                 pre-scaled by 2^-sh, and scale / zero are applied per group in fp32:
-//                 y += s*(2^24*sum(x'q') - z*sum_g(x)).  2 VALU cycles per pair; results
-//                 are the real-valued dequant (no per-weight fp16 roundings), ~3e-4 of the
-//                 output rms away from the reference's rounded-weight result.
+//     MATH_LINEAR (opt-in): every field is shifted to one mantissa position and fed to the MFMA as the fp16
+//                 subnormal q*2^(SH-24) (gfx950 MFMA honours fp16 subnormals -- measured); scale / zero are applied
+//                 per group in fp32:  y += s*(2^(24-SH)*sum(x q) - z*sum_g(x)), with the group sums of x taken once in
+//                 the staging pass.  4 VALU cycles per pair; results are the real-valued dequant (no per-weight fp16
+//                 roundings), ~3e-4 of the output rms away from the reference's rounded-weight result.
 //   * per row-tile, fixed-order cross-wave sum through double-buffered LDS and one
 //     barrier: deterministic, no atomics.
 //   * several linears that share x (q/k/v, gate/up) with different bit-widths
@@ -45,7 +44,7 @@ constexpr int XPAD = 8;              // halves of padding per staged x row (16 B
 struct GemvKArgs {
     const void* x; const void* x2; const void* gamma;
     int M, K, x_stride, nseg;
-    float eps; int rpt, lin_mask, lin_copies;
+    float eps; int rpt, pad0_, pad1_;
     int wg_begin[GEMV_MAX_SEG];
     int n_rt[GEMV_MAX_SEG];
     int key[GEMV_MAX_SEG];                 // bits * 2 + mode
@@ -68,7 +67,6 @@ struct GemvHot {
     const void* x; const void* x2; const void* gamma;
     int M, K, x_stride, rpt;
     float eps;
-    int lin_mask, lin_copies;
 };
 
 #ifdef AMQ_STAMP
@@ -98,28 +96,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + __expf(-g)); }
 
-// log2 of the pre-scale of x for MATH_LINEAR: field shift of pair P = 4*t + p of a lane (amq_common.cuh layout)
-__device__ __forceinline__ int lin_shift(int bits, int t, int p) {
-    const int P = 4 * t + p;
-    if (bits == 4) return (p & 1) ? 4 : 0;                       // fields 0,4 | (>>8) 0,4
-    if (bits == 2) { const int i = P & 7; return i < 5 ? 2 * i : 2 * (i - 5); }   // 0..8 | (>>10) 0,2,4
-    if (P == 15) return 0;                                       // 3-bit spare-bit pair, assembled at 0
-    const int i = P % 5;
-    return i < 3 ? 3 * i : 3 * (i - 3);                          // 0,3,6 | (>>9) 0,3
-}
-
 // ---------------------------------------------------------------- staging
 // Writes the (transformed) activations into LDS as fp16.
 //   exact / dot : xl[m][xs]
-//   linear      : for every bit-width b in lin_mask a copy xl_b[m][xs] pre-scaled by 2^-shift, and
-//                 xg[G][16] = per-group sums of x per row (fp32; rows >= M are zero)
+//   linear      : the same xl[m][xs] plus xg[G][16] = per-group (128 k) sums of x per row (fp32; rows >= M are zero)
 template <int PRO, int NW, bool LIN>
 __device__ __forceinline__ void stage_x(const GemvHot& a, _Float16* xl, float* xg, float* red, int xs) {
     constexpr int THREADS = NW * 64;
     const int tid = threadIdx.x;
     const int K = a.K;
     const int chunks = K >> 3;      // 8 halves per chunk
-    const size_t copy_stride = (size_t)a.M * xs;
     if (LIN)
         for (int i = tid; i < (K >> 7) * 16; i += THREADS) xg[i] = 0.f;      // (rows written below are disjoint from these only by thread; ordered by the barrier after staging)
     if (LIN) __syncthreads();
@@ -159,25 +145,8 @@ __device__ __forceinline__ void stage_x(const GemvHot& a, _Float16* xl, float* x
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { _Float16 nrm = (_Float16)((float)v[i] * rstd); r[i] = gm[i] * nrm; }
             }
-            if (!LIN) {
-                *(h8*)(lrow + 8 * c) = r;
-            } else {
-                const int t = (c >> 2) & 3;
-                int slot = 0;
-#pragma unroll
-                for (int b = 2; b <= 4; ++b) {
-                    if (a.lin_mask & (1 << b)) {
-                        h8 q;
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) {
-                            const _Float16 sc = (_Float16)(1.0f / (float)(1 << lin_shift(b, t, p)));
-                            q[2 * p] = r[2 * p] * sc;
-                            q[2 * p + 1] = r[2 * p + 1] * sc;
-                        }
-                        *(h8*)(lrow + slot * copy_stride + 8 * c) = q;
-                        ++slot;
-                    }
-                }
+            *(h8*)(lrow + 8 * c) = r;
+            if (LIN) {
                 float cs = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) cs += (float)r[i];
@@ -215,8 +184,8 @@ __device__ __forceinline__ void x_issue(const GemvHot& a, XRegs& xr) {
     }
 }
 
-template <int PRO, int NW, int XCH>
-__device__ __forceinline__ void x_finish(const GemvHot& a, const XRegs& xr, _Float16* xl, float* red) {
+template <int PRO, int NW, int XCH, bool LIN>
+__device__ __forceinline__ void x_finish(const GemvHot& a, const XRegs& xr, _Float16* xl, float* xg, float* red) {
     constexpr int THREADS = NW * 64;
     const int tid = threadIdx.x;
     const int chunks = a.K >> 3;
@@ -241,6 +210,7 @@ __device__ __forceinline__ void x_finish(const GemvHot& a, const XRegs& xr, _Flo
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
         const int c = tid + i * THREADS;
+        float cs = 0.f;
         if (c < chunks) {
             h8 r;
             if (PRO == PRO_NONE) {
@@ -253,6 +223,18 @@ __device__ __forceinline__ void x_finish(const GemvHot& a, const XRegs& xr, _Flo
                 for (int e = 0; e < 8; ++e) { _Float16 nrm = (_Float16)((float)xr.v[i][e] * rstd); r[e] = xr.w[i][e] * nrm; }
             }
             *(h8*)(xl + 8 * c) = r;
+            if (LIN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs += (float)r[e];
+            }
+        }
+        if (LIN) {
+            // 16 chunks = one 128-k group = one 16-lane DPP row (threads per pass are a multiple of 16); row 0 of xg[G][16]
+            cs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cs), 0xB1, 0xF, 0xF, false));
+            cs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cs), 0x4E, 0xF, 0xF, false));
+            cs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cs), 0x141, 0xF, 0xF, false));
+            cs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cs), 0x140, 0xF, 0xF, false));
+            if ((tid & 15) == 0 && c < chunks) xg[(size_t)(c >> 4) * 16] = cs;
         }
     }
     // (the caller's barrier publishes xl; red[] is next written only after that barrier)
@@ -266,42 +248,50 @@ __device__ __forceinline__ void store_out(const SegOut& s, int m, int n, float a
     s.y[(size_t)m * s.y_stride + n] = y;
 }
 
-// and-only unpack for MATH_LINEAR: out[4t+p] = packed fp16 subnormals q * 2^(shift-24)
+// shift+mask unpack for MATH_LINEAR: every pair at ONE mantissa position, out[4t+p] = packed fp16 subnormals q * 2^(SH-24)
+template <int BITS> struct LinCfg;
+template <> struct LinCfg<4> { static constexpr int SH = 6; };
+template <> struct LinCfg<3> { static constexpr int SH = 7; };
+template <> struct LinCfg<2> { static constexpr int SH = 8; };
+
 template <int BITS>
 __device__ __forceinline__ void unpack_lane_sub(const uint32_t* w, h2* out) {
-    if (BITS == 4) {
+    constexpr int SH = LinCfg<BITS>::SH;
+    constexpr uint32_t fm = (1u << BITS) - 1u;
+    constexpr uint32_t msk = (fm << SH) | ((fm << SH) << 16);
+    if (BITS == 4) {            // fields at bits 0,4,8,12 of each half
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const uint32_t u = w[t], v = u >> 8;
-            out[4 * t + 0] = as_h2(u & 0x000F000Fu);
-            out[4 * t + 1] = as_h2(u & 0x00F000F0u);
-            out[4 * t + 2] = as_h2(v & 0x000F000Fu);
-            out[4 * t + 3] = as_h2(v & 0x00F000F0u);
+            const uint32_t u = w[t];
+            out[4 * t + 0] = as_h2((u << 6) & msk);
+            out[4 * t + 1] = as_h2((u << 2) & msk);
+            out[4 * t + 2] = as_h2((u >> 2) & msk);
+            out[4 * t + 3] = as_h2((u >> 6) & msk);
         }
-    } else if (BITS == 2) {
+    } else if (BITS == 2) {     // fields at bits 2i of each half
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-            const uint32_t u = w[d], v = u >> 10;
-            out[8 * d + 0] = as_h2(u & 0x00030003u);
-            out[8 * d + 1] = as_h2(u & 0x000C000Cu);
-            out[8 * d + 2] = as_h2(u & 0x00300030u);
-            out[8 * d + 3] = as_h2(u & 0x00C000C0u);
-            out[8 * d + 4] = as_h2(u & 0x03000300u);
-            out[8 * d + 5] = as_h2(v & 0x00030003u);
-            out[8 * d + 6] = as_h2(v & 0x000C000Cu);
-            out[8 * d + 7] = as_h2(v & 0x00300030u);
+            const uint32_t u = w[d];
+            out[8 * d + 0] = as_h2((u << 8) & msk);
+            out[8 * d + 1] = as_h2((u << 6) & msk);
+            out[8 * d + 2] = as_h2((u << 4) & msk);
+            out[8 * d + 3] = as_h2((u << 2) & msk);
+            out[8 * d + 4] = as_h2(u & msk);
+            out[8 * d + 5] = as_h2((u >> 2) & msk);
+            out[8 * d + 6] = as_h2((u >> 4) & msk);
+            out[8 * d + 7] = as_h2((u >> 6) & msk);
         }
-    } else {
+    } else {                    // fields at bits 3i of each half; pair 15 in bits 15 / 31 of the three dwords
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const uint32_t u = w[d], v = u >> 9;
-            out[5 * d + 0] = as_h2(u & 0x00070007u);
-            out[5 * d + 1] = as_h2(u & 0x00380038u);
-            out[5 * d + 2] = as_h2(u & 0x01C001C0u);
-            out[5 * d + 3] = as_h2(v & 0x00070007u);
-            out[5 * d + 4] = as_h2(v & 0x00380038u);
+            const uint32_t u = w[d];
+            out[5 * d + 0] = as_h2((u << 7) & msk);
+            out[5 * d + 1] = as_h2((u << 4) & msk);
+            out[5 * d + 2] = as_h2((u << 1) & msk);
+            out[5 * d + 3] = as_h2((u >> 2) & msk);
+            out[5 * d + 4] = as_h2((u >> 5) & msk);
         }
-        out[15] = as_h2(((w[0] >> 15) & 0x00010001u) | ((w[1] >> 14) & 0x00020002u) | ((w[2] >> 13) & 0x00040004u));
+        out[15] = as_h2(((w[0] >> 8) & 0x00800080u) | ((w[1] >> 7) & 0x01000100u) | ((w[2] >> 6) & 0x02000200u));
     }
 }
 
@@ -372,7 +362,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     so.y = (_Float16*)blk.y[sidx];
     so.y_stride = blk.y_stride[sidx];
 #ifndef AMQ_ABL_NOSTAGE
-    if (fastx) x_finish<PRO, NW, XCH>(a, xr, lds_x, red);
+    if (fastx) x_finish<PRO, NW, XCH, MATH == MATH_LINEAR>(a, xr, lds_x, xg, red);
     else stage_x<PRO, NW, MATH == MATH_LINEAR>(a, lds_x, xg, red, xs);
 #endif
     __syncthreads();
@@ -470,10 +460,10 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
                 c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, c_, 0, 0, 0);                 \
             }                                                                                    \
             if (MATH == MATH_LINEAR) {                                                           \
-                /* rows m = 4*o + i of this lane's column r: y += s*(2^24*S - z*X_g)  (HQQ) */   \
-                /*                                            y += s*2^24*S + c*X_g    (FMA) */   \
+                /* rows m = 4*o + i of this lane's column r: y += s*(2^(24-SH)*S - z*X_g)  (HQQ) */ \
+                /*                                            y += s*2^(24-SH)*S + c*X_g    (FMA) */ \
                 const float sf = (float)meta[slot].x, zf = (float)meta[slot].y;                  \
-                const float s24 = sf * 16777216.0f;                                              \
+                const float s24 = sf * (float)(1 << (24 - LinCfg<BITS>::SH));                    \
                 const float zx = (MODE == MODE_HQQ) ? -(sf * zf) : zf;                           \
                 const f4 xs4 = *(const f4*)(xg + g_ * 16 + 4 * o);                               \
                 _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                 \
@@ -613,13 +603,11 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const v
     a.x = p_x; a.x2 = p_xw; a.gamma = p_xw;
     a.K = p_K; a.M = p_m_nseg & 0xFFFF; a.rpt = p_rpt; a.eps = p_eps;
     const int nseg = p_m_nseg >> 16;
-    const bool slow_x = MATH == MATH_LINEAR || a.M != 1 || (a.K >> 3) > XCH * NW * 64;   // generic staging path
+    const bool slow_x = a.M != 1 || (a.K >> 3) > XCH * NW * 64;   // generic staging path
     a.x_stride = slow_x ? blk.x_stride : a.K;
-    a.lin_mask = MATH == MATH_LINEAR ? blk.lin_mask : 0;
-    a.lin_copies = MATH == MATH_LINEAR ? blk.lin_copies : 1;
     const int xs = a.K + XPAD;
     _Float16* xl = (_Float16*)smem;
-    const size_t xbytes = ((size_t)a.M * xs * 2 * (MATH == MATH_LINEAR ? a.lin_copies : 1) + 15) & ~(size_t)15;
+    const size_t xbytes = ((size_t)a.M * xs * 2 + 15) & ~(size_t)15;
     float* xg = (float*)(smem + xbytes);                                        // [G][16] (linear math only)
     const size_t xgbytes = (MATH == MATH_LINEAR) ? (size_t)(a.K >> 7) * 64 : 0;
     float* red = (float*)(smem + xbytes + xgbytes);                             // [2][NW][16][16]
@@ -664,12 +652,6 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const v
     if (fastx) x_issue<PRO, NW, XCH>(a, xr);
 
     const _Float16* xuse = xl;
-    if (MATH == MATH_LINEAR) {
-        const int bits = key >> 1;
-        int slot = 0;
-        for (int b = 2; b < bits; ++b) slot += (a.lin_mask >> b) & 1;
-        xuse = xl + (size_t)slot * a.M * xs;
-    }
     switch (key) {
         case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
         case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
@@ -689,8 +671,8 @@ unsigned long long* g_stamp_ptr = nullptr;
 extern "C" int amq_debug_set_stamps(void* p) { g_stamp_ptr = (unsigned long long*)p; return 0; }
 #endif
 
-size_t gemv_lds_bytes(int M, int K, int copies) {
-    const size_t xbytes = (((size_t)M * (K + XPAD) * 2 * copies) + 15) & ~(size_t)15;
+size_t gemv_lds_bytes(int M, int K, int /*copies: one staged x for every math mode*/) {
+    const size_t xbytes = (((size_t)M * (K + XPAD) * 2) + 15) & ~(size_t)15;
     const size_t xg = (size_t)(K >> 7) * 64;
     const size_t red = (size_t)2 * 16 /*max NW*/ * 16 * 16 * 4;
     return xbytes + xg + red;
@@ -766,13 +748,12 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
         mask |= 1 << a.seg[i].bits;
     }
     const bool lin = (a.flags & GEMV_FLAG_LINEAR) && !((a.flags & GEMV_FLAG_DOT) && a.M == 1);
-    a.lin_mask = lin ? mask : 0;
-    a.lin_copies = lin ? __builtin_popcount(mask) : 1;
-    const size_t lds = gemv_lds_bytes(a.M, a.K, a.lin_copies);
+    (void)lin; (void)mask;
+    const size_t lds = gemv_lds_bytes(a.M, a.K, 1);
     GemvKArgs k{};
     k.x = a.x; k.x2 = a.x2; k.gamma = a.gamma;
     k.M = a.M; k.K = a.K; k.x_stride = a.x_stride; k.nseg = a.nseg;
-    k.eps = a.eps; k.rpt = rpt; k.lin_mask = a.lin_mask; k.lin_copies = a.lin_copies;
+    k.eps = a.eps; k.rpt = rpt;
     for (int i = 0; i < a.nseg; ++i) {
         const GemvSeg& s = a.seg[i];
         k.wg_begin[i] = s.wg_begin; k.n_rt[i] = s.n_rt; k.key[i] = s.bits * 2 + s.mode;

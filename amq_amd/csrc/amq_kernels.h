@@ -40,8 +40,6 @@ struct GemvArgs {
     int force_waves;       // 0 = auto, else 4 / 8 / 16 waves per workgroup
     int force_depth;       // 0 = auto, else 2 / 4 tile loads in flight per wave
     int force_rpt;         // 0 = auto, else row-tiles per workgroup
-    int lin_mask;          // linear math: bit b set = a segment with b-bit weights is present (filled by launch_gemv)
-    int lin_copies;        // number of pre-scaled x copies in LDS                          (filled by launch_gemv)
 };
 enum { GEMV_FLAG_DOT = 1, GEMV_FLAG_LINEAR = 2 };
 constexpr int GEMV_MAX_M = 16;
