@@ -16,7 +16,7 @@ AMQ_OK = 0
 MODE_HQQ, MODE_FMA = 0, 1
 PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
-OPT_GEMV_DOT, OPT_GEMV_WAVES, OPT_GEMV_DEPTH, OPT_GEMV_RPT, OPT_GEMV_MATH, OPT_GEMM_NSUB = 1, 2, 3, 4, 5, 6
+OPT_GEMV_DOT, OPT_GEMV_WAVES, OPT_GEMV_DEPTH, OPT_GEMV_RPT, OPT_GEMV_MATH, OPT_GEMM_NSUB, OPT_GEMM_SKINNY_MAX = 1, 2, 3, 4, 5, 6, 7
 MATH_EXACT, MATH_LINEAR = 0, 1
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -56,6 +56,9 @@ SIGNATURES = {
     "amq_rope_table_f16": (_i, [_vp, _i, _f, _vp]),
     "amq_decode_tail_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "amq_attn_decode_cur_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "amq_gemm_res_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "amq_silu_mul_f16": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),
 }
 
@@ -87,7 +90,7 @@ def load():
     _lib = lib
     # A/B knobs from the environment (tools/, bench experiments): AMQ_GEMV_WAVES / _DEPTH / _RPT / _MATH
     for env, opt in (("AMQ_GEMV_WAVES", OPT_GEMV_WAVES), ("AMQ_GEMV_DEPTH", OPT_GEMV_DEPTH), ("AMQ_GEMV_RPT", OPT_GEMV_RPT),
-                     ("AMQ_GEMV_MATH", OPT_GEMV_MATH)):
+                     ("AMQ_GEMV_MATH", OPT_GEMV_MATH), ("AMQ_GEMM_SKINNY_MAX", OPT_GEMM_SKINNY_MAX)):
         if os.environ.get(env):
             check(lib.amq_set_option(opt, int(os.environ[env])))
     return lib

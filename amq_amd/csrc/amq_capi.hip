@@ -68,6 +68,11 @@ int amq_set_option(int option, int value) {
         amq::g_gemm_nsub = value;
         return AMQ_OK;
     }
+    if (option == AMQ_OPT_GEMM_SKINNY_MAX) {
+        if (value < 0 || value > 4096) return fail(AMQ_EINVAL, "skinny-GEMM row limit must be 0..4096");
+        amq::g_gemm_skinny_max = value;
+        return AMQ_OK;
+    }
     if (option == AMQ_OPT_GEMV_RPT) {
         if (value < 0 || value > 64) return fail(AMQ_EINVAL, "row-tiles per workgroup must be 0..64");
         g_opt_rpt = value;
@@ -202,6 +207,39 @@ int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qn, const
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N,
                     (float*)workspace, amq::gemm_pick_splits(M, N, K)};
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream), "gemm_splitk");
+}
+
+int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, const void* residual,
+                     void* y, int M, int N, int K, int group, int x_stride, int y_stride, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (int rc = check_mode(mode)) return rc;
+    if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
+    const size_t need = amq_gemm_splitk_workspace_bytes(M, N, K);
+    const bool split = need != 0 && workspace != nullptr;          // no workspace: single pass
+    if (split && workspace_bytes < need)
+        return fail(AMQ_EINVAL, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N,
+                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K) : 1, residual};
+    return check_hip(amq::launch_gemm(a, (hipStream_t)stream), "gemm_res");
+}
+
+int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
+                       int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int head_dim, int max_seq, void* stream) {
+    if (!q || !k || !v || !kcache || !vcache || !rope_table) return fail(AMQ_EINVAL, "null pointer");
+    if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
+    if (S < 1 || n_heads < 1 || n_kv_heads < 1 || rope_rows < 1) return fail(AMQ_ESHAPE, "bad sizes");
+    if (pos0 < 0 || pos0 + S > max_seq) return fail(AMQ_ESHAPE, "rows %d..%d do not fit the cache (max_seq %d)", pos0, pos0 + S, max_seq);
+    if (S > 65535) return fail(AMQ_ESHAPE, "S=%d exceeds one launch (65535 rows)", S);
+    return check_hip(amq::launch_rope_cache(q, k, v, kcache, vcache, rope_table, rope_rows, pos0, S, n_heads, n_kv_heads, max_seq,
+                                            (hipStream_t)stream), "rope_cache");
+}
+
+int amq_silu_mul_f16(const void* gate, const void* up, void* out, size_t n, void* stream) {
+    if (!gate || !up || !out) return fail(AMQ_EINVAL, "null pointer");
+    if (n == 0 || (n & 7)) return fail(AMQ_ESHAPE, "n must be a positive multiple of 8 (got %zu)", n);
+    return check_hip(amq::launch_silu_mul(gate, up, out, (long)n, (hipStream_t)stream), "silu_mul");
 }
 
 int amq_linear_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,

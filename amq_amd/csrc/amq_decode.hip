@@ -487,6 +487,65 @@ hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st
     return hipGetLastError();
 }
 
+// ---- prefill glue ------------------------------------------------------------------------------------
+// One 64-thread workgroup per (prompt row s, head): query heads are rotated in place, key heads are rotated INTO the
+// cache row pos0 + s, value heads are copied there.  Same fp16 expression and cos/sin table as the decode kernel's
+// rotate_and_append, so a prefilled cache row equals the row a decode step would have appended.
+__global__ __launch_bounds__(64) void rope_cache_kernel(_Float16* q, const _Float16* k, const _Float16* v, _Float16* kc,
+                                                        _Float16* vc, const h2* tab, int rope_rows, int pos0, int nh, int nkv,
+                                                        int max_seq) {
+    const int i = threadIdx.x, hx = blockIdx.x, s = blockIdx.y;
+    const int pos = pos0 + s;
+    const h2 cs = tab[(size_t)(pos < rope_rows ? pos : rope_rows - 1) * 64 + i];
+    const _Float16 c16 = cs.x, s16 = cs.y;
+    if (hx < nh) {
+        _Float16* row = q + ((size_t)s * nh + hx) * ATT_D;
+        const _Float16 a0 = row[i], a1 = row[i + 64];
+        row[i] = a0 * c16 + (-a1) * s16;
+        row[i + 64] = a1 * c16 + a0 * s16;
+    } else {
+        const int h = hx - nh;
+        const _Float16* kr = k + ((size_t)s * nkv + h) * ATT_D;
+        const _Float16* vr = v + ((size_t)s * nkv + h) * ATT_D;
+        const _Float16 a0 = kr[i], a1 = kr[i + 64];
+        const size_t dst = ((size_t)h * max_seq + pos) * ATT_D;
+        kc[dst + i] = a0 * c16 + (-a1) * s16;
+        kc[dst + i + 64] = a1 * c16 + a0 * s16;
+        vc[dst + i] = vr[i];
+        vc[dst + i + 64] = vr[i + 64];
+    }
+}
+
+hipError_t launch_rope_cache(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
+                             int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int max_seq, hipStream_t st) {
+    hipLaunchKernelGGL(rope_cache_kernel, dim3(n_heads + n_kv_heads, S), dim3(64), 0, st, (_Float16*)q, (const _Float16*)k,
+                       (const _Float16*)v, (_Float16*)kcache, (_Float16*)vcache, (const h2*)rope_table, rope_rows, pos0, n_heads,
+                       n_kv_heads, max_seq);
+    return hipGetLastError();
+}
+
+// out = fp16(silu(gate)) * up, 8 elements per thread (the GEMV SiLU prologue's expression, for many-row launches)
+__global__ __launch_bounds__(256) void silu_mul_kernel(const h8* g, const h8* u, h8* o, long n8) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n8) return;
+    const h8 gv = g[idx], uv = u[idx];
+    h8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float gf = (float)gv[e];
+        const _Float16 sg = (_Float16)(gf / (1.0f + __expf(-gf)));
+        r[e] = sg * uv[e];
+    }
+    o[idx] = r;
+}
+
+hipError_t launch_silu_mul(const void* gate, const void* up, void* out, long n, hipStream_t st) {
+    const long n8 = n >> 3;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const h8*)gate, (const h8*)up,
+                       (h8*)out, n8);
+    return hipGetLastError();
+}
+
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st) {
     const size_t lds = 6 * ATT_D + (size_t)a.max_seq * 4;
     if (lds > 64 * 1024) {

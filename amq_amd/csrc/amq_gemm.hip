@@ -138,6 +138,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 
     // epilogue: acc[mb][nb][i] = D[m = mb*16 + 4*o + i][n = nb*16 + r]
     const _Float16* bias = (const _Float16*)a.bias;
+    const _Float16* res = (const _Float16*)a.residual;
     _Float16* y = (_Float16*)a.y;
 #pragma unroll
     for (int mb = 0; mb < MBLK; ++mb)
@@ -153,15 +154,16 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
                     } else {
                         _Float16 v = (_Float16)acc[mb][nb][i];
                         if (bias) v = v + bias[n];
+                        if (res) v = res[(size_t)m * a.y_stride + n] + v;
                         y[(size_t)m * a.y_stride + n] = v;
                     }
                 }
             }
 }
 
-// y[m][n] = fp16(sum over splits, in order) (+ bias): 8 columns per thread
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, const _Float16* bias, _Float16* y, int M, int N,
-                                                           int y_stride, int splits) {
+// y[m][n] = fp16(sum over splits, in order) (+ bias) (+ residual): 8 columns per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, const _Float16* bias, const _Float16* res, _Float16* y,
+                                                           int M, int N, int y_stride, int splits) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int nchunk = N >> 3;
     if (idx >= (long)M * nchunk) return;
@@ -173,19 +175,187 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, con
 #pragma unroll
         for (int e = 0; e < 4; ++e) { acc[e] += lo[e]; acc[4 + e] += hi[e]; }
     }
-    h8 o;
+    h8 o, rv;
+    if (res) rv = *(const h8*)(res + (size_t)m * y_stride + n);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         _Float16 v = (_Float16)acc[e];
         if (bias) v = v + bias[n + e];
+        if (res) v = rv[e] + v;
         o[e] = v;
     }
     *(h8*)(y + (size_t)m * y_stride + n) = o;
 }
 
+// ---- skinny GEMM: 9 .. 16*MB*gridDim.y rows -------------------------------------------------------------
+// A few dozen rows are neither GEMV- nor GEMM-shaped: the packed weights are a few MB (one pass, HBM-trivial) and x
+// (M x K fp16, <= 1 MB) lives in L2, so the launch is bound by latency and by how fast the CUs can pull x fragments.
+// The tiled kernel above needs split-K to occupy the chip at these sizes (4 K steps per workgroup, a barrier and a full
+// load latency each, fp32 partials written and re-read by a second launch: 15 + 4.6 us for 64 x 4096 x 4096).  Here a
+// workgroup owns 16*NSUB output columns for ALL of K, GEMV style: wave w walks K tiles w, w+4, ... with a D-deep
+// register ring (no LDS, no barrier in the loop), the x fragments come straight from L2 in MFMA A-operand layout
+// (lane (r, o): row r, halves 32t + 8o .. +8), each unpacked W tile feeds MB (x NSUB) MFMAs, and the four waves' fp32
+// accumulators are summed through LDS in wave order (deterministic, no workspace).  K tiles past the end are
+// neutralised by a zero (scale, zero) pair instead of a branch, so every vmcnt wait stays a counted one.
+// Measured (MI355X, 3-bit, us per launch, skinny | tiled+split-K): 4096x4096  M=16 7.8|12.2  32 9.8|13.4  64 16.2|15.6;
+// 11008x4096  12.8|20.3  20.3|21.1  42.5|24.0;  4096x11008  15.8|19.4  20.4|19.8  34.2|20.9  -> taken up to 32 rows.
+int g_gemm_skinny_max = 32;      // rows up to which launch_gemm takes this kernel (AMQ_OPT_GEMM_SKINNY_MAX; 0 disables)
+
+template <int BITS, int MB, int NSUB>
+struct SkinnyTile { h8 xr[MB * 4]; LanePayload<BITS> pay[NSUB]; h2 meta[NSUB]; };
+
+template <int BITS, int MODE, int MB, int NSUB, int D>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
+    // per-wave transpose scratch (16*MB rows x 256 B, XOR-swizzled like the tiled kernel's x tiles); reused for the
+    // cross-wave sum after the K loop
+    constexpr int SCR = MB * 16 * 128;             // halves per wave
+    __shared__ __attribute__((aligned(16))) _Float16 scratch[4 * SCR];
+    static_assert(4 * SCR * 2 >= 4 * MB * NSUB * 64 * 16, "accumulator exchange must fit the scratch");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, o = lane >> 4;
+    const int G = a.K >> 7;
+    const int nblk0 = (int)blockIdx.x * NSUB, nblk_last = (a.N >> 4) - 1;
+    const int m_base = (int)blockIdx.y * (16 * MB);
+    const uint32_t* qw = (const uint32_t*)a.qweight;
+    const h2* mt = (const h2*)a.meta;
+    const _Float16* x = (const _Float16*)a.x;
+    _Float16* const my = scratch + wave * SCR;
+
+    // x fragments are fetched row-coalesced (instruction j: rows 4j .. 4j+3, 256 contiguous bytes each; lane l holds
+    // row 4j + (l >> 4), 16-byte chunk l & 15) and turned into MFMA A operands through the wave's scratch: fetching them
+    // directly in operand layout (16 rows x 64 B per instruction) ran at ~12 B/clk per CU
+    int xoff[MB * 4];
+#pragma unroll
+    for (int j = 0; j < MB * 4; ++j) {
+        int m = m_base + 4 * j + o;
+        m = m < a.M ? m : a.M - 1;                 // rows past M: computed, never stored
+        xoff[j] = m * a.x_stride + r * 8;
+    }
+    size_t tile0[NSUB];
+#pragma unroll
+    for (int nb = 0; nb < NSUB; ++nb) tile0[nb] = (size_t)min(nblk0 + nb, nblk_last) * G;
+
+    f4 acc[MB][NSUB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NSUB; ++nb) acc[mb][nb] = (f4){0, 0, 0, 0};
+
+    SkinnyTile<BITS, MB, NSUB> ring[D];
+    auto load = [&](SkinnyTile<BITS, MB, NSUB>& T, int kt) {
+        const bool valid = kt < G;
+        const int ktc = valid ? kt : G - 1;
+#pragma unroll
+        for (int nb = 0; nb < NSUB; ++nb) {
+            const size_t tile = tile0[nb] + ktc;
+            const uint32_t* p = qw + tile * 64 * BITS + lane * BITS;
+#pragma unroll
+            for (int d = 0; d < BITS; ++d) T.pay[nb].w[d] = p[d];
+            const h2 mv = mt[tile * 16 + r];
+            T.meta[nb] = valid ? mv : (h2){(_Float16)0.f, (_Float16)0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < MB * 4; ++j) T.xr[j] = *(const h8*)(x + (size_t)xoff[j] + ktc * 128);
+    };
+    auto compute = [&](const SkinnyTile<BITS, MB, NSUB>& T) {
+        h2 wv[NSUB][16];
+#pragma unroll
+        for (int nb = 0; nb < NSUB; ++nb) dequant_lane_sd<BITS, MODE>(T.pay[nb].w, T.meta[nb], wv[nb]);
+#pragma unroll
+        for (int j = 0; j < MB * 4; ++j) {
+            const int row = 4 * j + o;
+            *(h8*)(my + row * 128 + ((r ^ (row & 15)) << 3)) = T.xr[j];
+        }
+        __builtin_amdgcn_wave_barrier();           // same wave writes and reads: the LDS pipe keeps the order
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            h8 b[NSUB];
+#pragma unroll
+            for (int nb = 0; nb < NSUB; ++nb)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { b[nb][2 * p] = wv[nb][4 * t + p].x; b[nb][2 * p + 1] = wv[nb][4 * t + p].y; }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const h8 av = *(const h8*)(my + (mb * 16 + r) * 128 + (((4 * t + o) ^ r) << 3));
+#pragma unroll
+                for (int nb = 0; nb < NSUB; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b[nb], acc[mb][nb], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(ring[d], wave + 4 * d);
+    const int nt = (G + 3) >> 2;                   // K tiles of wave 0 (the other waves' extra tile is neutralised)
+    for (int j = 0; j < nt; j += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            compute(ring[d]);                      // tiles j + d >= nt carry zero meta
+            load(ring[d], wave + 4 * (j + d + D));
+        }
+    }
+
+    // cross-wave sum in wave order, then wave w finishes (mb, nb) pairs w, w + 4, ...
+    __syncthreads();                               // every wave is done with its transpose scratch
+    f4* const part = (f4*)scratch;                 // [4 waves][MB * NSUB][64 lanes]
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NSUB; ++nb) part[(wave * (MB * NSUB) + mb * NSUB + nb) * 64 + lane] = acc[mb][nb];
+    __syncthreads();
+    const _Float16* bias = (const _Float16*)a.bias;
+    const _Float16* res = (const _Float16*)a.residual;
+    _Float16* y = (_Float16*)a.y;
+    for (int idx = wave; idx < MB * NSUB; idx += 4) {
+        const int mb = idx / NSUB, nb = idx % NSUB;
+        f4 s = part[idx * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f4 p = part[(w * (MB * NSUB) + idx) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] += p[i];
+        }
+        const int n = (nblk0 + nb) * 16 + r;
+        if (nblk0 + nb > nblk_last) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_base + mb * 16 + 4 * o + i;
+            if (m < a.M) {
+                _Float16 v = (_Float16)s[i];
+                if (bias) v = v + bias[n];
+                if (res) v = res[(size_t)m * a.y_stride + n] + v;
+                y[(size_t)m * a.y_stride + n] = v;
+            }
+        }
+    }
+}
+
+template <int BITS, int MODE, int MB>
+static hipError_t skinny_launch_mb(const GemmArgs& a, hipStream_t st) {
+    const int nblk = a.N >> 4;
+    const int ny = (a.M + 16 * MB - 1) / (16 * MB);
+    // two column blocks per workgroup once one block each would be several rounds of workgroups per CU
+    if ((long)nblk * ny >= 1024 && MB <= 4)
+        hipLaunchKernelGGL((gemm_skinny_kernel<BITS, MODE, MB, 2, 2>), dim3((nblk + 1) / 2, ny), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((gemm_skinny_kernel<BITS, MODE, MB, 1, 3>), dim3(nblk, ny), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int BITS, int MODE>
+static hipError_t skinny_launch(const GemmArgs& a, hipStream_t st) {
+    if (a.M <= 16) return skinny_launch_mb<BITS, MODE, 1>(a, st);
+    if (a.M <= 32) return skinny_launch_mb<BITS, MODE, 2>(a, st);
+    return skinny_launch_mb<BITS, MODE, 4>(a, st);
+}
+
+static bool gemm_is_skinny(int M) { return M <= g_gemm_skinny_max; }
+
 int gemm_pick_splits(int M, int N, int K) {
     const long wg = (long)((M + 63) / 64) * ((N + 127) / 128);      // 64-row tiles (what such launches use)
     const int G = K >> 7;
+    if (gemm_is_skinny(M)) return 1;                                 // gemm_skinny_kernel: no partials
     if (wg >= 192 || G < 4 || (N & 7)) return 1;
     int s = (int)((256 + wg - 1) / wg);
     if (s > 8) s = 8;
@@ -210,7 +380,7 @@ static hipError_t gemm_launch_cfg(const GemmArgs& a, hipStream_t st) {
     if (e != hipSuccess || a.splits <= 1) return e;
     const long items = (long)a.M * (a.N >> 3);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (const float*)a.ws,
-                       (const _Float16*)a.bias, (_Float16*)a.y, a.M, a.N, a.y_stride, a.splits);
+                       (const _Float16*)a.bias, (const _Float16*)a.residual, (_Float16*)a.y, a.M, a.N, a.y_stride, a.splits);
     return hipGetLastError();
 }
 
@@ -227,6 +397,16 @@ static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st) {
+    if (gemm_is_skinny(a.M)) {
+        if (a.mode == MODE_HQQ) {
+            if (a.bits == 4) return skinny_launch<4, MODE_HQQ>(a, st);
+            if (a.bits == 3) return skinny_launch<3, MODE_HQQ>(a, st);
+            return skinny_launch<2, MODE_HQQ>(a, st);
+        }
+        if (a.bits == 4) return skinny_launch<4, MODE_FMA>(a, st);
+        if (a.bits == 3) return skinny_launch<3, MODE_FMA>(a, st);
+        return skinny_launch<2, MODE_FMA>(a, st);
+    }
     if (a.mode == MODE_HQQ) {
         if (a.bits == 4) return gemm_launch_bm<4, MODE_HQQ>(a, st);
         if (a.bits == 3) return gemm_launch_bm<3, MODE_HQQ>(a, st);

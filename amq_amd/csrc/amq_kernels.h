@@ -53,10 +53,12 @@ struct GemmArgs {
     int M, N, K, bits, mode, x_stride, y_stride;
     float* ws;      // split-K partials [splits][M][N] fp32 (or null)
     int splits;     // >= 1
+    const void* residual;   // fp16 [M, y_stride] added to the rounded result (y = residual + fp16(acc (+ bias))), or null
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st);
 int gemm_pick_splits(int M, int N, int K);
 extern int g_gemm_nsub;
+extern int g_gemm_skinny_max;
 
 // decode-step surroundings (amq_decode.hip)
 struct AttnArgs {
@@ -77,6 +79,10 @@ struct AttnArgs {
 hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st);
 hipError_t launch_rmsnorm(const void* x, const void* gamma, void* y, int M, int K, float eps, hipStream_t st);
+// prefill glue (amq_decode.hip)
+hipError_t launch_rope_cache(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
+                             int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int max_seq, hipStream_t st);
+hipError_t launch_silu_mul(const void* gate, const void* up, void* out, long n, hipStream_t st);
 hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, int hidden, void* token, void* pos, void* x,
                               const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st);
 hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,

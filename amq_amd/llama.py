@@ -241,6 +241,53 @@ class QuantLlama:
         return self.logits
 
     def _prefill_eager(self, ids):
+        """Many-row pass over the prompt: per block 2 RMSNorm + 7 GEMMs (residuals fused into the o_proj / down_proj
+        epilogues) + one RoPE-and-cache-write launch + causal attention (library SDPA reading K/V straight from the
+        cache) + one SiLU*up launch."""
+        S = ids.numel()
+        if S > self.max_seq:
+            raise ValueError("prompt longer than the KV cache")
+        H, nh, nkv = self.H, self.nh, self.nkv
+        x = self.embed.index_select(0, ids.to(self.dev))           # [S, H]; the residual stream, updated in place
+
+        def lin(l, inp, residual=None):
+            if S > 8:
+                return ops.gemm(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, residual=residual, out=residual)
+            y = ops.linear(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K)
+            return y if residual is None else residual.add_(y)
+
+        for blk in self.blocks:
+            h = ops.rmsnorm(x, blk["ln1"], self.eps)
+            q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
+            ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, 0, nh, nkv)
+            x = lin(blk["self_attn.o_proj"], self._prefill_attention(q, blk, S), residual=x)
+            h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
+            g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
+            x = lin(blk["mlp.down_proj"], ops.silu_mul(g, u, out=g), residual=x)
+        return self._prefill_finish(x, S)
+
+    def _prefill_attention(self, q, blk, S):
+        # q: [S, nh*128] rotated; K/V: the cache rows just written
+        nh, nkv = self.nh, self.nkv
+        qh = q.view(S, nh, 128).transpose(0, 1)
+        kh, vh = blk["kc"][0, :, :S], blk["vc"][0, :, :S]
+        if nkv != nh:
+            kh = kh.repeat_interleave(nh // nkv, dim=0)
+            vh = vh.repeat_interleave(nh // nkv, dim=0)
+        a = torch.nn.functional.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
+        return a.transpose(0, 1).reshape(S, self.H).contiguous()
+
+    def _prefill_finish(self, x, S):
+        last = x[S - 1].contiguous()
+        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
+        self.pos.fill_(S)
+        self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
+        return self.logits
+
+    def _prefill_unfused(self, ids):
+        """The same pass with framework ops for everything but the linears and RMSNorm (HF-style RoPE in fp32 -> fp16,
+        separate cache copies, residual adds, SiLU and product): kept as the comparison point of the fused pass
+        (tests/test_gpu_decode.py)."""
         S = ids.numel()
         if S > self.max_seq:
             raise ValueError("prompt longer than the KV cache")
@@ -259,21 +306,11 @@ class QuantLlama:
             q, k = self._rope(q, positions), self._rope(k, positions)
             blk["kc"][0, :, :S] = k.transpose(0, 1)
             blk["vc"][0, :, :S] = v.transpose(0, 1)
-            qh, kh, vh = q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1)
-            if nkv != nh:
-                kh = kh.repeat_interleave(nh // nkv, dim=0)
-                vh = vh.repeat_interleave(nh // nkv, dim=0)
-            a = torch.nn.functional.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
-            a = a.transpose(0, 1).reshape(S, H).contiguous()
-            x = x + lin(blk["self_attn.o_proj"], a)
+            x = x + lin(blk["self_attn.o_proj"], self._prefill_attention(q.reshape(S, nh * 128), blk, S))
             h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
             x = x + lin(blk["mlp.down_proj"], torch.nn.functional.silu(g) * u)
-        last = x[S - 1].contiguous()
-        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        self.pos.fill_(S)
-        self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
-        return self.logits
+        return self._prefill_finish(x, S)
 
     def reset(self):
         self.pos.zero_()
@@ -365,31 +402,17 @@ class DenseLlama(QuantLlama):
         S = ids.numel()
         if S > self.max_seq:
             raise ValueError("prompt longer than the KV cache")
-        H, nh, nkv = self.H, self.nh, self.nkv
+        nh, nkv = self.nh, self.nkv
         x = self.embed.index_select(0, ids.to(self.dev))
-        positions = torch.arange(S, device=self.dev)
         for blk in self.blocks:
             h = ops.rmsnorm(x, blk["ln1"], self.eps)
-            q = F.linear(h, blk["self_attn.q_proj"]).view(S, nh, 128)
-            k = F.linear(h, blk["self_attn.k_proj"]).view(S, nkv, 128)
-            v = F.linear(h, blk["self_attn.v_proj"]).view(S, nkv, 128)
-            q, k = self._rope(q, positions), self._rope(k, positions)
-            blk["kc"][0, :, :S] = k.transpose(0, 1)
-            blk["vc"][0, :, :S] = v.transpose(0, 1)
-            qh, kh, vh = q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1)
-            if nkv != nh:
-                kh = kh.repeat_interleave(nh // nkv, dim=0)
-                vh = vh.repeat_interleave(nh // nkv, dim=0)
-            a = F.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
-            a = a.transpose(0, 1).reshape(S, H).contiguous()
-            x = x + F.linear(a, blk["self_attn.o_proj"])
+            q, k, v = F.linear(h, blk["self_attn.q_proj"]), F.linear(h, blk["self_attn.k_proj"]), F.linear(h, blk["self_attn.v_proj"])
+            ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, 0, nh, nkv)
+            x = torch.addmm(x, self._prefill_attention(q, blk, S), blk["self_attn.o_proj"].t())
             h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
-            x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]), blk["mlp.down_proj"])
-        last = x[S - 1].contiguous()
-        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        self.pos.fill_(S)
-        self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
-        return self.logits
+            g, u = F.linear(h2, blk["mlp.gate_proj"]), F.linear(h2, blk["mlp.up_proj"])
+            x = torch.addmm(x, ops.silu_mul(g, u, out=g), blk["mlp.down_proj"].t())
+        return self._prefill_finish(x, S)
 
 
 def get_memory_footprint(model):

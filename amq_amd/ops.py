@@ -155,25 +155,25 @@ def _splitk_workspace(device, nbytes):
     return ws
 
 
-def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None):
-    """y = x . W^T for any number of rows (MFMA tiles; split-K when few rows would leave the chip idle)."""
+def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None):
+    """y = x . W^T for any number of rows (MFMA tiles; split-K when few rows would leave the chip idle).
+    ``residual`` (fp16 [M, N], may be ``out``) is added in the epilogue: y = residual + fp16(x . W^T (+ bias))."""
     _check_shape(bits, N, K)
     _check_native(qn, mn, bits, N, K)
     x2 = _prep_x(x, K)
     M = x2.shape[0]
     if bias is not None:
         _need(bias, torch.float16, "bias", N)
+    if residual is not None:
+        _need(residual, torch.float16, "residual", M * N)
     y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=x.device)
     _need(y, torch.float16, "y", M * N)
     lib = _lib.load()
     need = lib.amq_gemm_splitk_workspace_bytes(M, N, K)
-    if need:
-        ws = _splitk_workspace(x.device, need)
-        _lib.check(lib.amq_gemm_splitk_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias), _lib.ptr(y),
-                                           M, N, K, GROUP, 0, 0, _lib.ptr(ws), ws.numel() * 4, _lib.current_stream()))
-    else:
-        _lib.check(lib.amq_gemm_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
-                                    _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.current_stream()))
+    ws = _splitk_workspace(x.device, need) if need else None
+    _lib.check(lib.amq_gemm_res_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias), _lib.ptr(residual),
+                                    _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.ptr(ws), ws.numel() * 4 if need else 0,
+                                    _lib.current_stream()))
     return y.reshape(*x.shape[:-1], N)
 
 
@@ -268,6 +268,33 @@ def decode_tail(logits, embed, token, pos, x, table=None, cur=None):
     _lib.check(_lib.load().amq_decode_tail_f16(_lib.ptr(logits), vocab, _lib.ptr(embed), hidden, _lib.ptr(token), _lib.ptr(pos),
                                                _lib.ptr(x), _lib.ptr(table) if cur is not None else None, _lib.ptr(cur),
                                                table.numel() // 128 if cur is not None else 0, _lib.current_stream()))
+
+
+def rope_cache(q, k, v, kcache, vcache, table, pos0, n_heads, n_kv_heads):
+    """Prefill glue for ONE sequence: rotate q [S, n_heads*128] in place, rotate k [S, n_kv_heads*128] into
+    kcache[h, pos0+s], copy v into vcache (both [n_kv_heads, max_seq, 128]); ``table`` from :func:`rope_table`."""
+    S = q.shape[0]
+    _need(q, torch.float16, "q", S * n_heads * 128)
+    _need(k, torch.float16, "k", S * n_kv_heads * 128)
+    _need(v, torch.float16, "v", S * n_kv_heads * 128)
+    if kcache.dim() != 3 or kcache.shape[0] != n_kv_heads or kcache.shape[2] != 128 or vcache.shape != kcache.shape:
+        raise ValueError("caches must be [n_kv_heads, max_seq, 128]")
+    _need(kcache, torch.float16, "kcache")
+    _need(vcache, torch.float16, "vcache")
+    _need(table, torch.float16, "rope table")
+    _lib.check(_lib.load().amq_rope_cache_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(kcache), _lib.ptr(vcache),
+                                              _lib.ptr(table), table.numel() // 128, int(pos0), S, n_heads, n_kv_heads, 128,
+                                              kcache.shape[1], _lib.current_stream()))
+
+
+def silu_mul(gate, up, out=None):
+    """fp16(silu(gate)) * up (LlamaMLP activation), the same expression as the GEMV SiLU prologue."""
+    _need(gate, torch.float16, "gate")
+    _need(up, torch.float16, "up", gate.numel())
+    y = out if out is not None else torch.empty_like(gate)
+    _need(y, torch.float16, "out", gate.numel())
+    _lib.check(_lib.load().amq_silu_mul_f16(_lib.ptr(gate), _lib.ptr(up), _lib.ptr(y), gate.numel(), _lib.current_stream()))
+    return y
 
 
 def new_step_state(device):

@@ -64,6 +64,7 @@ const char* amq_last_error(void);
 #define AMQ_OPT_GEMV_RPT   4       /* row-tiles walked by one GEMV workgroup: 0 = auto (default), 1..64 */
 #define AMQ_OPT_GEMV_MATH  5       /* AMQ_MATH_EXACT (default) or AMQ_MATH_LINEAR */
 #define AMQ_OPT_GEMM_NSUB  6       /* 16-column sub-tiles per GEMM wave: 0 = auto (default), 2 or 4 */
+#define AMQ_OPT_GEMM_SKINNY_MAX 7  /* rows up to which GEMMs run the barrier-free K-split-by-wave kernel (default 32; 0 = never) */
 /* GEMV arithmetic.  EXACT reproduces the reference's dequantized fp16 weights (two fp16 roundings per
  * weight) and accumulates x*w in fp32.  LINEAR skips the per-weight roundings: y = sum_g s_g*(sum_k x_k q_k
  * - z_g sum_k x_k) in fp32 (scale / zero applied once per 128-group) -- the real-valued dequant; it is
@@ -202,6 +203,25 @@ int amq_attn_decode_cur_f16(const void* q, const void* k, const void* v, void* k
  * a hipGraph.  logits, embed, x: fp16; token: int64; pos: int32; all device pointers. */
 int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
                         const void* rope_table, void* rope_cur, int rope_rows, void* stream);
+
+/* ---- many-row (prefill) glue --------------------------------------------------------------------------
+ * The reference runs these steps as framework ops between the linears of a HF Llama block
+ * (transformers LlamaAttention / LlamaMLP / LlamaDecoderLayer as driven by amq/utils/speed.py:150-200); on this path
+ * they are ~20 tiny launches per block, so they are offered fused. */
+
+/* amq_gemm_splitk_f16 plus a fused residual: y = residual + fp16(x . W^T (+ bias)); residual fp16 [M, y_stride] or
+ * NULL, may alias y.  workspace NULL = single pass (no split-K). */
+int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
+                     const void* bias, const void* residual, void* y, int M, int N, int K, int group, int x_stride,
+                     int y_stride, void* workspace, size_t workspace_bytes, void* stream);
+/* RoPE + KV-cache write for S new rows at positions pos0 .. pos0+S-1 of ONE sequence: q fp16 [S, n_heads*128] is
+ * rotated in place; k [S, n_kv_heads*128] is rotated into kcache[h][pos0+s][:], v copied into vcache (both
+ * [n_kv_heads, max_seq, 128]); rope_table from amq_rope_table_f16 (rows past rope_rows-1 clamp).  Same numerics as the
+ * rotation inside amq_attn_decode_f16. */
+int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
+                       int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int head_dim, int max_seq, void* stream);
+/* out = fp16(silu(gate)) * up elementwise, n fp16 elements (n % 8 == 0): the LlamaMLP activation between up/gate and down */
+int amq_silu_mul_f16(const void* gate, const void* up, void* out, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

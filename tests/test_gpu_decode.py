@@ -218,6 +218,75 @@ def test_token_step_runner_matches_dense_reference(gqa):
         assert int(m.pos.item()) == seq.numel()
 
 
+@pytest.mark.parametrize("gqa,S", [(False, 12), (True, 40), (False, 5)])
+def test_fused_prefill_matches_framework_glue(gqa, S):
+    """The fused many-row pass (RoPE + cache write, SiLU*up, residual epilogues) against the same pass with framework
+    ops for the glue: same next token, logits and KV cache within fp16 rounding of the differently-ordered roundings."""
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 2 if gqa else 4, 1, vocab=1024))
+    m = QuantLlama(cfg, None, device="cuda:0", max_seq=64, seed=2)
+    ids = torch.randint(0, 1024, (S,), generator=torch.Generator().manual_seed(S)).to(_dev())
+    a = m._prefill_unfused(ids).clone()
+    tok_a = int(m.token.item())
+    kc_a = [b["kc"].clone() for b in m.blocks]
+    vc_a = [b["vc"].clone() for b in m.blocks]
+    for b in m.blocks:
+        b["kc"].zero_()
+        b["vc"].zero_()
+    m.reset()
+    f = m.prefill(ids, use_graph=False).clone()
+    scale = a.float().abs().max()
+    assert (f.float() - a.float()).abs().max() <= 1e-2 * scale
+    assert int(m.token.item()) == tok_a and int(m.pos.item()) == S
+    for blk, ka, va in zip(m.blocks, kc_a, vc_a):
+        assert torch.equal(blk["kc"][0, :, S:], ka[0, :, S:])                       # rows past the prompt untouched
+        assert (blk["kc"].float() - ka.float()).abs().max() <= 1e-2 * ka.float().abs().max()
+        assert (blk["vc"].float() - va.float()).abs().max() <= 1e-2 * va.float().abs().max()
+    g = m.prefill(ids, use_graph=True).clone()                                      # captured replay = eager launches
+    assert torch.equal(g, f)
+
+
+def test_rope_cache_matches_decode_append():
+    """amq_rope_cache_f16 writes exactly the cache rows the decode kernel appends for the same k / v, and rotates q
+    like HF apply_rotary_pos_emb on fp16 tensors."""
+    from amq_amd import ops, _lib
+    dev = _dev()
+    nh, nkv, S, max_seq = 4, 2, 9, 32
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(S, nh * 128, generator=g).half().to(dev)
+    k = torch.randn(S, nkv * 128, generator=g).half().to(dev)
+    v = torch.randn(S, nkv * 128, generator=g).half().to(dev)
+    tab = ops.rope_table(max_seq, 10000.0, dev)
+    kc = torch.zeros(nkv, max_seq, 128, dtype=torch.float16, device=dev)
+    vc = torch.zeros_like(kc)
+    q_rot = q.clone()
+    ops.rope_cache(q_rot, k, v, kc, vc, tab, 3, nh, nkv)                             # rows 3 .. 11
+    kc2 = torch.zeros(1, nkv, max_seq, 128, dtype=torch.float16, device=dev)
+    vc2 = torch.zeros_like(kc2)
+    out = torch.empty(1, nh * 128, dtype=torch.float16, device=dev)
+    for s in range(S):
+        pos = torch.tensor([3 + s], dtype=torch.int32, device=dev)
+        ops.attn_decode(q[s:s + 1], k[s:s + 1], v[s:s + 1], kc2, vc2, out, pos, nh, nkv, 10000.0, table=tab)
+    assert torch.equal(kc, kc2[0]) and torch.equal(vc, vc2[0])
+    assert torch.equal(kc[:, :3], torch.zeros_like(kc[:, :3])) and torch.equal(kc[:, 12:], torch.zeros_like(kc[:, 12:]))
+    ref = torch.stack([_rope_ref(q[s].view(nh, 128), 3 + s) for s in range(S)]).reshape(S, nh * 128)
+    assert torch.equal(q_rot, ref)                                                   # HF apply_rotary_pos_emb in fp16
+    with pytest.raises(_lib.AmqError):
+        ops.rope_cache(q_rot, k, v, kc, vc, tab, max_seq - 2, nh, nkv)               # rows would run past the cache
+
+
+def test_silu_mul():
+    from amq_amd import ops, _lib
+    g = torch.randn(7, 1384, generator=torch.Generator().manual_seed(1)).mul(3).half().to(_dev())
+    u = torch.randn(7, 1384, generator=torch.Generator().manual_seed(2)).half().to(_dev())
+    y = ops.silu_mul(g, u)
+    ref = torch.nn.functional.silu(g) * u
+    assert torch.allclose(y.float(), ref.float(), rtol=2e-3, atol=1e-4)
+    with pytest.raises(_lib.AmqError):
+        ops.silu_mul(g[:, :1383].contiguous(), u[:, :1383].contiguous())
+
+
 def test_generate_is_deterministic_and_graph_equals_eager():
     from amq_amd import arch
     from amq_amd.llama import QuantLlama

@@ -337,7 +337,7 @@ def test_error_paths_raise():
 
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
-@pytest.mark.parametrize("m,n,k", [(17, 256, 1024), (64, 512, 4096), (100, 1280, 2048), (64, 4096, 11008)])
+@pytest.mark.parametrize("m,n,k", [(80, 256, 1024), (128, 512, 4096), (100, 1280, 2048), (96, 4096, 11008)])
 def test_gemm_splitk_matches_single_pass(bits, m, n, k):
     """few-row GEMMs take the split-K path (fp32 partial slices + ordered reduce): same result as the dequantized-weight
     matmul, deterministic, and the C entry point rejects a short workspace"""
@@ -365,3 +365,56 @@ def test_gemm_splitk_matches_single_pass(bits, m, n, k):
     rc = lib.amq_gemm_splitk_f16(bits, ops.MODE_HQQ, _lib.ptr(x), _lib.ptr(qn), _lib.ptr(mn), None, _lib.ptr(y), m, n, k, 128, 0, 0,
                                  _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
     assert rc != 0 and b"workspace" in lib.amq_last_error()
+
+
+@pytest.mark.parametrize("bits,m,n,k", [(3, 64, 4096, 4096), (4, 24, 1024, 512), (2, 300, 1536, 1024)])
+def test_gemm_residual_epilogue(bits, m, n, k):
+    """y = residual + fp16(x . W^T + bias) fused into the GEMM / split-K reduce epilogue is bit-identical to the
+    separate add (same two roundings), also when the residual buffer is the output buffer"""
+    from amq_amd import ops
+    from amq_amd.hqq_format import random_hqq
+    dev = torch.device("cuda:0")
+    h = random_hqq(n, k, bits, seed=7 * bits + m).to(dev)
+    qn, mn = ops.repack_from_hqq(h.W_q, h.scale.reshape(-1), h.zero.reshape(-1), bits, n, k)
+    gen = torch.Generator(device=dev).manual_seed(m + n)
+    x = torch.randn(m, k, device=dev, generator=gen).half()
+    bias = torch.randn(n, device=dev, generator=gen).half()
+    res = torch.randn(m, n, device=dev, generator=gen).half()
+    plain = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias)
+    fused = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=res)
+    assert torch.equal(fused, res + plain)
+    inplace = res.clone()
+    ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=inplace, out=inplace)
+    assert torch.equal(inplace, fused)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("m,n,k", [(9, 48, 128), (16, 256, 384), (17, 1040, 1024), (33, 512, 4096), (64, 4096, 4096),
+                                   (50, 11008, 4096), (64, 4096, 11008), (40, 16400, 256)])
+def test_gemm_skinny(bits, m, n, k):
+    """few-row GEMMs (9..32 rows by default; 64 forced here) run the barrier-free kernel (waves split K, register ring, cross-wave sum in LDS): checked against the
+    oracle linear on the reference's dequantized weights, against the tiled kernel (same fp16 weights, different fp32
+    summation order), for determinism, and with bias + residual; K tiles < 4 waves, ragged column-block pairs."""
+    from amq_amd import _lib, ops
+    h, qn, mn, w_ref = _random_case(bits, n, k, seed=17 * bits + m, bias=True)
+    dev = _dev()
+    gen = torch.Generator().manual_seed(n + k + m)
+    x = torch.randn(m, k, generator=gen).to(torch.float16)
+    res = torch.randn(m, n, generator=gen).to(torch.float16)
+    bias = h.bias.to(dev)
+    lib = _lib.load()
+    _lib.check(lib.amq_set_option(_lib.OPT_GEMM_SKINNY_MAX, 64))         # default limit is 32 rows; cover the 4-block variant too
+    try:
+        assert lib.amq_gemm_splitk_workspace_bytes(m, n, k) == 0
+        y = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias)
+        _assert_close(y.cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref, h.bias.numpy()), f"skinny {bits}b {n}x{k} M={m}")
+        assert torch.equal(ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias), y)
+        yr = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=res.to(dev))
+        assert torch.equal(yr, res.to(dev) + y)
+        _lib.check(lib.amq_set_option(_lib.OPT_GEMM_SKINNY_MAX, 0))
+        tiled = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias)
+    finally:
+        _lib.check(lib.amq_set_option(_lib.OPT_GEMM_SKINNY_MAX, 32))
+    ref = x.to(dev).float() @ ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).float().t()
+    tol = 2.0 ** -9 * ref.abs() + 2.0 ** -9 * y.float().abs() + 1e-3 * ref.pow(2).mean().sqrt()
+    assert torch.all((y.float() - tiled.float()).abs() <= tol)

@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--zero", type=int, default=0, help="1: all-zero packed weights (data-dependent clock check)")
     ap.add_argument("--hot", type=int, default=0, help="1: a single weight buffer (stays in L2 / Infinity Cache)")
     ap.add_argument("--only", default="", help="N,K: just this shape")
+    ap.add_argument("--gemm_m", default="64,256,512,1024,4096,16384", help="row counts of the GEMM table")
+    ap.add_argument("--gemm_shape", default="5120,5120", help="N,K of the GEMM table")
+    ap.add_argument("--gemm_bits", default="4,3,2")
     args = ap.parse_args()
     global HOT, ZERO
     HOT = bool(args.hot)
@@ -107,10 +110,11 @@ def main():
             print(json.dumps(bench_case(4096, 4096, 4, m, args.iters)), flush=True)
     if not args.gemm:
         return
-    for m in (64, 256, 512, 1024, 4096, 16384):
-        for bits in (4, 3, 2):
-            r = bench_case(5120, 5120, bits, m, max(20, args.iters // 10), "gemm")
-            r["TFLOPs"] = round(2.0 * m * 5120 * 5120 / r["us"] / 1e6, 1)
+    gn, gk = (int(v) for v in args.gemm_shape.split(","))
+    for m in (int(v) for v in args.gemm_m.split(",")):
+        for bits in (int(v) for v in args.gemm_bits.split(",")):
+            r = bench_case(gn, gk, bits, m, max(20, args.iters // 10), "gemm")
+            r["TFLOPs"] = round(2.0 * m * gn * gk / r["us"] / 1e6, 1)
             print(json.dumps(r), flush=True)
 
 
