@@ -16,6 +16,7 @@
 // reused across all BM/16 row blocks, so the unpack VALU work is amortised BM/16x.
 // fp32 accumulate; split-K is not used (K/128 steps stay inside one workgroup,
 // results are deterministic).
+#include <cstdlib>
 #include "amq_common.cuh"
 #include "amq_kernels.h"
 
@@ -192,25 +193,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, con
 // (M x K fp16, <= 1 MB) lives in L2, so the launch is bound by latency and by how fast the CUs can pull x fragments.
 // The tiled kernel above needs split-K to occupy the chip at these sizes (4 K steps per workgroup, a barrier and a full
 // load latency each, fp32 partials written and re-read by a second launch: 15 + 4.6 us for 64 x 4096 x 4096).  Here a
-// workgroup owns 16*NSUB output columns for ALL of K, GEMV style: wave w walks K tiles w, w+4, ... with a D-deep
+// workgroup owns 16*NSUB output columns for ALL of K, GEMV style: wave w walks K tiles w, w+NWV, ... with a D-deep
 // register ring (no LDS, no barrier in the loop), the x fragments come straight from L2 in MFMA A-operand layout
 // (lane (r, o): row r, halves 32t + 8o .. +8), each unpacked W tile feeds MB (x NSUB) MFMAs, and the four waves' fp32
 // accumulators are summed through LDS in wave order (deterministic, no workspace).  K tiles past the end are
 // neutralised by a zero (scale, zero) pair instead of a branch, so every vmcnt wait stays a counted one.
-// Measured (MI355X, 3-bit, us per launch, skinny | tiled+split-K): 4096x4096  M=16 7.8|12.2  32 9.8|13.4  64 16.2|15.6;
-// 11008x4096  12.8|20.3  20.3|21.1  42.5|24.0;  4096x11008  15.8|19.4  20.4|19.8  34.2|20.9  -> taken up to 32 rows.
-int g_gemm_skinny_max = 32;      // rows up to which launch_gemm takes this kernel (AMQ_OPT_GEMM_SKINNY_MAX; 0 disables)
+// Measured (MI355X, 3-bit, us per launch, skinny | tiled+split-K): 4096x4096  M=16 6.2|12.2  32 8.0|13.4  64 12.8|15.6;
+// 11008x4096  M=32 18.0|21.1  64 33.0|24.0;  4096x11008  M=32 18.0|19.8  64 29.9|20.9.
+int g_gemm_skinny_max = 32;      // rows up to which launch_gemm always takes this kernel (AMQ_OPT_GEMM_SKINNY_MAX; 0 disables)
 
 template <int BITS, int MB, int NSUB>
 struct SkinnyTile { h8 xr[MB * 4]; LanePayload<BITS> pay[NSUB]; h2 meta[NSUB]; };
 
-template <int BITS, int MODE, int MB, int NSUB, int D>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
+template <int BITS, int MODE, int MB, int NSUB, int D, int NWV>
+__global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(GemmArgs a) {
     // per-wave transpose scratch (16*MB rows x 256 B, XOR-swizzled like the tiled kernel's x tiles); reused for the
     // cross-wave sum after the K loop
     constexpr int SCR = MB * 16 * 128;             // halves per wave
-    __shared__ __attribute__((aligned(16))) _Float16 scratch[4 * SCR];
-    static_assert(4 * SCR * 2 >= 4 * MB * NSUB * 64 * 16, "accumulator exchange must fit the scratch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* const scratch = (_Float16*)smem;              // NWV * SCR halves
+    static_assert(SCR * 2 >= MB * NSUB * 64 * 16, "accumulator exchange must fit the scratch");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, o = lane >> 4;
     const int G = a.K >> 7;
@@ -286,19 +288,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
     };
 
 #pragma unroll
-    for (int d = 0; d < D; ++d) load(ring[d], wave + 4 * d);
-    const int nt = (G + 3) >> 2;                   // K tiles of wave 0 (the other waves' extra tile is neutralised)
+    for (int d = 0; d < D; ++d) load(ring[d], wave + NWV * d);
+    const int nt = (G + NWV - 1) / NWV;                   // K tiles of wave 0 (the other waves' extra tile is neutralised)
     for (int j = 0; j < nt; j += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             compute(ring[d]);                      // tiles j + d >= nt carry zero meta
-            load(ring[d], wave + 4 * (j + d + D));
+            load(ring[d], wave + NWV * (j + d + D));
         }
     }
 
     // cross-wave sum in wave order, then wave w finishes (mb, nb) pairs w, w + 4, ...
     __syncthreads();                               // every wave is done with its transpose scratch
-    f4* const part = (f4*)scratch;                 // [4 waves][MB * NSUB][64 lanes]
+    f4* const part = (f4*)scratch;                 // [NWV waves][MB * NSUB][64 lanes]
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -307,11 +309,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
     const _Float16* bias = (const _Float16*)a.bias;
     const _Float16* res = (const _Float16*)a.residual;
     _Float16* y = (_Float16*)a.y;
-    for (int idx = wave; idx < MB * NSUB; idx += 4) {
+    for (int idx = wave; idx < MB * NSUB; idx += NWV) {
         const int mb = idx / NSUB, nb = idx % NSUB;
         f4 s = part[idx * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NWV; ++w) {
             const f4 p = part[(w * (MB * NSUB) + idx) * 64 + lane];
 #pragma unroll
             for (int i = 0; i < 4; ++i) s[i] += p[i];
@@ -333,13 +335,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
 
 template <int BITS, int MODE, int MB>
 static hipError_t skinny_launch_mb(const GemmArgs& a, hipStream_t st) {
+    // 8 waves split K (two per SIMD overlap each other's fetch / transpose / unpack / MFMA phases: 16.2 -> 12.8 us at
+    // 64 x 4096 x 4096 against 4 waves with a 3-deep ring); one 16-column block per workgroup
+    constexpr int NWV = 8;
+    constexpr int LDS = NWV * MB * 16 * 128 * 2;
     const int nblk = a.N >> 4;
     const int ny = (a.M + 16 * MB - 1) / (16 * MB);
-    // two column blocks per workgroup once one block each would be several rounds of workgroups per CU
-    if ((long)nblk * ny >= 1024 && MB <= 4)
-        hipLaunchKernelGGL((gemm_skinny_kernel<BITS, MODE, MB, 2, 2>), dim3((nblk + 1) / 2, ny), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((gemm_skinny_kernel<BITS, MODE, MB, 1, 3>), dim3(nblk, ny), dim3(256), 0, st, a);
+    auto k = gemm_skinny_kernel<BITS, MODE, MB, 1, 2, NWV>;
+    if (LDS > 64 * 1024) {
+        static hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL(k, dim3(nblk, ny), dim3(NWV * 64), LDS, st, a);
     return hipGetLastError();
 }
 
@@ -350,12 +357,16 @@ static hipError_t skinny_launch(const GemmArgs& a, hipStream_t st) {
     return skinny_launch_mb<BITS, MODE, 4>(a, st);
 }
 
-static bool gemm_is_skinny(int M) { return M <= g_gemm_skinny_max; }
+// up to g_gemm_skinny_max rows always; up to twice that while the column blocks fit one round of workgroups (measured
+// above: at 64 rows the kernel wins for N = 4096 and loses for N = 11008, where 688 workgroups take 2.7 rounds)
+static bool gemm_is_skinny(int M, int N) {
+    return M <= g_gemm_skinny_max || (M <= 2 * g_gemm_skinny_max && M <= 64 && (N >> 4) <= 320);
+}
 
 int gemm_pick_splits(int M, int N, int K) {
     const long wg = (long)((M + 63) / 64) * ((N + 127) / 128);      // 64-row tiles (what such launches use)
     const int G = K >> 7;
-    if (gemm_is_skinny(M)) return 1;                                 // gemm_skinny_kernel: no partials
+    if (gemm_is_skinny(M, N)) return 1;                               // gemm_skinny_kernel: no partials
     if (wg >= 192 || G < 4 || (N & 7)) return 1;
     int s = (int)((256 + wg - 1) / wg);
     if (s > 8) s = 8;
@@ -397,7 +408,7 @@ static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st) {
-    if (gemm_is_skinny(a.M)) {
+    if (gemm_is_skinny(a.M, a.N)) {
         if (a.mode == MODE_HQQ) {
             if (a.bits == 4) return skinny_launch<4, MODE_HQQ>(a, st);
             if (a.bits == 3) return skinny_launch<3, MODE_HQQ>(a, st);
