@@ -16,7 +16,6 @@
 // reused across all BM/16 row blocks, so the unpack VALU work is amortised BM/16x.
 // fp32 accumulate; split-K is not used (K/128 steps stay inside one workgroup,
 // results are deterministic).
-#include <cstdlib>
 #include "amq_common.cuh"
 #include "amq_kernels.h"
 
@@ -363,12 +362,18 @@ static bool gemm_is_skinny(int M, int N) {
     return M <= g_gemm_skinny_max || (M <= 2 * g_gemm_skinny_max && M <= 64 && (N >> 4) <= 320);
 }
 
+// Split-K policy (profiles/r01c_gemm_split_sweep.txt, 3-bit, us at M = 64 / 128 / 256): up to 256 rows 64-column workgroups aiming at
+// two per CU (4096^2: 14.3 / 16.9 / 23.0; 11008x4096: 21.7 / 29.7 / 48.2), beyond that 128-column workgroups aiming at one
+// per CU (15.6 / 18.2 / 24.6; 23.8 / 31.2 / 47.6; better from 512 rows on).
+static bool split_narrow(int M) { return M <= 256; }
+
 int gemm_pick_splits(int M, int N, int K) {
-    const long wg = (long)((M + 63) / 64) * ((N + 127) / 128);      // 64-row tiles (what such launches use)
+    const int bn = split_narrow(M) ? 64 : 128, target = split_narrow(M) ? 512 : 256;
+    const long wg = (long)((M + 63) / 64) * ((N + bn - 1) / bn);      // 64-row tiles (what such launches use)
     const int G = K >> 7;
     if (gemm_is_skinny(M, N)) return 1;                               // gemm_skinny_kernel: no partials
-    if (wg >= 192 || G < 4 || (N & 7)) return 1;
-    int s = (int)((256 + wg - 1) / wg);
+    if (wg >= target * 3 / 4 || G < 4 || (N & 7)) return 1;
+    int s = (int)((target + wg - 1) / wg);
     if (s > 8) s = 8;
     if (s > G / 2) s = G / 2;
     return s < 1 ? 1 : s;
@@ -399,6 +404,7 @@ template <int BITS, int MODE>
 static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
     // 64-row tiles while 128-row tiles would leave the chip under-filled (< 1.5 workgroups per CU)
     const long wg128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.splits > 1 && split_narrow(a.M)) return gemm_launch_cfg<BITS, MODE, 64, 1>(a, st);
     if (a.M <= 64 || wg128 < 384 || a.splits > 1) return gemm_launch_cfg<BITS, MODE, 64, 2>(a, st);
     // measured (5120x5120, M = 4096 / 16384): NSUB = 2 -> 0.81 / 0.89-0.92 PFLOP/s; NSUB = 4 needs ~390 VGPRs
     // (one wave per SIMD) and drops to 0.68 / 0.76 -- kept only as an A/B knob
