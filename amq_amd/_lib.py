@@ -57,6 +57,10 @@ SIGNATURES = {
     "amq_decode_tail_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "amq_attn_decode_cur_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amq_gemm_res_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "amq_xfrag_bytes": (_sz, [_i, _i]),
+    "amq_xfrag_f16": (_i, [_vp, _vp, _i, _i, ctypes.c_longlong, ctypes.c_longlong, _vp]),
+    "amq_rmsnorm_xfrag_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "amq_gemm_xfrag_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_silu_mul_f16": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),

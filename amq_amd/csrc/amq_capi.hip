@@ -225,6 +225,36 @@ int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qn, const vo
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream), "gemm_res");
 }
 
+size_t amq_xfrag_bytes(int M, int K) {
+    if (M < 1 || K < 128 || (K % 128) != 0) return 0;
+    return (size_t)((M + 63) / 64) * 64 * (size_t)K * 2;
+}
+
+int amq_xfrag_f16(const void* src, void* xf, int M, int K, long long stride_m, long long stride_kt, void* stream) {
+    if (!src || !xf) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1 || K < 128 || (K % 128) != 0) return fail(AMQ_ESHAPE, "need M >= 1 and K %% 128 == 0 (got M=%d K=%d)", M, K);
+    if (stride_m < 0 || stride_kt < 128 || (stride_m % 8) != 0 || (stride_kt % 8) != 0)
+        return fail(AMQ_ESHAPE, "strides must be multiples of 8 halves, stride_kt >= 128");
+    return check_hip(amq::launch_xfrag(src, xf, M, K, (long)stride_m, (long)stride_kt, (hipStream_t)stream), "xfrag");
+}
+
+int amq_rmsnorm_xfrag_f16(const void* x, const void* gamma, void* xf, int M, int K, float eps, void* stream) {
+    if (!x || !gamma || !xf) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1 || K < 128 || (K % 128) != 0) return fail(AMQ_ESHAPE, "need M >= 1 and K %% 128 == 0 (got M=%d K=%d)", M, K);
+    return check_hip(amq::launch_rmsnorm_xfrag(x, gamma, xf, M, K, eps, (hipStream_t)stream), "rmsnorm_xfrag");
+}
+
+int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qn, const void* mn, const void* bias,
+                       const void* residual, void* y, int M, int N, int K, int group, int y_stride, void* stream) {
+    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (int rc = check_mode(mode)) return rc;
+    if (!xf || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
+    if ((M + 63) / 64 > 65535) return fail(AMQ_ESHAPE, "M=%d exceeds one launch", M);
+    amq::GemmArgs a{xf, qn, mn, bias, y, M, N, K, bits, mode, K, y_stride ? y_stride : N, nullptr, 1, residual};
+    return check_hip(amq::launch_gemm_xfrag(a, (hipStream_t)stream), "gemm_xfrag");
+}
+
 int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
                        int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int head_dim, int max_seq, void* stream) {
     if (!q || !k || !v || !kcache || !vcache || !rope_table) return fail(AMQ_EINVAL, "null pointer");

@@ -28,11 +28,15 @@ __device__ __forceinline__ float wave_max_f(float v) {
 }
 
 // ------------------------------------------------------------------ RMSNorm
-// one workgroup (256 threads) per row; y = gamma * fp16(x * rsqrt(mean(x^2) + eps))
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const _Float16* x, const _Float16* gamma, _Float16* y, int K, float eps) {
+// one workgroup (256 threads) per row; y = gamma * fp16(x * rsqrt(mean(x^2) + eps)).  FRAG: the row is written in
+// fragment order (amq_hip.h: amq_xfrag_f16) for the few-row GEMMs that follow -- one workgroup per row of the padded
+// 64-row groups, rows >= M written as zeros.
+template <bool FRAG>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const _Float16* x, const _Float16* gamma, _Float16* y, int M, int K, float eps) {
     __shared__ float red[4];
-    const _Float16* xr = x + (size_t)blockIdx.x * K;
-    _Float16* yr = y + (size_t)blockIdx.x * K;
+    const int m = blockIdx.x;
+    const bool live = m < M;
+    const _Float16* xr = x + (size_t)(live ? m : 0) * K;
     float ss = 0.f;
     for (int c = threadIdx.x; c < (K >> 3); c += 256) {
         h8 v = *(const h8*)(xr + 8 * c);
@@ -43,18 +47,31 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const _Float16* x, const _
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
     const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+    const int G = K >> 7, gy = m >> 6, mb = (m & 63) >> 4, r = m & 15;
     for (int c = threadIdx.x; c < (K >> 3); c += 256) {
         h8 v = *(const h8*)(xr + 8 * c);
         h8 g = *(const h8*)(gamma + 8 * c);
-        h8 r;
+        h8 o8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { _Float16 n = (_Float16)((float)v[i] * rstd); r[i] = g[i] * n; }
-        *(h8*)(yr + 8 * c) = r;
+        for (int i = 0; i < 8; ++i) { _Float16 n = (_Float16)((float)v[i] * rstd); o8[i] = g[i] * n; }
+        if (FRAG) {
+            if (!live) o8 = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            const int kt = c >> 4, t = (c >> 2) & 3, o = c & 3;     // k = 8c = kt*128 + 32t + 8o
+            *(h8*)(y + ((((size_t)gy * G + kt) * 16 + mb * 4 + t) * 64 + o * 16 + r) * 8) = o8;
+        } else {
+            *(h8*)(y + (size_t)m * K + 8 * c) = o8;
+        }
     }
 }
 
 hipError_t launch_rmsnorm(const void* x, const void* gamma, void* y, int M, int K, float eps, hipStream_t st) {
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(M), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)gamma, (_Float16*)y, K, eps);
+    hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3(M), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)gamma, (_Float16*)y, M, K, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmsnorm_xfrag(const void* x, const void* gamma, void* xf, int M, int K, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3(((M + 63) / 64) * 64), dim3(256), 0, st, (const _Float16*)x,
+                       (const _Float16*)gamma, (_Float16*)xf, M, K, eps);
     return hipGetLastError();
 }
 

@@ -204,7 +204,7 @@ int g_gemm_skinny_max = 32;      // rows up to which launch_gemm always takes th
 template <int BITS, int MB, int NSUB>
 struct SkinnyTile { h8 xr[MB * 4]; LanePayload<BITS> pay[NSUB]; h2 meta[NSUB]; };
 
-template <int BITS, int MODE, int MB, int NSUB, int D, int NWV>
+template <int BITS, int MODE, int MB, int NSUB, int D, int NWV, bool XF>
 __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(GemmArgs a) {
     // per-wave transpose scratch (16*MB rows x 256 B, XOR-swizzled like the tiled kernel's x tiles); reused for the
     // cross-wave sum after the K loop
@@ -255,19 +255,27 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(GemmArgs a) {
             const h2 mv = mt[tile * 16 + r];
             T.meta[nb] = valid ? mv : (h2){(_Float16)0.f, (_Float16)0.f};
         }
+        if (XF) {       // fragment-ordered x (amq_xfrag_f16): instruction j = mb*4 + t is one contiguous KiB, already an A operand
+            const _Float16* xt = x + ((size_t)blockIdx.y * G + ktc) * (64 * 128) + lane * 8;
 #pragma unroll
-        for (int j = 0; j < MB * 4; ++j) T.xr[j] = *(const h8*)(x + (size_t)xoff[j] + ktc * 128);
+            for (int j = 0; j < MB * 4; ++j) T.xr[j] = *(const h8*)(xt + j * 512);
+        } else {
+#pragma unroll
+            for (int j = 0; j < MB * 4; ++j) T.xr[j] = *(const h8*)(x + (size_t)xoff[j] + ktc * 128);
+        }
     };
     auto compute = [&](const SkinnyTile<BITS, MB, NSUB>& T) {
         h2 wv[NSUB][16];
 #pragma unroll
         for (int nb = 0; nb < NSUB; ++nb) dequant_lane_sd<BITS, MODE>(T.pay[nb].w, T.meta[nb], wv[nb]);
+        if (!XF) {
 #pragma unroll
-        for (int j = 0; j < MB * 4; ++j) {
-            const int row = 4 * j + o;
-            *(h8*)(my + row * 128 + ((r ^ (row & 15)) << 3)) = T.xr[j];
+            for (int j = 0; j < MB * 4; ++j) {
+                const int row = 4 * j + o;
+                *(h8*)(my + row * 128 + ((r ^ (row & 15)) << 3)) = T.xr[j];
+            }
+            __builtin_amdgcn_wave_barrier();       // same wave writes and reads: the LDS pipe keeps the order
         }
-        __builtin_amdgcn_wave_barrier();           // same wave writes and reads: the LDS pipe keeps the order
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             h8 b[NSUB];
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(GemmArgs a) {
                 for (int p = 0; p < 4; ++p) { b[nb][2 * p] = wv[nb][4 * t + p].x; b[nb][2 * p + 1] = wv[nb][4 * t + p].y; }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const h8 av = *(const h8*)(my + (mb * 16 + r) * 128 + (((4 * t + o) ^ r) << 3));
+                const h8 av = XF ? T.xr[mb * 4 + t] : *(const h8*)(my + (mb * 16 + r) * 128 + (((4 * t + o) ^ r) << 3));
 #pragma unroll
                 for (int nb = 0; nb < NSUB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b[nb], acc[mb][nb], 0, 0, 0);
@@ -340,12 +348,71 @@ static hipError_t skinny_launch_mb(const GemmArgs& a, hipStream_t st) {
     constexpr int LDS = NWV * MB * 16 * 128 * 2;
     const int nblk = a.N >> 4;
     const int ny = (a.M + 16 * MB - 1) / (16 * MB);
-    auto k = gemm_skinny_kernel<BITS, MODE, MB, 1, 2, NWV>;
+    auto k = gemm_skinny_kernel<BITS, MODE, MB, 1, 2, NWV, false>;
     if (LDS > 64 * 1024) {
         static hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (attr != hipSuccess) return attr;
     }
     hipLaunchKernelGGL(k, dim3(nblk, ny), dim3(NWV * 64), LDS, st, a);
+    return hipGetLastError();
+}
+
+// fragment-ordered x (launch_xfrag / launch_rmsnorm_xfrag): 64-row groups (grid.y), the A operands are fetched as whole
+// contiguous KiB straight into registers -- no transpose scratch, LDS only for the final cross-wave sum.  Every workgroup
+// still streams its rows' whole x from L2 (M*K*2 bytes through one CU's L1), so the column blocks per workgroup grow with
+// the launch.  Measured (3-bit, us, this | tiled + split-K): 4096^2 M = 64 / 128 / 256: 9.0 / 10.5 / 16.5 | 14.3 / 16.9 /
+// 23.0; 11008x4096: 17.3 / 30.1 / 47.7 | 21.7 / 29.7 / 48.2; 4096x11008 (x = 1.4 MB per workgroup): 24.4 / 28.0 / 43.8 |
+// 20.4 / 28.1 / 51.4.
+template <int BITS, int MODE>
+static hipError_t skinny_launch_xf(const GemmArgs& a, hipStream_t st) {
+    const int nblk = a.N >> 4;
+    const int ny = (a.M + 63) / 64;
+    const long blocks = (long)nblk * ny;
+    if (blocks <= 320) {
+        hipLaunchKernelGGL((gemm_skinny_kernel<BITS, MODE, 4, 1, 2, 8, true>), dim3(nblk, ny), dim3(512), 8 * 4096, st, a);
+    } else if (blocks <= 640) {
+        hipLaunchKernelGGL((gemm_skinny_kernel<BITS, MODE, 4, 2, 2, 8, true>), dim3((nblk + 1) / 2, ny), dim3(512), 8 * 2 * 4096, st, a);
+    } else {
+        auto k = gemm_skinny_kernel<BITS, MODE, 4, 4, 2, 8, true>;
+        static hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(k, dim3((nblk + 3) / 4, ny), dim3(512), 8 * 4 * 4096, st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_xfrag(const GemmArgs& a, hipStream_t st) {
+    if (a.mode == MODE_HQQ) {
+        if (a.bits == 4) return skinny_launch_xf<4, MODE_HQQ>(a, st);
+        if (a.bits == 3) return skinny_launch_xf<3, MODE_HQQ>(a, st);
+        return skinny_launch_xf<2, MODE_HQQ>(a, st);
+    }
+    if (a.bits == 4) return skinny_launch_xf<4, MODE_FMA>(a, st);
+    if (a.bits == 3) return skinny_launch_xf<3, MODE_FMA>(a, st);
+    return skinny_launch_xf<2, MODE_FMA>(a, st);
+}
+
+// rows -> fragment order: xf[gy][kt][mb*4 + t][lane = 16*o + r][8] = x[gy*64 + mb*16 + r][kt*128 + 32*t + 8*o ..+8]
+// (zero for rows >= M).  Source element (m, k) lives at src[m*stride_m + (k >> 7)*stride_kt + (k & 127)]: stride_kt = 128
+// for row-major [M, K]; an attention output [heads, M, 128] is read in place with stride_m = 128, stride_kt = M*128.
+__global__ __launch_bounds__(256) void xfrag_kernel(const _Float16* src, _Float16* xf, int M, int G, long stride_m, long stride_kt) {
+    // one thread per 16-byte chunk of the destination; consecutive threads -> consecutive destination chunks
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = (int)(idx & 63), j = (int)((idx >> 6) & 15);
+    const long tile = idx >> 10;                   // gy * G + kt
+    const int kt = (int)(tile % G), gy = (int)(tile / G);
+    const int r = lane & 15, o = lane >> 4, mb = j >> 2, t = j & 3;
+    const int m = gy * 64 + mb * 16 + r;
+    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (m < M) v = *(const h8*)(src + (size_t)m * stride_m + (size_t)kt * stride_kt + 32 * t + 8 * o);
+    *(h8*)(xf + idx * 8) = v;
+}
+
+hipError_t launch_xfrag(const void* src, void* xf, int M, int K, long stride_m, long stride_kt, hipStream_t st) {
+    const int G = K >> 7, ny = (M + 63) / 64;
+    const long chunks = (long)ny * G * 1024;
+    hipLaunchKernelGGL(xfrag_kernel, dim3((unsigned)(chunks / 256)), dim3(256), 0, st, (const _Float16*)src, (_Float16*)xf, M, G,
+                       stride_m, stride_kt);
     return hipGetLastError();
 }
 

@@ -56,6 +56,8 @@ struct GemmArgs {
     const void* residual;   // fp16 [M, y_stride] added to the rounded result (y = residual + fp16(acc (+ bias))), or null
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st);
+hipError_t launch_gemm_xfrag(const GemmArgs& a, hipStream_t st);     // a.x in fragment order (launch_xfrag)
+hipError_t launch_xfrag(const void* src, void* xf, int M, int K, long stride_m, long stride_kt, hipStream_t st);
 int gemm_pick_splits(int M, int N, int K);
 extern int g_gemm_nsub;
 extern int g_gemm_skinny_max;
@@ -79,6 +81,7 @@ struct AttnArgs {
 hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st);
 hipError_t launch_rmsnorm(const void* x, const void* gamma, void* y, int M, int K, float eps, hipStream_t st);
+hipError_t launch_rmsnorm_xfrag(const void* x, const void* gamma, void* xf, int M, int K, float eps, hipStream_t st);
 // prefill glue (amq_decode.hip)
 hipError_t launch_rope_cache(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
                              int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int max_seq, hipStream_t st);

@@ -256,17 +256,34 @@ class QuantLlama:
             y = ops.linear(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K)
             return y if residual is None else residual.add_(y)
 
+        def lin_xf(l, xf, residual=None):
+            return ops.gemm_xfrag(xf, S, l.qn, l.mn, l.bits, l.mode, l.N, l.K, residual=residual, out=residual)
+
+        # up to 256 rows the projections that read a normed / attention activation take it in fragment order (written
+        # that way by the producing launch): 1.2-1.6x faster few-row GEMMs; down_proj (K = 11008: the
+        # per-workgroup x stream is what bounds that kernel) and longer prompts stay on the tiled kernel
+        frag = 8 < S <= 256
         for blk in self.blocks:
-            h = ops.rmsnorm(x, blk["ln1"], self.eps)
-            q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
+            if frag:
+                h = ops.rmsnorm_xfrag(x, blk["ln1"], self.eps)
+                q, k, v = (lin_xf(blk["self_attn." + n], h) for n in ("q_proj", "k_proj", "v_proj"))
+            else:
+                h = ops.rmsnorm(x, blk["ln1"], self.eps)
+                q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
             ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, 0, nh, nkv)
-            x = lin(blk["self_attn.o_proj"], self._prefill_attention(q, blk, S), residual=x)
-            h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
-            g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
+            if frag:
+                a = self._prefill_attention(q, blk, S, heads_first=True)            # [nh, S, 128], any strides
+                x = lin_xf(blk["self_attn.o_proj"], ops.xfrag(a, S, H, stride_m=a.stride(1), stride_kt=a.stride(0)), residual=x)
+                h2 = ops.rmsnorm_xfrag(x, blk["ln2"], self.eps)
+                g, u = lin_xf(blk["mlp.gate_proj"], h2), lin_xf(blk["mlp.up_proj"], h2)
+            else:
+                x = lin(blk["self_attn.o_proj"], self._prefill_attention(q, blk, S), residual=x)
+                h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
+                g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
             x = lin(blk["mlp.down_proj"], ops.silu_mul(g, u, out=g), residual=x)
         return self._prefill_finish(x, S)
 
-    def _prefill_attention(self, q, blk, S):
+    def _prefill_attention(self, q, blk, S, heads_first=False):
         # q: [S, nh*128] rotated; K/V: the cache rows just written
         nh, nkv = self.nh, self.nkv
         qh = q.view(S, nh, 128).transpose(0, 1)
@@ -275,6 +292,8 @@ class QuantLlama:
             kh = kh.repeat_interleave(nh // nkv, dim=0)
             vh = vh.repeat_interleave(nh // nkv, dim=0)
         a = torch.nn.functional.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
+        if heads_first:
+            return a if a.stride(2) == 1 else a.contiguous()
         return a.transpose(0, 1).reshape(S, self.H).contiguous()
 
     def _prefill_finish(self, x, S):

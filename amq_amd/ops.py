@@ -177,6 +177,49 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None):
     return y.reshape(*x.shape[:-1], N)
 
 
+def xfrag(src, M, K, stride_m=None, stride_kt=128, out=None):
+    """Fragment-ordered copy of M x K activations (see include/amq_hip.h: amq_xfrag_f16).  ``src`` is any fp16 tensor whose
+    element (m, k) sits at m*stride_m + (k // 128)*stride_kt + k % 128 (default: row-major [M, K])."""
+    if not isinstance(src, torch.Tensor) or not src.is_cuda or src.dtype != torch.float16:
+        raise ValueError("src: expected an fp16 tensor on the GPU")
+    lib = _lib.load()
+    nbytes = lib.amq_xfrag_bytes(M, K)
+    xf = out if out is not None else torch.empty(nbytes // 2, dtype=torch.float16, device=src.device)
+    _need(xf, torch.float16, "xf", nbytes // 2)
+    _lib.check(lib.amq_xfrag_f16(_lib.ptr(src), _lib.ptr(xf), M, K, K if stride_m is None else int(stride_m), int(stride_kt),
+                                 _lib.current_stream()))
+    return xf
+
+
+def rmsnorm_xfrag(x, gamma, eps, out=None):
+    """:func:`rmsnorm` of x [M, K] with the result in fragment order (input of :func:`gemm_xfrag`)."""
+    M, K = x.shape
+    _need(x, torch.float16, "x")
+    _need(gamma, torch.float16, "gamma", K)
+    lib = _lib.load()
+    nbytes = lib.amq_xfrag_bytes(M, K)
+    xf = out if out is not None else torch.empty(nbytes // 2, dtype=torch.float16, device=x.device)
+    _need(xf, torch.float16, "xf", nbytes // 2)
+    _lib.check(lib.amq_rmsnorm_xfrag_f16(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(xf), M, K, float(eps), _lib.current_stream()))
+    return xf
+
+
+def gemm_xfrag(xf, M, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None):
+    """y[M, N] = x . W^T with x given in fragment order (:func:`xfrag`); ``residual`` as in :func:`gemm`."""
+    _check_shape(bits, N, K)
+    _check_native(qn, mn, bits, N, K)
+    _need(xf, torch.float16, "xf", _lib.load().amq_xfrag_bytes(M, K) // 2)
+    if bias is not None:
+        _need(bias, torch.float16, "bias", N)
+    if residual is not None:
+        _need(residual, torch.float16, "residual", M * N)
+    y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=xf.device)
+    _need(y, torch.float16, "y", M * N)
+    _lib.check(_lib.load().amq_gemm_xfrag_f16(bits, mode, _lib.ptr(xf), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
+                                              _lib.ptr(residual), _lib.ptr(y), M, N, K, GROUP, 0, _lib.current_stream()))
+    return y
+
+
 def linear(x, qn, mn, bits, mode, N, K, bias=None):
     """Reference-style dispatch: few rows -> gemv family, otherwise gemm."""
     _check_shape(bits, N, K)

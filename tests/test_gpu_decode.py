@@ -218,7 +218,7 @@ def test_token_step_runner_matches_dense_reference(gqa):
         assert int(m.pos.item()) == seq.numel()
 
 
-@pytest.mark.parametrize("gqa,S", [(False, 12), (True, 40), (False, 5)])
+@pytest.mark.parametrize("gqa,S", [(False, 12), (True, 40), (False, 5), (True, 60)])
 def test_fused_prefill_matches_framework_glue(gqa, S):
     """The fused many-row pass (RoPE + cache write, SiLU*up, residual epilogues) against the same pass with framework
     ops for the glue: same next token, logits and KV cache within fp16 rounding of the differently-ordered roundings."""

@@ -418,3 +418,47 @@ def test_gemm_skinny(bits, m, n, k):
     ref = x.to(dev).float() @ ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).float().t()
     tol = 2.0 ** -9 * ref.abs() + 2.0 ** -9 * y.float().abs() + 1e-3 * ref.pow(2).mean().sqrt()
     assert torch.all((y.float() - tiled.float()).abs() <= tol)
+
+
+@pytest.mark.parametrize("m,k", [(1, 128), (9, 384), (64, 4096), (65, 1024), (200, 512)])
+def test_xfrag_layout(m, k):
+    """fragment order = xf[g][kt][mb*4 + t][16*o + r][8] <- x[g*64 + mb*16 + r][kt*128 + 32t + 8o ..+8], rows >= M zero;
+    strided sources (an attention output [heads, M, 128]) and the fused RMSNorm writer produce the same image"""
+    from amq_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=gen).half().to(dev)
+    g, ny = k // 128, (m + 63) // 64
+    xp = torch.zeros(ny * 64, k, dtype=torch.float16, device=dev)
+    xp[:m] = x
+    ref = xp.view(ny, 4, 16, g, 4, 4, 8).permute(0, 3, 1, 4, 5, 2, 6).contiguous().reshape(-1)   # gy, kt, mb, t, o, r, 8
+    xf = ops.xfrag(x, m, k)
+    assert torch.equal(xf, ref)
+    heads = x.view(m, g, 128).transpose(0, 1).contiguous()                                       # [heads, M, 128]
+    assert torch.equal(ops.xfrag(heads, m, k, stride_m=heads.stride(1), stride_kt=heads.stride(0)), ref)
+    gamma = torch.randn(k, generator=gen).half().to(dev)
+    assert torch.equal(ops.rmsnorm_xfrag(x, gamma, 1e-5), ops.xfrag(ops.rmsnorm(x, gamma, 1e-5), m, k))
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("m,n,k", [(9, 48, 128), (64, 4096, 4096), (100, 1040, 1024), (130, 11008, 512), (256, 4096, 1024),
+                                   (40, 16400, 256)])
+def test_gemm_xfrag(bits, m, n, k):
+    """few-row GEMM over fragment-ordered x (1, 2 or 4 column blocks per workgroup by launch size): oracle linear on the
+    reference's dequantized weights, determinism, bias + residual (in place)"""
+    from amq_amd import ops
+    h, qn, mn, w_ref = _random_case(bits, n, k, seed=13 * bits + m, bias=True)
+    dev = _dev()
+    gen = torch.Generator().manual_seed(n + k + m)
+    x = torch.randn(m, k, generator=gen).to(torch.float16)
+    res = torch.randn(m, n, generator=gen).to(torch.float16).to(dev)
+    bias = h.bias.to(dev)
+    xf = ops.xfrag(x.to(dev), m, k)
+    y0 = ops.gemm_xfrag(xf, m, qn, mn, bits, ops.MODE_HQQ, n, k)
+    _assert_close(y0.cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref, None), f"xfrag {bits}b {n}x{k} M={m}")
+    y = ops.gemm_xfrag(xf, m, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias)
+    assert torch.equal(y, y0 + bias)                       # y = fp16(fp16(acc) + bias), like the other kernels
+    assert torch.equal(ops.gemm_xfrag(xf, m, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias), y)
+    inplace = res.clone()
+    ops.gemm_xfrag(xf, m, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=inplace, out=inplace)
+    assert torch.equal(inplace, res + y)

@@ -39,6 +39,15 @@ def bench_case(n, k, bits, m, iters, fn_name="gemv"):
     x = torch.randn(m, k, device=dev).half()
     y = torch.empty(m, n, device=dev, dtype=torch.float16)
     fn = getattr(ops, fn_name)
+    if fn_name == "gemm_xfrag":                       # x pre-arranged in fragment order (ops.xfrag), as a fused producer would
+        xf = ops.xfrag(x, m, k)
+        ref = ops.gemm(x, qn0, mn0, bits, ops.MODE_HQQ, n, k)
+        got = ops.gemm_xfrag(xf, m, qn0, mn0, bits, ops.MODE_HQQ, n, k)
+        err = (got.float() - ref.float()).abs().max().item() / ref.float().abs().max().item()
+        assert err < 2e-3, err
+
+        def fn(x_, q, mt, bits_, mode, n_, k_, out=None):
+            return ops.gemm_xfrag(xf, m, q, mt, bits_, mode, n_, k_, out=out)
     for i in range(copies):
         fn(x, bufs[i][0], bufs[i][1], bits, ops.MODE_HQQ, n, k, out=y)
     torch.cuda.synchronize()
@@ -86,6 +95,7 @@ def main():
     ap.add_argument("--gemm_m", default="64,256,512,1024,4096,16384", help="row counts of the GEMM table")
     ap.add_argument("--gemm_shape", default="5120,5120", help="N,K of the GEMM table")
     ap.add_argument("--gemm_bits", default="4,3,2")
+    ap.add_argument("--gemm_fn", default="gemm", help="gemm | gemm_xfrag")
     args = ap.parse_args()
     global HOT, ZERO
     HOT = bool(args.hot)
@@ -113,7 +123,7 @@ def main():
     gn, gk = (int(v) for v in args.gemm_shape.split(","))
     for m in (int(v) for v in args.gemm_m.split(",")):
         for bits in (int(v) for v in args.gemm_bits.split(",")):
-            r = bench_case(gn, gk, bits, m, max(20, args.iters // 10), "gemm")
+            r = bench_case(gn, gk, bits, m, max(20, args.iters // 10), args.gemm_fn)
             r["TFLOPs"] = round(2.0 * m * gn * gk / r["us"] / 1e6, 1)
             print(json.dumps(r), flush=True)
 
