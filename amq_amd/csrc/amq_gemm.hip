@@ -423,10 +423,11 @@ static hipError_t skinny_launch(const GemmArgs& a, hipStream_t st) {
     return skinny_launch_mb<BITS, MODE, 4>(a, st);
 }
 
-// up to g_gemm_skinny_max rows always; up to twice that while the column blocks fit one round of workgroups (measured
-// above: at 64 rows the kernel wins for N = 4096 and loses for N = 11008, where 688 workgroups take 2.7 rounds)
-static bool gemm_is_skinny(int M, int N) {
-    return M <= g_gemm_skinny_max || (M <= 2 * g_gemm_skinny_max && M <= 64 && (N >> 4) <= 320);
+// up to g_gemm_skinny_max rows always; up to twice that while the column blocks fit one round of workgroups and K is
+// short (measured above: at 64 rows the kernel wins for 4096x4096, loses for N = 11008 -- 688 workgroups, 2.7 rounds --
+// and for K = 11008 -- 1.4 MB of x per workgroup)
+static bool gemm_is_skinny(int M, int N, int K) {
+    return M <= g_gemm_skinny_max || (M <= 2 * g_gemm_skinny_max && M <= 64 && (N >> 4) <= 320 && K <= 6144);
 }
 
 // Split-K policy (profiles/r01c_gemm_split_sweep.txt, 3-bit, us at M = 64 / 128 / 256): up to 256 rows 64-column workgroups aiming at
@@ -438,7 +439,7 @@ int gemm_pick_splits(int M, int N, int K) {
     const int bn = split_narrow(M) ? 64 : 128, target = split_narrow(M) ? 512 : 256;
     const long wg = (long)((M + 63) / 64) * ((N + bn - 1) / bn);      // 64-row tiles (what such launches use)
     const int G = K >> 7;
-    if (gemm_is_skinny(M, N)) return 1;                               // gemm_skinny_kernel: no partials
+    if (gemm_is_skinny(M, N, K)) return 1;                               // gemm_skinny_kernel: no partials
     if (wg >= target * 3 / 4 || G < 4 || (N & 7)) return 1;
     int s = (int)((target + wg - 1) / wg);
     if (s > 8) s = 8;
@@ -481,7 +482,7 @@ static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st) {
-    if (gemm_is_skinny(a.M, a.N)) {
+    if (gemm_is_skinny(a.M, a.N, a.K)) {
         if (a.mode == MODE_HQQ) {
             if (a.bits == 4) return skinny_launch<4, MODE_HQQ>(a, st);
             if (a.bits == 3) return skinny_launch<3, MODE_HQQ>(a, st);

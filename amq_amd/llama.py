@@ -262,7 +262,7 @@ class QuantLlama:
         # up to 256 rows the projections that read a normed / attention activation take it in fragment order (written
         # that way by the producing launch): 1.2-1.6x faster few-row GEMMs; down_proj (K = 11008: the
         # per-workgroup x stream is what bounds that kernel) and longer prompts stay on the tiled kernel
-        frag = 8 < S <= 256
+        frag = 32 < S <= 256                        # up to 32 rows the row-major skinny kernel (16 / 32-row variants) is as fast
         for blk in self.blocks:
             if frag:
                 h = ops.rmsnorm_xfrag(x, blk["ln1"], self.eps)
