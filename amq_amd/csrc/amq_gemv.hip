@@ -716,6 +716,8 @@ static hipError_t launch_nw(const GemvKArgs& a, int flags, int depth, int total_
     if (u == 4) return launch_one<PRO, NW, 4, MATH_EXACT>(a, total_wg, lds, st);
     if (NW == 16 && a.M == 1 && (a.K >> 3) > XCfg<16>::XC * 1024 && (a.K >> 3) <= 4 * 1024)
         return launch_one<PRO, 16, 2, MATH_EXACT, 4>(a, total_wg, lds, st);        // 16384 < K <= 32768 (70B down_proj)
+    if (NW == 8 && a.M == 1 && (a.K >> 3) > 512 && (a.K >> 3) <= 1024)
+        return launch_one<PRO, 8, 2, MATH_EXACT, 2>(a, total_wg, lds, st);         // 4096 < K <= 8192 on 8 waves (two x chunks per thread)
     return launch_one<PRO, NW, 2, MATH_EXACT>(a, total_wg, lds, st);
 }
 
@@ -730,13 +732,19 @@ static hipError_t launch_pro(const GemvKArgs& a, int flags, int depth, int nw, i
 hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     int total_rt = 0;
     for (int i = 0; i < a.nseg; ++i) { a.seg[i].n_rt = a.seg[i].N / 16; total_rt += a.seg[i].n_rt; }
-    const int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_rt, a.K);
+    int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_rt, a.K);
+    // 4096 < K <= 8192 at one row (13B / 70B hidden sizes): 8-wave workgroups staging two x chunks per thread, two per CU
+    // (~90 VGPRs), instead of one 16-wave workgroup -- 13B 464 -> 485 tokens/s, 70B 126.5 -> 133.  The same trade for
+    // 8192 < K <= 16384 (four chunks per thread) loses (13B 484 -> 467), as do three workgroups per CU (449 / 122).
+    const bool mid_k = !a.force_waves && nw == 16 && a.M == 1 && (a.K >> 3) > 512 && (a.K >> 3) <= 1024 &&
+                       !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4;    // (only the exact-math body has the two-chunk variant)
+    if (mid_k) nw = 8;
     // persistent-style grid: about 24 waves per CU (256 CUs) -- three 8-wave workgroups, but ONE 16-wave workgroup (two do
     // not fit the register file at 78 VGPRs, a second round of workgroups would run on an empty chip); a workgroup walks
     // `rpt` row-tiles
     int rpt = a.force_rpt;
     if (rpt <= 0) {
-        const int target = nw == 16 ? 256 : 256 * 24 / nw;
+        const int target = mid_k ? 512 : nw == 16 ? 256 : 256 * 24 / nw;
         rpt = (total_rt + target - 1) / target;
         if (rpt < 1) rpt = 1;
     }

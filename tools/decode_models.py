@@ -10,6 +10,8 @@ from amq_amd.llama import QuantLlama
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device("cuda:0")
 cases = [("Llama-2-7b-hf", 4.0, True), ("Llama-2-7b-hf", 3.0, False), ("Llama-2-13b-hf", 3.0, False), ("Llama-2-70b-hf", 3.0, False)]
+if os.environ.get("DECODE_MODELS"):
+    cases = [c for c in cases if any(k in c[0] for k in os.environ["DECODE_MODELS"].split(","))]
 for name, bits, uniform in cases:
     cfg = arch.MODEL_CONFIGS[name]
     if uniform:
