@@ -735,7 +735,8 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_rt, a.K);
     // 4096 < K <= 8192 at one row (13B / 70B hidden sizes): 8-wave workgroups staging two x chunks per thread, two per CU
     // (~90 VGPRs), instead of one 16-wave workgroup -- 13B 464 -> 485 tokens/s, 70B 126.5 -> 133.  The same trade for
-    // 8192 < K <= 16384 (four chunks per thread) loses (13B 484 -> 467), as do three workgroups per CU (449 / 122).
+    // 8192 < K <= 16384 (four chunks per thread) loses (13B 484 -> 467; 7B's K = 11008 with three chunks 808 -> 773), as do
+    // three workgroups per CU (449 / 122).
     const bool mid_k = !a.force_waves && nw == 16 && a.M == 1 && (a.K >> 3) > 512 && (a.K >> 3) <= 1024 &&
                        !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4;    // (only the exact-math body has the two-chunk variant)
     if (mid_k) nw = 8;
