@@ -191,12 +191,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, con
 // A few dozen rows are neither GEMV- nor GEMM-shaped: the packed weights are a few MB (one pass, HBM-trivial) and x
 // (M x K fp16, <= 1 MB) lives in L2, so the launch is bound by latency and by how fast the CUs can pull x fragments.
 // The tiled kernel above needs split-K to occupy the chip at these sizes (4 K steps per workgroup, a barrier and a full
-// load latency each, fp32 partials written and re-read by a second launch: 15 + 4.6 us for 64 x 4096 x 4096).  Here a
+// load latency each, fp32 partials written and re-read by a second launch: 15.6 us for 64 x 4096 x 4096).  Here a
 // workgroup owns 16*NSUB output columns for ALL of K, GEMV style: wave w walks K tiles w, w+NWV, ... with a D-deep
-// register ring (no LDS, no barrier in the loop), the x fragments come straight from L2 in MFMA A-operand layout
-// (lane (r, o): row r, halves 32t + 8o .. +8), each unpacked W tile feeds MB (x NSUB) MFMAs, and the four waves' fp32
-// accumulators are summed through LDS in wave order (deterministic, no workspace).  K tiles past the end are
-// neutralised by a zero (scale, zero) pair instead of a branch, so every vmcnt wait stays a counted one.
+// register ring and no barrier in the loop; each unpacked W tile feeds MB (x NSUB) MFMAs; the waves' fp32 accumulators
+// are summed through LDS in wave order (deterministic, no workspace).  K tiles past the end are neutralised by a zero
+// (scale, zero) pair instead of a branch, so every vmcnt wait stays a counted one.  Two ways of getting x:
+//   XF = false  row-major x: fetched row-coalesced and transposed into MFMA A operands through a wave-private LDS scratch
+//   XF = true   fragment-ordered x (launch_xfrag / rmsnorm_kernel<true>): every wave-load is a contiguous KiB that
+//               already is an operand; LDS is used only for the final sum
 // Measured (MI355X, 3-bit, us per launch, skinny | tiled+split-K): 4096x4096  M=16 6.2|12.2  32 8.0|13.4  64 12.8|15.6;
 // 11008x4096  M=32 18.0|21.1  64 33.0|24.0;  4096x11008  M=32 18.0|19.8  64 29.9|20.9.
 int g_gemm_skinny_max = 32;      // rows up to which launch_gemm always takes this kernel (AMQ_OPT_GEMM_SKINNY_MAX; 0 disables)
