@@ -14,8 +14,8 @@
 // The packed W tile never touches LDS -- each lane's 16/12/8-byte payload unpacks
 // directly into the B operand of v_mfma_f32_16x16x32_f16 and is
 // reused across all BM/16 row blocks, so the unpack VALU work is amortised BM/16x.
-// fp32 accumulate; split-K is not used (K/128 steps stay inside one workgroup,
-// results are deterministic).
+// fp32 accumulate.  Launches with too few tiles to fill the chip run split-K into fp32 slices of a caller-owned workspace
+// followed by an ordered reduce (deterministic); a few dozen rows take gemm_skinny_kernel further down instead.
 #include "amq_common.cuh"
 #include "amq_kernels.h"
 
