@@ -685,7 +685,8 @@ int gemv_pick_waves(int total_rt, int K) {
     // on 256 row-tiles (o_proj) 8 waves are ~10% faster (16-wave workgroups dispatch later); tiny K: 4 waves.
     // K > 4096 always takes 16 waves: the register-held activation staging of the decode prologue covers
     // K <= 8 * XC * threads (4096 for 8 waves, 16384 for 16), and one 16-wave workgroup per CU is within 5% of the
-    // 8-wave grids on every shape measured.
+    // 8-wave grids on every shape measured.  (Exception made in launch_gemv: single-row launches with 4096 < K <= 8192
+    // go to 8-wave workgroups that stage two chunks per thread, two workgroups per CU.)
     const int G = K >> 7;
     if (G < 16) return 4;
     if (G > 32) return 16;
