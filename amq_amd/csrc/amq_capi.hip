@@ -266,6 +266,17 @@ int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void
                                             (hipStream_t)stream), "rope_cache");
 }
 
+int amq_rope_rows_f16(void* q, void* k, const void* rope_table, int rope_rows, int pos0, int rows, int seq_len, int n_heads,
+                      int n_kv_heads, int head_dim, void* stream) {
+    if (!q || !k || !rope_table) return fail(AMQ_EINVAL, "null pointer");
+    if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
+    if (rows < 1 || seq_len < 1 || (rows % seq_len) != 0 || n_heads < 1 || n_kv_heads < 1 || rope_rows < 1 || pos0 < 0)
+        return fail(AMQ_ESHAPE, "bad sizes (rows=%d must be a multiple of seq_len=%d)", rows, seq_len);
+    if (rows > 65535) return fail(AMQ_ESHAPE, "rows=%d exceeds one launch (65535)", rows);
+    return check_hip(amq::launch_rope_rows(q, k, rope_table, rope_rows, pos0, rows, seq_len, n_heads, n_kv_heads,
+                                           (hipStream_t)stream), "rope_rows");
+}
+
 int amq_silu_mul_f16(const void* gate, const void* up, void* out, size_t n, void* stream) {
     if (!gate || !up || !out) return fail(AMQ_EINVAL, "null pointer");
     if (n == 0 || (n & 7)) return fail(AMQ_ESHAPE, "n must be a positive multiple of 8 (got %zu)", n);

@@ -541,6 +541,28 @@ hipError_t launch_rope_cache(void* q, const void* k, const void* v, void* kcache
     return hipGetLastError();
 }
 
+// RoPE in place on q AND k for `rows` rows that are `rows / seq_len` sequences of seq_len positions each (batched prompt
+// pass without a cache: the reference harness' GeMM mode at batch > 1): position of row s = pos0 + s % seq_len.
+__global__ __launch_bounds__(64) void rope_rows_kernel(_Float16* q, _Float16* k, const h2* tab, int rope_rows, int pos0, int seq_len,
+                                                       int nh, int nkv) {
+    const int i = threadIdx.x, hx = blockIdx.x;
+    const long s = blockIdx.y;
+    const int pos = pos0 + (int)(s % seq_len);
+    const h2 cs = tab[(size_t)(pos < rope_rows ? pos : rope_rows - 1) * 64 + i];
+    const _Float16 c16 = cs.x, s16 = cs.y;
+    _Float16* row = hx < nh ? q + ((size_t)s * nh + hx) * ATT_D : k + ((size_t)s * nkv + (hx - nh)) * ATT_D;
+    const _Float16 a0 = row[i], a1 = row[i + 64];
+    row[i] = a0 * c16 + (-a1) * s16;
+    row[i + 64] = a1 * c16 + a0 * s16;
+}
+
+hipError_t launch_rope_rows(void* q, void* k, const void* rope_table, int rope_rows, int pos0, int rows, int seq_len, int n_heads,
+                            int n_kv_heads, hipStream_t st) {
+    hipLaunchKernelGGL(rope_rows_kernel, dim3(n_heads + n_kv_heads, rows), dim3(64), 0, st, (_Float16*)q, (_Float16*)k,
+                       (const h2*)rope_table, rope_rows, pos0, seq_len, n_heads, n_kv_heads);
+    return hipGetLastError();
+}
+
 // out = fp16(silu(gate)) * up, 8 elements per thread (the GEMV SiLU prologue's expression, for many-row launches)
 __global__ __launch_bounds__(256) void silu_mul_kernel(const h8* g, const h8* u, h8* o, long n8) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;

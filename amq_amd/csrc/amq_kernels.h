@@ -85,6 +85,8 @@ hipError_t launch_rmsnorm_xfrag(const void* x, const void* gamma, void* xf, int 
 // prefill glue (amq_decode.hip)
 hipError_t launch_rope_cache(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
                              int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int max_seq, hipStream_t st);
+hipError_t launch_rope_rows(void* q, void* k, const void* rope_table, int rope_rows, int pos0, int rows, int seq_len, int n_heads,
+                            int n_kv_heads, hipStream_t st);
 hipError_t launch_silu_mul(const void* gate, const void* up, void* out, long n, hipStream_t st);
 hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, int hidden, void* token, void* pos, void* x,
                               const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st);

@@ -283,6 +283,42 @@ class QuantLlama:
             x = lin(blk["mlp.down_proj"], ops.silu_mul(g, u, out=g), residual=x)
         return self._prefill_finish(x, S)
 
+    def _rows_linear(self, l, inp, residual=None):
+        # y = inp . W^T (+ residual, in place) for many rows
+        return ops.gemm(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, residual=residual, out=residual)
+
+    def prefill_batch(self, ids):
+        """ids: int64 [B, S].  The many-row pass over B prompts at once (B*S rows through every linear): what the reference
+        harness times in GeMM mode with batch_size > 1 (amq/utils/speed.py:61-71; BASELINE.json configs[3] = 16 x 2048 on
+        13B).  Returns the last-token logits [B, vocab].  The runner's KV cache is batch-1 (like the reference's FT path),
+        so this pass does not write it and cannot be followed by decode steps."""
+        B, S = ids.shape
+        if S > self.max_seq:
+            raise ValueError("prompt longer than the RoPE table")
+        H, nh, nkv, M = self.H, self.nh, self.nkv, B * S
+        x = self.embed.index_select(0, ids.reshape(-1).to(self.dev))
+
+        lin = self._rows_linear
+        sdpa = torch.nn.functional.scaled_dot_product_attention
+        for blk in self.blocks:
+            h = ops.rmsnorm(x, blk["ln1"], self.eps)
+            q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
+            ops.rope_rows(q, k, self.rope_tab, S, nh, nkv)
+            qh = q.view(B, S, nh, 128).transpose(1, 2)
+            kh, vh = k.view(B, S, nkv, 128).transpose(1, 2), v.view(B, S, nkv, 128).transpose(1, 2)
+            if nkv != nh:
+                kh, vh = kh.repeat_interleave(nh // nkv, dim=1), vh.repeat_interleave(nh // nkv, dim=1)
+            a = sdpa(qh, kh, vh, is_causal=True).transpose(1, 2).reshape(M, H).contiguous()
+            x = lin(blk["self_attn.o_proj"], a, residual=x)
+            h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
+            g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
+            x = lin(blk["mlp.down_proj"], ops.silu_mul(g, u, out=g), residual=x)
+        last = x.view(B, S, H)[:, S - 1].contiguous()
+        logits = torch.empty(B, self.vocab, dtype=torch.float16, device=self.dev)
+        for b in range(B):
+            ops.gemv_f16w(last[b], self.lm_head, gamma=self.norm, eps=self.eps, out=logits[b])
+        return logits
+
     def _prefill_attention(self, q, blk, S, heads_first=False):
         # q: [S, nh*128] rotated; K/V: the cache rows just written
         nh, nkv = self.nh, self.nkv
@@ -415,6 +451,11 @@ class DenseLlama(QuantLlama):
                              blk["mlp.down_proj"])
         ops.gemv_f16w(x.reshape(-1).contiguous(), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
+
+    def _rows_linear(self, w, inp, residual=None):
+        if residual is None:
+            return torch.nn.functional.linear(inp, w)
+        return torch.addmm(residual, inp, w.t(), out=residual)
 
     def _prefill_eager(self, ids):
         F = torch.nn.functional

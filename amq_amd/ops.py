@@ -330,6 +330,16 @@ def rope_cache(q, k, v, kcache, vcache, table, pos0, n_heads, n_kv_heads):
                                               kcache.shape[1], _lib.current_stream()))
 
 
+def rope_rows(q, k, table, seq_len, n_heads, n_kv_heads, pos0=0):
+    """RoPE in place on q [rows, n_heads*128] and k [rows, n_kv_heads*128], rows = batch * seq_len (no cache)."""
+    rows = q.shape[0]
+    _need(q, torch.float16, "q", rows * n_heads * 128)
+    _need(k, torch.float16, "k", rows * n_kv_heads * 128)
+    _need(table, torch.float16, "rope table")
+    _lib.check(_lib.load().amq_rope_rows_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(table), table.numel() // 128, int(pos0), rows,
+                                             int(seq_len), n_heads, n_kv_heads, 128, _lib.current_stream()))
+
+
 def silu_mul(gate, up, out=None):
     """fp16(silu(gate)) * up (LlamaMLP activation), the same expression as the GEMV SiLU prologue."""
     _need(gate, torch.float16, "gate")

@@ -69,6 +69,36 @@ def benchmark_gemv_gemm(model, input_ids, gen_seq_len, iteration, mode="gemv"):
 
 
 @torch.inference_mode()
+def _benchmark_gemm_batch(model, sizes, iteration, get_peak_memory):
+    """GeMM mode at batch_size > 1 (speed.py:61-71, 95-105): 1 / median latency of the batched prompt pass."""
+    batch_size, input_seq_len, gen_seq_len = sizes
+    device = model.dev
+    data = {"gemm": {}}
+    if get_peak_memory:
+        cleanup()
+        torch.cuda.reset_peak_memory_stats(device=device)
+        data["peak_memory"] = {}
+    input_ids = torch.randint(0, model.vocab - 1, (batch_size, input_seq_len), dtype=torch.long).to(device)
+    device_warmup(device)
+    model.prefill_batch(input_ids)                       # allocator warm-up
+    times = []
+    for _ in range(iteration):
+        cleanup()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.prefill_batch(input_ids)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    key = f"{batch_size}.{input_seq_len}.{gen_seq_len}"
+    data["gemm"][key] = float(1 / np.median(times))
+    if get_peak_memory:
+        data["peak_memory"][key] = torch.cuda.max_memory_allocated(device=device) / 1024 ** 3
+    torch.cuda.reset_peak_memory_stats(device=device)
+    cleanup()
+    return data
+
+
+@torch.inference_mode()
 def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 128, 128), mode="TPS", get_peak_memory=True):
     """speed.py:131-255.  ``model``: a runner with reset()/prefill()/decode_step()/generate()
     (QuantLlama or DenseLlama).  ``tokenizer`` / ``use_ft`` are accepted for signature parity."""
@@ -76,7 +106,13 @@ def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 1
         "speed benchmark mode should be one of ['TPS', 'GeMV', 'GeMM', 'TTFT']"
     batch_size, input_seq_len, gen_seq_len = sizes
     if batch_size != 1:
-        raise NotImplementedError("the static KV cache is batch 1 (as in the reference's FT path)")
+        # the static KV cache is batch 1 (as in the reference's FT path, ftllama_modeling.py:61-68): batches are served
+        # for the prompt pass only (GeMM mode), which needs no cache
+        if mode.lower() != "gemm":
+            raise NotImplementedError("batch_size > 1 is supported in GeMM mode only (the static KV cache is batch 1)")
+        if input_seq_len > model.max_seq:
+            raise ValueError("sizes do not fit the model's RoPE table")
+        return _benchmark_gemm_batch(model, sizes, iteration, get_peak_memory)
     if input_seq_len + gen_seq_len > model.max_seq:
         raise ValueError("sizes do not fit the model's KV cache")
     device = model.dev

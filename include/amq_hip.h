@@ -233,6 +233,11 @@ int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qweight_n
  * rotation inside amq_attn_decode_f16. */
 int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
                        int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int head_dim, int max_seq, void* stream);
+/* RoPE in place on q [rows, n_heads*128] and k [rows, n_kv_heads*128] for rows = batch * seq_len (no cache write):
+ * position of row s = pos0 + s % seq_len.  For the batched prompt pass of the harness' GeMM mode (amq/utils/speed.py:61-71
+ * with batch_size > 1, BASELINE.json configs[3]). */
+int amq_rope_rows_f16(void* q, void* k, const void* rope_table, int rope_rows, int pos0, int rows, int seq_len, int n_heads,
+                      int n_kv_heads, int head_dim, void* stream);
 /* out = fp16(silu(gate)) * up elementwise, n fp16 elements (n % 8 == 0): the LlamaMLP activation between up/gate and down */
 int amq_silu_mul_f16(const void* gate, const void* up, void* out, size_t n, void* stream);
 

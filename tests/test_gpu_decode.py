@@ -375,3 +375,36 @@ def test_speed_benchmark_cli_with_reference_checkpoints(tmp_path, monkeypatch):
     with pytest.raises(FileNotFoundError):
         speed_benchmark.main(["--model_name", "tiny-llama", "--save_path", str(save), "--gemv", "--skip_fp16",
                               "--seq_length", "8", "--gen_length", "4", "--target_bits", "3.0", "--arch_path", str(stats)])
+
+
+@pytest.mark.parametrize("gqa", [False, True])
+def test_prefill_batch_matches_single_sequence_passes(gqa):
+    """the batched prompt pass (GeMM mode at batch_size > 1) gives each sequence the logits of its own single-sequence pass"""
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama, DenseLlama
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 2 if gqa else 4, 1, vocab=1024))
+    m = QuantLlama(cfg, None, device="cuda:0", max_seq=64, seed=4)
+    ids = torch.randint(0, 1024, (3, 40), generator=torch.Generator().manual_seed(9)).to(_dev())
+    got = m.prefill_batch(ids)
+    assert got.shape == (3, 1024)
+    for b in range(3):
+        m.reset()
+        ref = m.prefill(ids[b], use_graph=False).float()
+        assert (got[b].float() - ref).abs().max() <= 1e-2 * ref.abs().max()
+    d = DenseLlama(cfg, device="cuda:0", max_seq=64, seed=4)
+    gd = d.prefill_batch(ids)
+    d.reset()
+    rd = d.prefill(ids[1], use_graph=False).float()
+    assert (gd[1].float() - rd).abs().max() <= 1e-2 * rd.abs().max()
+
+
+def test_speed_harness_gemm_mode_batched():
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama
+    from amq_amd.speed import benchmark_speed
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 4, 1, vocab=1024))
+    m = QuantLlama(cfg, None, device="cuda:0", max_seq=64, seed=4)
+    r = benchmark_speed(m, iteration=2, sizes=(4, 32, 8), mode="GeMM", get_peak_memory=True)
+    assert r["gemm"]["4.32.8"] > 0 and r["peak_memory"]["4.32.8"] > 0
+    with pytest.raises(NotImplementedError):
+        benchmark_speed(m, iteration=1, sizes=(4, 32, 8), mode="TPS", get_peak_memory=False)
