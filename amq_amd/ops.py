@@ -5,6 +5,7 @@ a kernel is launched (shape/dtype/contiguity), because an out-of-bounds access
 in a hand-written kernel can take the GPU down.
 """
 import ctypes
+import os
 
 import torch
 
@@ -94,10 +95,12 @@ def _check_native(qn, mn, bits, N, K):
     _need(mn, torch.float16, "meta_native", mb // 2)
 
 
-def dequantize(qn, mn, bits, mode, N, K):
+def dequantize(qn, mn, bits, mode, N, K, out=None):
     _check_shape(bits, N, K)
     _check_native(qn, mn, bits, N, K)
-    out = torch.empty(N, K, dtype=torch.float16, device=qn.device)
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.float16, device=qn.device)
+    _need(out, torch.float16, "out", N * K)
     _lib.check(_lib.load().amq_dequantize_f16(bits, mode, _lib.ptr(qn), _lib.ptr(mn), N, K, GROUP,
                                               _lib.ptr(out), _lib.current_stream()))
     return out
@@ -155,9 +158,28 @@ def _splitk_workspace(device, nbytes):
     return ws
 
 
+# Rows from which `gemm` hands the (bit-exactly) dequantized weights to the library GEMM instead of running the fused
+# unpack + MFMA kernel.  In the MFMA-bound regime the unpack is pure overhead: the dequantize kernel costs 10-30 us per
+# layer once, hipBLASLt then runs at 1.45-1.5 PFLOP/s where the fused kernel reaches 1.0-1.05 (tools/lib_gemm_crossover.py:
+# 5120x5120, M = 1024 / 2048 / 4096 / 32768: 69 / 104 / 189 / 1196 us against 76 / 137 / 224 / 1708).  This is also what the
+# reference does from 128 rows on (GPTQLinear.forward: torch unpack + matmul, hqq/backends/autogptq.py:245-283).  0 disables.
+LIB_GEMM_ROWS = int(os.environ.get("AMQ_LIB_GEMM_ROWS", "1024"))
+_DEQ_SCRATCH = {}
+
+
+def _dequant_scratch(device, numel):
+    """per-device fp16 scratch for one dequantized weight matrix (grown on demand, reused by every launch on the stream)"""
+    w = _DEQ_SCRATCH.get(device)
+    if w is None or w.numel() < numel:
+        w = _DEQ_SCRATCH[device] = torch.empty(numel, dtype=torch.float16, device=device)
+    return w[:numel]
+
+
 def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None):
-    """y = x . W^T for any number of rows (MFMA tiles; split-K when few rows would leave the chip idle).
-    ``residual`` (fp16 [M, N], may be ``out``) is added in the epilogue: y = residual + fp16(x . W^T (+ bias))."""
+    """y = x . W^T for any number of rows: few-row kernel, tiled MFMA kernel (split-K when few rows would leave the chip
+    idle), or -- from LIB_GEMM_ROWS rows -- dequantize kernel + library GEMM.
+    ``residual`` (fp16 [M, N], may be ``out``) is added in the epilogue: y = residual + fp16(x . W^T (+ bias))
+    (the library path rounds the sum once)."""
     _check_shape(bits, N, K)
     _check_native(qn, mn, bits, N, K)
     x2 = _prep_x(x, K)
@@ -169,6 +191,22 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None):
     y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=x.device)
     _need(y, torch.float16, "y", M * N)
     lib = _lib.load()
+    if LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
+        w = dequantize(qn, mn, bits, mode, N, K, out=_dequant_scratch(x.device, N * K).view(N, K))
+        y2 = y.view(M, N)
+        if residual is not None:
+            r2 = residual.view(M, N)
+            if r2.data_ptr() == y2.data_ptr():
+                y2.addmm_(x2, w.t())
+            else:
+                torch.addmm(r2, x2, w.t(), out=y2)
+            if bias is not None:
+                y2.add_(bias)
+        elif bias is not None:
+            torch.addmm(bias, x2, w.t(), out=y2)
+        else:
+            torch.matmul(x2, w.t(), out=y2)
+        return y.reshape(*x.shape[:-1], N)
     need = lib.amq_gemm_splitk_workspace_bytes(M, N, K)
     ws = _splitk_workspace(x.device, need) if need else None
     _lib.check(lib.amq_gemm_res_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias), _lib.ptr(residual),

@@ -462,3 +462,35 @@ def test_gemm_xfrag(bits, m, n, k):
     inplace = res.clone()
     ops.gemm_xfrag(xf, m, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=inplace, out=inplace)
     assert torch.equal(inplace, res + y)
+
+
+@pytest.mark.parametrize("bits,m,n,k", [(3, 1024, 1024, 2048), (4, 1500, 512, 1024), (2, 2048, 1280, 512)])
+def test_gemm_library_path_matches_fused_kernel(bits, m, n, k, monkeypatch):
+    """from ops.LIB_GEMM_ROWS rows `gemm` runs dequantize kernel + library GEMM: same fp16 weights, fp32 accumulation,
+    so it agrees with the fused unpack + MFMA kernel to summation-order / rounding-order distance; bias and residual
+    (separate and in place) included"""
+    from amq_amd import ops
+    h, qn, mn, w_ref = _random_case(bits, n, k, seed=5 * bits + m, bias=True)
+    dev = _dev()
+    gen = torch.Generator().manual_seed(m)
+    x = torch.randn(m, k, generator=gen).half().to(dev)
+    res = torch.randn(m, n, generator=gen).half().to(dev)
+    bias = h.bias.to(dev)
+    assert m >= ops.LIB_GEMM_ROWS > 0
+    lib = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k)
+    lib_b = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias)
+    lib_r = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=res)
+    inplace = res.clone()
+    ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=inplace, out=inplace)
+    assert torch.equal(inplace, lib_r)
+    monkeypatch.setattr(ops, "LIB_GEMM_ROWS", 0)
+    own = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k)
+    own_r = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=res)
+    ref = x.float() @ ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).float().t()
+    rms = ref.pow(2).mean().sqrt()
+    assert torch.all((lib.float() - own.float()).abs() <= 2.0 ** -10 * ref.abs() + 1e-3 * rms)
+    _assert_close(lib.cpu().numpy(), linear_ref.linear_f16(x.cpu().numpy(), w_ref, None), f"library path {bits}b M={m}")
+    full = ref + bias.float() + res.float()
+    for got in (lib_r, own_r):                              # one rounding (library) / three roundings (fused), same target
+        assert torch.all((got.float() - full).abs() <= 3 * 2.0 ** -10 * (ref.abs() + bias.float().abs() + res.float().abs()) + 1e-3 * rms)
+    assert torch.all((lib_b.float() - (ref + bias.float())).abs() <= 2.0 ** -10 * (ref.abs() + bias.float().abs()) + 1e-3 * rms)

@@ -96,11 +96,13 @@ def main():
     ap.add_argument("--gemm_shape", default="5120,5120", help="N,K of the GEMM table")
     ap.add_argument("--gemm_bits", default="4,3,2")
     ap.add_argument("--gemm_fn", default="gemm", help="gemm | gemm_xfrag")
+    ap.add_argument("--lib_gemm_rows", type=int, default=0, help="ops.LIB_GEMM_ROWS (0: always time the own kernels)")
     args = ap.parse_args()
     global HOT, ZERO
     HOT = bool(args.hot)
     ZERO = bool(args.zero)
     from amq_amd import _lib
+    ops.LIB_GEMM_ROWS = args.lib_gemm_rows
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DOT, args.dot))
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_WAVES, args.waves))
     _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DEPTH, args.depth))

@@ -4,6 +4,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from amq_amd import ops
+ops.LIB_GEMM_ROWS = 0        # time / check the fused unpack + MFMA kernel itself
 from amq_amd.hqq_format import random_hqq
 m, n, k, bits = (int(v) for v in sys.argv[1:5])
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10

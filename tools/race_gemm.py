@@ -2,7 +2,8 @@
 """repeat one GEMM shape many times through the split-K and the single-pass entry points; report mismatching launches"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from amq_amd import ops, _lib
+from amq_amd import ops
+ops.LIB_GEMM_ROWS = 0        # time / check the fused unpack + MFMA kernel itself, _lib
 from amq_amd.hqq_format import random_hqq
 dev = torch.device("cuda:0")
 lib = _lib.load()
