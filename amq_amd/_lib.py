@@ -60,7 +60,7 @@ SIGNATURES = {
     "amq_xfrag_bytes": (_sz, [_i, _i]),
     "amq_xfrag_f16": (_i, [_vp, _vp, _i, _i, ctypes.c_longlong, ctypes.c_longlong, _vp]),
     "amq_rmsnorm_xfrag_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
-    "amq_gemm_xfrag_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "amq_gemm_xfrag_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_silu_mul_f16": (_i, [_vp, _vp, _vp, _sz, _vp]),

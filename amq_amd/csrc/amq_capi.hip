@@ -245,13 +245,14 @@ int amq_rmsnorm_xfrag_f16(const void* x, const void* gamma, void* xf, int M, int
 }
 
 int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qn, const void* mn, const void* bias,
-                       const void* residual, void* y, int M, int N, int K, int group, int y_stride, void* stream) {
+                       const void* gate, const void* residual, void* y, int M, int N, int K, int group, int y_stride,
+                       void* stream) {
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!xf || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     if ((M + 63) / 64 > 65535) return fail(AMQ_ESHAPE, "M=%d exceeds one launch", M);
-    amq::GemmArgs a{xf, qn, mn, bias, y, M, N, K, bits, mode, K, y_stride ? y_stride : N, nullptr, 1, residual};
+    amq::GemmArgs a{xf, qn, mn, bias, y, M, N, K, bits, mode, K, y_stride ? y_stride : N, nullptr, 1, residual, gate};
     return check_hip(amq::launch_gemm_xfrag(a, (hipStream_t)stream), "gemm_xfrag");
 }
 

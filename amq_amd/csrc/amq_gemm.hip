@@ -317,6 +317,7 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(GemmArgs a) {
     __syncthreads();
     const _Float16* bias = (const _Float16*)a.bias;
     const _Float16* res = (const _Float16*)a.residual;
+    const _Float16* gate = (const _Float16*)a.gate;
     _Float16* y = (_Float16*)a.y;
     for (int idx = wave; idx < MB * NSUB; idx += NWV) {
         const int mb = idx / NSUB, nb = idx % NSUB;
@@ -335,6 +336,10 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(GemmArgs a) {
             if (m < a.M) {
                 _Float16 v = (_Float16)s[i];
                 if (bias) v = v + bias[n];
+                if (gate) {                                    // act = fp16(silu(gate)) * up   (silu_mul_kernel's expression)
+                    const float gf = (float)gate[(size_t)m * a.y_stride + n];
+                    v = (_Float16)(gf / (1.0f + __expf(-gf))) * v;
+                }
                 if (res) v = res[(size_t)m * a.y_stride + n] + v;
                 y[(size_t)m * a.y_stride + n] = v;
             }

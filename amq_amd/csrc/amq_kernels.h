@@ -54,6 +54,7 @@ struct GemmArgs {
     float* ws;      // split-K partials [splits][M][N] fp32 (or null)
     int splits;     // >= 1
     const void* residual;   // fp16 [M, y_stride] added to the rounded result (y = residual + fp16(acc (+ bias))), or null
+    const void* gate;       // few-row kernel only: fp16 [M, y_stride]; y = fp16(silu(gate)) * fp16(acc (+ bias)) (LlamaMLP), or null
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st);
 hipError_t launch_gemm_xfrag(const GemmArgs& a, hipStream_t st);     // a.x in fragment order (launch_xfrag)

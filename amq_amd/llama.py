@@ -256,8 +256,9 @@ class QuantLlama:
             y = ops.linear(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K)
             return y if residual is None else residual.add_(y)
 
-        def lin_xf(l, xf, residual=None):
-            return ops.gemm_xfrag(xf, S, l.qn, l.mn, l.bits, l.mode, l.N, l.K, residual=residual, out=residual)
+        def lin_xf(l, xf, residual=None, gate=None):
+            return ops.gemm_xfrag(xf, S, l.qn, l.mn, l.bits, l.mode, l.N, l.K, residual=residual, gate=gate,
+                                  out=residual if residual is not None else gate)
 
         # up to 256 rows the projections that read a normed / attention activation take it in fragment order (written
         # that way by the producing launch): 1.2-1.6x faster few-row GEMMs; down_proj (K = 11008: the
@@ -275,12 +276,14 @@ class QuantLlama:
                 a = self._prefill_attention(q, blk, S, heads_first=True)            # [nh, S, 128], any strides
                 x = lin_xf(blk["self_attn.o_proj"], ops.xfrag(a, S, H, stride_m=a.stride(1), stride_kt=a.stride(0)), residual=x)
                 h2 = ops.rmsnorm_xfrag(x, blk["ln2"], self.eps)
-                g, u = lin_xf(blk["mlp.gate_proj"], h2), lin_xf(blk["mlp.up_proj"], h2)
+                g = lin_xf(blk["mlp.gate_proj"], h2)
+                act = lin_xf(blk["mlp.up_proj"], h2, gate=g)                       # silu(gate) * up in up_proj's epilogue
             else:
                 x = lin(blk["self_attn.o_proj"], self._prefill_attention(q, blk, S), residual=x)
                 h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
                 g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
-            x = lin(blk["mlp.down_proj"], ops.silu_mul(g, u, out=g), residual=x)
+                act = ops.silu_mul(g, u, out=g)
+            x = lin(blk["mlp.down_proj"], act, residual=x)
         return self._prefill_finish(x, S)
 
     def _rows_linear(self, l, inp, residual=None):

@@ -242,8 +242,9 @@ def rmsnorm_xfrag(x, gamma, eps, out=None):
     return xf
 
 
-def gemm_xfrag(xf, M, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None):
-    """y[M, N] = x . W^T with x given in fragment order (:func:`xfrag`); ``residual`` as in :func:`gemm`."""
+def gemm_xfrag(xf, M, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, gate=None):
+    """y[M, N] = x . W^T with x given in fragment order (:func:`xfrag`); ``residual`` as in :func:`gemm`;
+    ``gate`` (fp16 [M, N], may be ``out``): y = fp16(silu(gate)) * fp16(x . W^T (+ bias)), i.e. :func:`silu_mul` fused."""
     _check_shape(bits, N, K)
     _check_native(qn, mn, bits, N, K)
     _need(xf, torch.float16, "xf", _lib.load().amq_xfrag_bytes(M, K) // 2)
@@ -251,10 +252,13 @@ def gemm_xfrag(xf, M, qn, mn, bits, mode, N, K, bias=None, out=None, residual=No
         _need(bias, torch.float16, "bias", N)
     if residual is not None:
         _need(residual, torch.float16, "residual", M * N)
+    if gate is not None:
+        _need(gate, torch.float16, "gate", M * N)
     y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=xf.device)
     _need(y, torch.float16, "y", M * N)
     _lib.check(_lib.load().amq_gemm_xfrag_f16(bits, mode, _lib.ptr(xf), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
-                                              _lib.ptr(residual), _lib.ptr(y), M, N, K, GROUP, 0, _lib.current_stream()))
+                                              _lib.ptr(gate), _lib.ptr(residual), _lib.ptr(y), M, N, K, GROUP, 0,
+                                              _lib.current_stream()))
     return y
 
 

@@ -219,14 +219,16 @@ int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qweight_nati
  * operand:  xf[g][kt][mb*4 + t][lane = 16*o + r][8] = x[g*64 + mb*16 + r][kt*128 + 32*t + 8*o .. +8]  (rows >= M zero),
  * amq_xfrag_bytes(M, K) bytes.  Source element (m, k) is read at src[m*stride_m + (k/128)*stride_kt + k%128] (halves):
  * row-major [M, K]: stride_m = K (or more), stride_kt = 128; an attention output [heads, M, 128]: 128, M*128.
- * amq_gemm_xfrag_f16 = amq_gemm_res_f16 reading such a buffer (any M; no workspace). */
+ * amq_gemm_xfrag_f16 = amq_gemm_res_f16 reading such a buffer (any M; no workspace), plus an optional SiLU gate. */
 size_t amq_xfrag_bytes(int M, int K);
 int amq_xfrag_f16(const void* src, void* xf, int M, int K, long long stride_m, long long stride_kt, void* stream);
 /* amq_rmsnorm_f16 (rows of K, contiguous) writing its result in fragment order */
 int amq_rmsnorm_xfrag_f16(const void* x, const void* gamma, void* xf, int M, int K, float eps, void* stream);
+/* gate (fp16 [M, y_stride] or NULL, may alias y): y = fp16(silu(gate)) * fp16(x . W^T (+ bias)) -- the LlamaMLP product
+ * act_fn(gate_proj(x)) * up_proj(x) formed in up_proj's epilogue (same expression as amq_silu_mul_f16) */
 int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qweight_native, const void* meta_native,
-                       const void* bias, const void* residual, void* y, int M, int N, int K, int group, int y_stride,
-                       void* stream);
+                       const void* bias, const void* gate, const void* residual, void* y, int M, int N, int K, int group,
+                       int y_stride, void* stream);
 /* RoPE + KV-cache write for S new rows at positions pos0 .. pos0+S-1 of ONE sequence: q fp16 [S, n_heads*128] is
  * rotated in place; k [S, n_kv_heads*128] is rotated into kcache[h][pos0+s][:], v copied into vcache (both
  * [n_kv_heads, max_seq, 128]); rope_table from amq_rope_table_f16 (rows past rope_rows-1 clamp).  Same numerics as the

@@ -462,6 +462,12 @@ def test_gemm_xfrag(bits, m, n, k):
     inplace = res.clone()
     ops.gemm_xfrag(xf, m, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=inplace, out=inplace)
     assert torch.equal(inplace, res + y)
+    gate = (3 * torch.randn(m, n, generator=gen)).to(torch.float16).to(dev)
+    act = ops.gemm_xfrag(xf, m, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, gate=gate)
+    assert torch.equal(act, ops.silu_mul(gate, y))            # the fused epilogue = the separate launch, bit for bit
+    gio = gate.clone()
+    ops.gemm_xfrag(xf, m, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, gate=gio, out=gio)
+    assert torch.equal(gio, act)
 
 
 @pytest.mark.parametrize("bits,m,n,k", [(3, 1024, 1024, 2048), (4, 1500, 512, 1024), (2, 2048, 1280, 512)])
