@@ -16,8 +16,8 @@ AMQ_OK = 0
 MODE_HQQ, MODE_FMA = 0, 1
 PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
-OPT_GEMV_DOT, OPT_GEMV_WAVES, OPT_GEMV_DEPTH, OPT_GEMV_RPT, OPT_GEMV_MATH, OPT_GEMM_NSUB, OPT_GEMM_SKINNY_MAX = 1, 2, 3, 4, 5, 6, 7
 MATH_EXACT, MATH_LINEAR = 0, 1
+GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING = 0, 1, 2, 3
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
@@ -28,11 +28,15 @@ class Segment(ctypes.Structure):
                 ("y", _vp), ("N", _i), ("bits", _i), ("mode", _i), ("y_stride", _i)]
 
 
+class GemvOpts(ctypes.Structure):
+    """mirror of `amq_gemv_opts` (include/amq_hip.h): per-call launch options, all zero = defaults"""
+    _fields_ = [("math", _i), ("waves", _i), ("depth", _i), ("rpt", _i), ("dot", _i)]
+
+
 # name -> (restype, argtypes); must list every symbol include/amq_hip.h declares
 SIGNATURES = {
     "amq_version": (_i, []),
     "amq_last_error": (ctypes.c_char_p, []),
-    "amq_set_option": (_i, [_i, _i]),
     "amq_query": (_i, [_i, ctypes.POINTER(_i), _i]),
     "amq_native_qweight_bytes": (_sz, [_i, _i, _i]),
     "amq_native_meta_bytes": (_sz, [_i, _i, _i]),
@@ -64,7 +68,9 @@ SIGNATURES = {
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_silu_mul_f16": (_i, [_vp, _vp, _vp, _sz, _vp]),
-    "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp]),
+    "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, ctypes.POINTER(GemvOpts), _vp]),
+    "amq_gemm_route_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "amq_gemm_route_f16": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 _lib = None
@@ -93,11 +99,6 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
     _lib = lib
-    # A/B knobs from the environment (tools/, bench experiments): AMQ_GEMV_WAVES / _DEPTH / _RPT / _MATH
-    for env, opt in (("AMQ_GEMV_WAVES", OPT_GEMV_WAVES), ("AMQ_GEMV_DEPTH", OPT_GEMV_DEPTH), ("AMQ_GEMV_RPT", OPT_GEMV_RPT),
-                     ("AMQ_GEMV_MATH", OPT_GEMV_MATH), ("AMQ_GEMM_SKINNY_MAX", OPT_GEMM_SKINNY_MAX)):
-        if os.environ.get(env):
-            check(lib.amq_set_option(opt, int(os.environ[env])))
     return lib
 
 

@@ -25,9 +25,9 @@ def load_hqq_dir(path):
     """-> (hf_config dict, {module_name: HQQWeights | {'weight': tensor, ...}})"""
     with open(os.path.join(path, "config.json")) as f:
         hf = json.load(f)
-    # the file holds torch.Size / torch.dtype objects next to the tensors -> a full unpickle is required;
-    # only load checkpoints you produced or trust
-    raw = torch.load(os.path.join(path, "qmodel.pt"), map_location="cpu", weights_only=False)
+    # tensors + plain Python values + torch.Size / torch.dtype: all on torch's weights-only allow-list, so no arbitrary
+    # pickle code runs (the reference loads the same file the same way, hqq/models/base.py:254-257)
+    raw = torch.load(os.path.join(path, "qmodel.pt"), map_location="cpu", weights_only=True)
     out = {}
     for name, sd in raw.items():
         if "W_q" in sd:

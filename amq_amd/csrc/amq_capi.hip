@@ -38,11 +38,6 @@ int check_mode(int mode) {
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
-int g_opt_dot = 0;
-int g_opt_waves = 0;
-int g_opt_depth = 0;
-int g_opt_rpt = 0;
-int g_opt_math = 0;
 
 }  // namespace
 
@@ -50,41 +45,6 @@ extern "C" {
 
 int amq_version(void) { return AMQ_VERSION; }
 const char* amq_last_error(void) { return g_err; }
-
-int amq_set_option(int option, int value) {
-    if (option == AMQ_OPT_GEMV_DOT) { g_opt_dot = value ? 1 : 0; return AMQ_OK; }
-    if (option == AMQ_OPT_GEMV_WAVES) {
-        if (value != 0 && value != 4 && value != 8 && value != 16) return fail(AMQ_EINVAL, "waves must be 0, 4, 8 or 16");
-        g_opt_waves = value;
-        return AMQ_OK;
-    }
-    if (option == AMQ_OPT_GEMV_DEPTH) {
-        if (value != 0 && value != 2 && value != 4) return fail(AMQ_EINVAL, "depth must be 0, 2 or 4");
-        g_opt_depth = value;
-        return AMQ_OK;
-    }
-    if (option == AMQ_OPT_GEMM_NSUB) {
-        if (value != 0 && value != 2 && value != 4) return fail(AMQ_EINVAL, "gemm sub-tiles must be 0, 2 or 4");
-        amq::g_gemm_nsub = value;
-        return AMQ_OK;
-    }
-    if (option == AMQ_OPT_GEMM_SKINNY_MAX) {
-        if (value < 0 || value > 4096) return fail(AMQ_EINVAL, "skinny-GEMM row limit must be 0..4096");
-        amq::g_gemm_skinny_max = value;
-        return AMQ_OK;
-    }
-    if (option == AMQ_OPT_GEMV_RPT) {
-        if (value < 0 || value > 64) return fail(AMQ_EINVAL, "row-tiles per workgroup must be 0..64");
-        g_opt_rpt = value;
-        return AMQ_OK;
-    }
-    if (option == AMQ_OPT_GEMV_MATH) {
-        if (value != AMQ_MATH_EXACT && value != AMQ_MATH_LINEAR) return fail(AMQ_EINVAL, "math must be AMQ_MATH_EXACT or AMQ_MATH_LINEAR");
-        g_opt_math = value;
-        return AMQ_OK;
-    }
-    return fail(AMQ_EINVAL, "unknown option %d", option);
-}
 
 int amq_query(int K, int* out, int cap) {
     int vals[4];
@@ -139,16 +99,20 @@ int amq_dequantize_hqq_f16(int bits, const void* W_q, const void* scale, const v
 }
 
 int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const void* x2, const void* gamma,
-                         float eps, int prologue, int M, int K, int group, int x_stride, void* stream) {
+                         float eps, int prologue, int M, int K, int group, int x_stride, const amq_gemv_opts* opts,
+                         void* stream) {
     if (!segs || nseg < 1 || nseg > AMQ_MAX_SEGMENTS) return fail(AMQ_EINVAL, "nseg must be 1..%d (got %d)", AMQ_MAX_SEGMENTS, nseg);
     if (!x) return fail(AMQ_EINVAL, "null x");
     if (prologue < AMQ_PRO_NONE || prologue > AMQ_PRO_SILU_MUL) return fail(AMQ_EINVAL, "unknown prologue %d", prologue);
     if (prologue == AMQ_PRO_RMSNORM && !gamma) return fail(AMQ_EINVAL, "RMSNorm prologue needs gamma");
     if (prologue == AMQ_PRO_SILU_MUL && !x2) return fail(AMQ_EINVAL, "SiLU*mul prologue needs x2");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
-    int bitmask = 0;
-    for (int i = 0; i < nseg; ++i) bitmask |= 1 << (segs[i].bits & 7);
-    (void)bitmask;
+    amq_gemv_opts o{};                                   // all zero = defaults
+    if (opts) o = *opts;
+    if (o.math != AMQ_MATH_EXACT && o.math != AMQ_MATH_LINEAR) return fail(AMQ_EINVAL, "opts.math must be AMQ_MATH_EXACT or AMQ_MATH_LINEAR");
+    if (o.waves != 0 && o.waves != 4 && o.waves != 8 && o.waves != 16) return fail(AMQ_EINVAL, "opts.waves must be 0, 4, 8 or 16");
+    if (o.depth != 0 && o.depth != 2 && o.depth != 4) return fail(AMQ_EINVAL, "opts.depth must be 0, 2 or 4");
+    if (o.rpt < 0 || o.rpt > 64) return fail(AMQ_EINVAL, "opts.rpt (row-tiles per workgroup) must be 0..64");
     if (M > amq::GEMV_MAX_M || amq::gemv_lds_bytes(M, K, 1) > LDS_LIMIT)
         return fail(AMQ_ESHAPE, "M=%d rows of K=%d do not fit LDS for the GEMV path; use amq_gemm_f16", M, K);
     amq::GemvArgs a{};
@@ -164,10 +128,10 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     }
     a.nseg = nseg; a.M = M; a.K = K; a.x_stride = x_stride ? x_stride : K;
     a.x = x; a.x2 = x2; a.gamma = gamma; a.eps = eps; a.prologue = prologue;
-    a.flags = (g_opt_dot ? amq::GEMV_FLAG_DOT : 0) | (g_opt_math == AMQ_MATH_LINEAR ? amq::GEMV_FLAG_LINEAR : 0);
-    a.force_waves = g_opt_waves;
-    a.force_depth = g_opt_depth;
-    a.force_rpt = g_opt_rpt;
+    a.flags = (o.dot ? amq::GEMV_FLAG_DOT : 0) | (o.math == AMQ_MATH_LINEAR ? amq::GEMV_FLAG_LINEAR : 0);
+    a.force_waves = o.waves;
+    a.force_depth = o.depth;
+    a.force_rpt = o.rpt;
     return check_hip(amq::launch_gemv(a, (hipStream_t)stream), "gemv");
 }
 
@@ -176,7 +140,7 @@ int amq_gemv_f16(int bits, int mode, const void* x, const void* qn, const void* 
     amq_segment s{};
     s.qweight_native = qn; s.meta_native = mn; s.bias = bias; s.residual = nullptr; s.y = y;
     s.N = N; s.bits = bits; s.mode = mode; s.y_stride = y_stride;
-    return amq_gemv_grouped_f16(&s, 1, x, nullptr, nullptr, 0.f, AMQ_PRO_NONE, M, K, group, x_stride, stream);
+    return amq_gemv_grouped_f16(&s, 1, x, nullptr, nullptr, 0.f, AMQ_PRO_NONE, M, K, group, x_stride, nullptr, stream);
 }
 
 int amq_gemm_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
@@ -209,20 +173,35 @@ int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qn, const
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream), "gemm_splitk");
 }
 
-int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, const void* residual,
-                     void* y, int M, int N, int K, int group, int x_stride, int y_stride, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K) {
+    if (M < 1 || N < 1 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_RING) return 0;
+    const int s = amq::gemm_pick_splits(M, N, K, route);
+    return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
+                       const void* residual, void* y, int M, int N, int K, int group, int x_stride, int y_stride,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_RING) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
-    const size_t need = amq_gemm_splitk_workspace_bytes(M, N, K);
+    if (route == AMQ_GEMM_SKINNY && M > 64) return fail(AMQ_ESHAPE, "the few-row kernel takes at most 64 rows (got %d)", M);
+    const size_t need = amq_gemm_route_workspace_bytes(route, M, N, K);
     const bool split = need != 0 && workspace != nullptr;          // no workspace: single pass
     if (split && workspace_bytes < need)
         return fail(AMQ_EINVAL, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N,
-                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K) : 1, residual};
-    return check_hip(amq::launch_gemm(a, (hipStream_t)stream), "gemm_res");
+                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, route) : 1, residual};
+    return check_hip(amq::launch_gemm(a, (hipStream_t)stream, route), "gemm");
+}
+
+int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, const void* residual,
+                     void* y, int M, int N, int K, int group, int x_stride, int y_stride, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    return amq_gemm_route_f16(AMQ_GEMM_AUTO, bits, mode, x, qn, mn, bias, residual, y, M, N, K, group, x_stride, y_stride,
+                              workspace, workspace_bytes, stream);
 }
 
 size_t amq_xfrag_bytes(int M, int K) {

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logit
         stok = ix;
         token[0] = (long long)ix;
         spos = pos[0] + 1;
-        pos[0] = spos;
+        if (rope_cur && spos > rope_rows) spos = rope_rows;      // saturate at the end of the cache: the attention kernel
+        pos[0] = spos;                                           // treats pos == max_seq as "out of range" (no-op + error word)
     }
     __syncthreads();
     if (rope_cur && tid < 128) {                                      // cos/sin row of the new position (last row once the cache is full)
@@ -353,6 +354,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
         int t = grp + ATT_GROUPS * i;
         t = t < max_seq - 1 ? t : max_seq - 1;
         krow[i] = *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
+    }
+    // A position outside the cache (a graph replayed past max_seq, a corrupted step state) must not index the cache or
+    // the LDS score array: the whole workgroup leaves (pos is wave-uniform), nothing is appended or written, and in
+    // step-state mode the sticky error word at byte 260 of the block is raised for the host to read.
+    if (pos < 0 || pos >= max_seq) {
+        if (cur_mode && tid == 0) *(int*)((char*)const_cast<void*>(p_state) + 260) = 1;
+        return;
     }
     const int T = pos + 1;
     ATT_STAMP(1);

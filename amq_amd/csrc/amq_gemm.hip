@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, con
 //               already is an operand; LDS is used only for the final sum
 // Measured (MI355X, 3-bit, us per launch, skinny | tiled+split-K): 4096x4096  M=16 6.2|12.2  32 8.0|13.4  64 12.8|15.6;
 // 11008x4096  M=32 18.0|21.1  64 33.0|24.0;  4096x11008  M=32 18.0|19.8  64 29.9|20.9.
-int g_gemm_skinny_max = 32;      // rows up to which launch_gemm always takes this kernel (AMQ_OPT_GEMM_SKINNY_MAX; 0 disables)
+constexpr int GEMM_SKINNY_MAX = 32;      // rows up to which launch_gemm (GEMM_ROUTE_AUTO) always takes this kernel
 
 template <int BITS, int MB, int NSUB>
 struct SkinnyTile { h8 xr[MB * 4]; LanePayload<BITS> pay[NSUB]; h2 meta[NSUB]; };
@@ -433,8 +433,10 @@ static hipError_t skinny_launch(const GemmArgs& a, hipStream_t st) {
 // up to g_gemm_skinny_max rows always; up to twice that while the column blocks fit one round of workgroups and K is
 // short (measured above: at 64 rows the kernel wins for 4096x4096, loses for N = 11008 -- 688 workgroups, 2.7 rounds --
 // and for K = 11008 -- 1.4 MB of x per workgroup)
-static bool gemm_is_skinny(int M, int N, int K) {
-    return M <= g_gemm_skinny_max || (M <= 2 * g_gemm_skinny_max && M <= 64 && (N >> 4) <= 320 && K <= 6144);
+static bool gemm_is_skinny(int M, int N, int K, int route) {
+    if (route == GEMM_ROUTE_TILED || route == GEMM_ROUTE_RING) return false;
+    if (route == GEMM_ROUTE_SKINNY) return M <= 64;
+    return M <= GEMM_SKINNY_MAX || (M <= 2 * GEMM_SKINNY_MAX && M <= 64 && (N >> 4) <= 320 && K <= 6144);
 }
 
 // Split-K policy (profiles/r01c_gemm_split_sweep.txt, 3-bit, us at M = 64 / 128 / 256): up to 256 rows 64-column workgroups aiming at
@@ -442,19 +444,17 @@ static bool gemm_is_skinny(int M, int N, int K) {
 // per CU (15.6 / 18.2 / 24.6; 23.8 / 31.2 / 47.6; better from 512 rows on).
 static bool split_narrow(int M) { return M <= 256; }
 
-int gemm_pick_splits(int M, int N, int K) {
+int gemm_pick_splits(int M, int N, int K, int route) {
     const int bn = split_narrow(M) ? 64 : 128, target = split_narrow(M) ? 512 : 256;
     const long wg = (long)((M + 63) / 64) * ((N + bn - 1) / bn);      // 64-row tiles (what such launches use)
     const int G = K >> 7;
-    if (gemm_is_skinny(M, N, K)) return 1;                               // gemm_skinny_kernel: no partials
+    if (gemm_is_skinny(M, N, K, route)) return 1;                        // gemm_skinny_kernel: no partials
     if (wg >= target * 3 / 4 || G < 4 || (N & 7)) return 1;
     int s = (int)((target + wg - 1) / wg);
     if (s > 8) s = 8;
     if (s > G / 2) s = G / 2;
     return s < 1 ? 1 : s;
 }
-
-int g_gemm_nsub = 0;     // A/B knob: 0 = auto, 2 or 4
 
 template <int BITS, int MODE, int BM, int NSUB>
 static hipError_t gemm_launch_cfg(const GemmArgs& a, hipStream_t st) {
@@ -482,14 +482,12 @@ static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
     if (a.splits > 1 && split_narrow(a.M)) return gemm_launch_cfg<BITS, MODE, 64, 1>(a, st);
     if (a.M <= 64 || wg128 < 384 || a.splits > 1) return gemm_launch_cfg<BITS, MODE, 64, 2>(a, st);
     // measured (5120x5120, M = 4096 / 16384): NSUB = 2 -> 0.81 / 0.89-0.92 PFLOP/s; NSUB = 4 needs ~390 VGPRs
-    // (one wave per SIMD) and drops to 0.68 / 0.76 -- kept only as an A/B knob
-    const bool wide = (g_gemm_nsub == 4);
-    if (wide) return gemm_launch_cfg<BITS, MODE, 128, 4>(a, st);
+    // (one wave per SIMD) and dropped to 0.68 / 0.76 (variant removed)
     return gemm_launch_cfg<BITS, MODE, 128, 2>(a, st);
 }
 
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t st) {
-    if (gemm_is_skinny(a.M, a.N, a.K)) {
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route) {
+    if (gemm_is_skinny(a.M, a.N, a.K, route)) {
         if (a.mode == MODE_HQQ) {
             if (a.bits == 4) return skinny_launch<4, MODE_HQQ>(a, st);
             if (a.bits == 3) return skinny_launch<3, MODE_HQQ>(a, st);

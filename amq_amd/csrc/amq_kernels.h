@@ -56,12 +56,12 @@ struct GemmArgs {
     const void* residual;   // fp16 [M, y_stride] added to the rounded result (y = residual + fp16(acc (+ bias))), or null
     const void* gate;       // few-row kernel only: fp16 [M, y_stride]; y = fp16(silu(gate)) * fp16(acc (+ bias)) (LlamaMLP), or null
 };
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t st);
+// route: which kernel family serves the launch (AUTO: by shape; the others force one for tests / A-B tools)
+enum { GEMM_ROUTE_AUTO = 0, GEMM_ROUTE_TILED = 1, GEMM_ROUTE_SKINNY = 2, GEMM_ROUTE_RING = 3 };
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route = GEMM_ROUTE_AUTO);
 hipError_t launch_gemm_xfrag(const GemmArgs& a, hipStream_t st);     // a.x in fragment order (launch_xfrag)
 hipError_t launch_xfrag(const void* src, void* xf, int M, int K, long stride_m, long stride_kt, hipStream_t st);
-int gemm_pick_splits(int M, int N, int K);
-extern int g_gemm_nsub;
-extern int g_gemm_skinny_max;
+int gemm_pick_splits(int M, int N, int K, int route = GEMM_ROUTE_AUTO);
 
 // decode-step surroundings (amq_decode.hip)
 struct AttnArgs {

@@ -129,9 +129,10 @@ class QuantLlama:
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.rope_tab = ops.rope_table(max_seq, self.theta, dev)
         # step state: cos/sin row of self.pos + the position itself in one block (set_token / the step's tail keep it)
-        self.rope_cur, self.pos = ops.new_step_state(dev)
+        self.rope_cur, self.pos, self.step_err = ops.new_step_state(dev)
         self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
+        self.host_pos = 0          # host mirror of self.pos (decode_step refuses to run past the cache without a device sync)
 
     # ----------------------------------------------------------------- sizes
     def linear_bytes_per_token(self):
@@ -162,9 +163,21 @@ class QuantLlama:
         # argmax, pos += 1, x = embed[token], rope_cur = cos/sin row of the new position
         ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
 
+    def set_pos(self, pos):
+        """set the position of the next decode step (device state + its host mirror); follow with set_token()"""
+        pos = int(pos)
+        if not 0 <= pos <= self.max_seq:
+            raise ValueError(f"position {pos} outside the KV cache (max_seq={self.max_seq})")
+        self.pos.fill_(pos)
+        self.host_pos = pos
+
+    def check(self):
+        """raise if any decode step ran with its device-side position outside the cache (synchronises)"""
+        ops.check_step_state(self.step_err)
+
     def set_token(self, token):
         """make ``token`` (int or 1-element tensor) the input of the next decode step; also re-derives what the step
-        reads besides the token (embedding row, cos/sin row of the current position) -- set self.pos first"""
+        reads besides the token (embedding row, cos/sin row of the current position) -- set_pos() first"""
         if isinstance(token, torch.Tensor):
             self.token.copy_(token.reshape(1))
         else:
@@ -177,6 +190,8 @@ class QuantLlama:
         """capture one token step into a hipGraph (replayed by decode_step)"""
         if self.graph is not None:
             return
+        if self.host_pos >= self.max_seq:
+            raise ValueError(f"cannot capture a decode step at position {self.host_pos}: the KV cache holds {self.max_seq} rows")
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         saved = (self.token.clone(), self.pos.clone())
@@ -193,6 +208,11 @@ class QuantLlama:
         self.graph = g
 
     def decode_step(self, use_graph=True):
+        # the step appends cache row host_pos: refuse on the host (the kernels also guard the device-side position:
+        # a step past the cache is skipped there and raises the sticky error word, see check())
+        if self.host_pos >= self.max_seq:
+            raise ValueError(f"decode step at position {self.host_pos} does not fit the KV cache (max_seq={self.max_seq})")
+        self.host_pos += 1
         if use_graph:
             if self.graph is None:
                 self.capture()
@@ -338,7 +358,7 @@ class QuantLlama:
     def _prefill_finish(self, x, S):
         last = x[S - 1].contiguous()
         ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        self.pos.fill_(S)
+        self.set_pos(S)
         self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
         return self.logits
 
@@ -371,7 +391,7 @@ class QuantLlama:
         return self._prefill_finish(x, S)
 
     def reset(self):
-        self.pos.zero_()
+        self.set_pos(0)
         self.set_token(0)
 
     def generate(self, ids, gen_len, use_graph=True):
@@ -432,9 +452,10 @@ class DenseLlama(QuantLlama):
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.rope_tab = ops.rope_table(max_seq, self.theta, dev)
         # step state: cos/sin row of self.pos + the position itself in one block (set_token / the step's tail keep it)
-        self.rope_cur, self.pos = ops.new_step_state(dev)
+        self.rope_cur, self.pos, self.step_err = ops.new_step_state(dev)
         self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
+        self.host_pos = 0
 
     def linear_bytes_per_token(self):
         return sum(blk[name].numel() * 2 for blk in self.blocks for name in self.cfg["linear"])

@@ -10,7 +10,8 @@ import os
 import torch
 
 from . import _lib
-from ._lib import MODE_HQQ, MODE_FMA, PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL, Segment  # noqa: F401
+from ._lib import (MODE_HQQ, MODE_FMA, PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL, Segment, GemvOpts,  # noqa: F401
+                   GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, MATH_EXACT, MATH_LINEAR)
 
 GROUP = 128
 
@@ -132,8 +133,13 @@ def _prep_x(x, K):
     return x2
 
 
-def gemv(x, qn, mn, bits, mode, N, K, bias=None, out=None):
-    """y = x . W^T for few rows (weight-streaming kernels)."""
+def gemv(x, qn, mn, bits, mode, N, K, bias=None, out=None, opts=None):
+    """y = x . W^T for few rows (weight-streaming kernels).  ``opts``: a :class:`GemvOpts` (per-call A/B / math options)."""
+    if opts is not None:
+        x2 = _prep_x(x, K)
+        y = out if out is not None else torch.empty(x2.shape[0], N, dtype=torch.float16, device=x.device)
+        gemv_grouped(x2, [dict(qn=qn, mn=mn, bits=bits, mode=mode, N=N, y=y, bias=bias)], K, opts=opts)
+        return y.reshape(*x.shape[:-1], N)
     _check_shape(bits, N, K)
     _check_native(qn, mn, bits, N, K)
     x2 = _prep_x(x, K)
@@ -147,15 +153,34 @@ def gemv(x, qn, mn, bits, mode, N, K, bias=None, out=None):
     return y.reshape(*x.shape[:-1], N)
 
 
-_SPLITK_WS = {}
+class _ScratchPool:
+    """Grow-only device scratch, one buffer per (device, stream).  A buffer that has been handed out is NEVER freed:
+    a captured hipGraph (QuantLlama.prefill keeps one per prompt length) has the raw pointer baked in, so when a larger
+    request arrives the old block is retired into ``_keep`` instead of being dropped -- replaying an older graph then
+    still writes memory this pool owns.  Keyed by stream so that launches on different streams never share partials."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self._cur = {}
+        self._keep = []
+
+    def get(self, device, numel):
+        key = (device.index if device.index is not None else torch.cuda.current_device(),
+               torch.cuda.current_stream(device).cuda_stream)
+        t = self._cur.get(key)
+        if t is None or t.numel() < numel:
+            if t is not None:
+                self._keep.append(t)
+            t = self._cur[key] = torch.empty(numel, dtype=self.dtype, device=device)
+        return t
+
+
+_SPLITK_WS = _ScratchPool(torch.float32)
 
 
 def _splitk_workspace(device, nbytes):
-    """per-device scratch for split-K partials (grown on demand, reused by every launch on the stream)"""
-    ws = _SPLITK_WS.get(device)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = _SPLITK_WS[device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-    return ws
+    """scratch for split-K partials (see _ScratchPool)"""
+    return _SPLITK_WS.get(device, (nbytes + 3) // 4)
 
 
 # Rows from which `gemm` hands the (bit-exactly) dequantized weights to the library GEMM instead of running the fused
@@ -163,23 +188,27 @@ def _splitk_workspace(device, nbytes):
 # layer once, hipBLASLt then runs at 1.45-1.5 PFLOP/s where the fused kernel reaches 1.0-1.05 (tools/lib_gemm_crossover.py:
 # 5120x5120, M = 1024 / 2048 / 4096 / 32768: 69 / 104 / 189 / 1196 us against 76 / 137 / 224 / 1708).  This is also what the
 # reference does from 128 rows on (GPTQLinear.forward: torch unpack + matmul, hqq/backends/autogptq.py:245-283).  0 disables.
-LIB_GEMM_ROWS = int(os.environ.get("AMQ_LIB_GEMM_ROWS", "1024"))
-_DEQ_SCRATCH = {}
+LIB_GEMM_ROWS = 1024
+_DEQ_SCRATCH = _ScratchPool(torch.float16)
 
 
 def _dequant_scratch(device, numel):
-    """per-device fp16 scratch for one dequantized weight matrix (grown on demand, reused by every launch on the stream)"""
-    w = _DEQ_SCRATCH.get(device)
-    if w is None or w.numel() < numel:
-        w = _DEQ_SCRATCH[device] = torch.empty(numel, dtype=torch.float16, device=device)
-    return w[:numel]
+    """fp16 scratch for one dequantized weight matrix (see _ScratchPool)"""
+    return _DEQ_SCRATCH.get(device, numel)[:numel]
 
 
-def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None):
+def gemm_route_name(M):
+    """what :func:`gemm` runs for M rows under the current settings (for result files)"""
+    if LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
+        return "amq::dequant_kernel + library GEMM (torch.matmul -> hipBLASLt)"
+    return "amq::gemm_kernel family (fused unpack + MFMA, hand-written)"
+
+
+def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=GEMM_AUTO):
     """y = x . W^T for any number of rows: few-row kernel, tiled MFMA kernel (split-K when few rows would leave the chip
     idle), or -- from LIB_GEMM_ROWS rows -- dequantize kernel + library GEMM.
     ``residual`` (fp16 [M, N], may be ``out``) is added in the epilogue: y = residual + fp16(x . W^T (+ bias))
-    (the library path rounds the sum once)."""
+    (the library path rounds the sum once).  ``route`` != GEMM_AUTO forces one hand-written kernel family (tests, tools)."""
     _check_shape(bits, N, K)
     _check_native(qn, mn, bits, N, K)
     x2 = _prep_x(x, K)
@@ -191,7 +220,7 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None):
     y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=x.device)
     _need(y, torch.float16, "y", M * N)
     lib = _lib.load()
-    if LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
+    if route == GEMM_AUTO and LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
         w = dequantize(qn, mn, bits, mode, N, K, out=_dequant_scratch(x.device, N * K).view(N, K))
         y2 = y.view(M, N)
         if residual is not None:
@@ -207,11 +236,11 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None):
         else:
             torch.matmul(x2, w.t(), out=y2)
         return y.reshape(*x.shape[:-1], N)
-    need = lib.amq_gemm_splitk_workspace_bytes(M, N, K)
+    need = lib.amq_gemm_route_workspace_bytes(route, M, N, K)
     ws = _splitk_workspace(x.device, need) if need else None
-    _lib.check(lib.amq_gemm_res_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias), _lib.ptr(residual),
-                                    _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.ptr(ws), ws.numel() * 4 if need else 0,
-                                    _lib.current_stream()))
+    _lib.check(lib.amq_gemm_route_f16(route, bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
+                                      _lib.ptr(residual), _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.ptr(ws),
+                                      ws.numel() * 4 if need else 0, _lib.current_stream()))
     return y.reshape(*x.shape[:-1], N)
 
 
@@ -280,7 +309,12 @@ def linear(x, qn, mn, bits, mode, N, K, bias=None):
     return y.reshape(*x.shape[:-1], N)
 
 
-def gemv_grouped(x, segments, K, prologue=PRO_NONE, x2=None, gamma=None, eps=0.0):
+# Default launch options of the grouped GEMV (None = the library's defaults: exact math, auto geometry).  Only tools/
+# set this (explicitly, from their own command lines) to run whole-model A/B experiments; no environment variable does.
+DEFAULT_GEMV_OPTS = None
+
+
+def gemv_grouped(x, segments, K, prologue=PRO_NONE, x2=None, gamma=None, eps=0.0, opts=None):
     """One launch for several linears sharing x.
 
     segments: list of dicts {qn, mn, bits, mode, N, y, bias=None, residual=None}
@@ -306,8 +340,11 @@ def gemv_grouped(x, segments, K, prologue=PRO_NONE, x2=None, gamma=None, eps=0.0
         x2 = _prep_x(x2, K)
         if x2.shape[0] != M:
             raise ValueError("x2 rows != x rows")
+    if opts is None:
+        opts = DEFAULT_GEMV_OPTS
     _lib.check(_lib.load().amq_gemv_grouped_f16(arr, len(segments), _lib.ptr(xx), _lib.ptr(x2), _lib.ptr(gamma),
-                                                ctypes.c_float(eps), prologue, M, K, GROUP, 0, _lib.current_stream()))
+                                                ctypes.c_float(eps), prologue, M, K, GROUP, 0,
+                                                ctypes.byref(opts) if opts is not None else None, _lib.current_stream()))
 
 
 # ---------------------------------------------------------------- decode-step surroundings
@@ -393,9 +430,17 @@ def silu_mul(gate, up, out=None):
 
 
 def new_step_state(device):
-    """-> (rope_cur fp16 [128], pos int32 [1]): two views of one 260-byte block, the layout amq_attn_decode_cur_f16 reads"""
-    block = torch.zeros(65, dtype=torch.int32, device=device)
-    return block[:64].view(torch.float16), block[64:65]
+    """-> (rope_cur fp16 [128], pos int32 [1], err int32 [1]): three views of one 264-byte block, the layout
+    amq_attn_decode_cur_f16 reads.  ``err`` is the sticky error word the attention kernel raises when the device-side
+    position is outside the cache (see :func:`check_step_state`)."""
+    block = torch.zeros(66, dtype=torch.int32, device=device)
+    return block[:64].view(torch.float16), block[64:65], block[65:66]
+
+
+def check_step_state(err):
+    """raise if a decode step ran with its device-side position outside the KV cache (synchronises)"""
+    if int(err.item()) != 0:
+        raise _lib.AmqError("a decode step ran with its position outside the KV cache (step skipped on the device)")
 
 
 def rope_table(max_seq, rope_theta, device):
@@ -424,7 +469,7 @@ def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_the
         if not 0 <= pos_i < max_seq:
             raise ValueError(f"pos {pos_i} outside the cache (max_seq={max_seq})")
     if cur is not None:
-        # step-state block: cos/sin row (256 bytes) immediately followed by the int32 position (new_step_state())
+        # step-state block: cos/sin row (256 bytes) immediately followed by the int32 position and the error word (new_step_state())
         _need(cur, torch.float16, "rope_cur", 128)
         if pos_dev is None or pos.data_ptr() != cur.data_ptr() + 256:
             raise ValueError("cur / pos must be the two views of one step-state block (ops.new_step_state)")

@@ -3,9 +3,49 @@ stream per process, no collective inside the token loop.  The only communication
 is a start/stop barrier and the max-over-ranks of the elapsed time (RCCL on
 GPUs -- backend "nccl" is RCCL on ROCm -- gloo on CPU for tests)."""
 import os
+import socket
+import subprocess
+import sys
 import time
 
 import torch
+
+
+def launch_local(n, argv, env=None, timeout=None):
+    """Start ``n`` ranks of ``argv`` (a full command line) as fresh child processes of THIS process, one per GPU:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT are set per child, stdout / stderr are inherited (rank 0
+    prints the result line).  The caller must not have touched the GPU: children are started with Popen, never by
+    re-executing a process that holds a device context.  Returns the largest exit code; if one rank fails the others
+    are terminated by PID."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        e = dict(os.environ if env is None else env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                  "MASTER_PORT": str(port)})
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(list(argv), env=e))
+    t_end = None if timeout is None else time.monotonic() + timeout
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(code))
+            if code != 0:                          # one rank died: the others would wait in the barrier forever
+                for q in live:
+                    q.terminate()
+        if live and t_end is not None and time.monotonic() > t_end:
+            for q in live:
+                q.kill()
+            rc = max(rc, 124)
+        time.sleep(0.05)
+    return rc
 
 
 class Replicas:
@@ -39,6 +79,15 @@ class Replicas:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather(self, value):
+        """every rank's ``value`` (float), in rank order, on every rank"""
+        if self.dist is None:
+            return [float(value)]
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
     def timed(self, fn, steps, sync=lambda: None):
         """barrier + sync, run fn() `steps` times, sync + barrier; returns max-over-ranks seconds"""
         sync()
@@ -48,6 +97,7 @@ class Replicas:
         for _ in range(steps):
             fn()
         sync()
+        self.last_local = time.perf_counter() - t0      # this rank's own time (before waiting for the others)
         self.barrier()
         return self.max_over_ranks(time.perf_counter() - t0)
 

@@ -18,12 +18,22 @@ roofline the dominant kernel is the weight-streaming GEMV (amq::gemv_kernel);
          the replay time of a hipGraph holding exactly those launches, timed with
          HIP events on the launch stream -- i.e. it INCLUDES the ~1.3-1.5 us
          device-side boundary between dependent kernels (conservative; the
-         rocprofv3 kernel-only averages are in profiles/).
+         rocprofv3 kernel-only averages are in profiles/).  `gemv_layers` is the second
+         half of the metric: the same measurement per (shape, bit-width) of the 7B
+         linears over cold weight copies.
 cpu_baseline  the reference's CPU path (nn.Linear on dequantized weights) ported
-         to torch CPU ops, timed on the host cores on a bounded sample (oracle/cpu_baseline.py).
+         to torch CPU ops, timed on the host cores on a bounded sample with the
+         thread count swept (oracle/cpu_baseline.py).
 
-N > 1: independent replicas (one decode stream per GPU, no data-path
-collective); RCCL is used only for the start barrier and the max-over-ranks time.
+--gpus N (N > 1) without a launcher (no WORLD_SIZE in the environment): this process
+spawns N fresh children, one rank per GPU, BEFORE touching the GPU itself; under
+`python -m torch.distributed.run` the ranks already exist and are used as they are.
+Ranks are independent replicas (one decode stream per GPU, no data-path collective);
+RCCL is used for the start/stop barrier, the max-over-ranks time and the per-rank rates.
+
+--config 4: BASELINE.json configs[3] instead -- Llama-2-13B avg-3-bit, 16 x 2048 prompt
+rows in one batched prompt pass (the harness' GeMM mode, amq/utils/speed.py:61-71); a step
+is one pass, the roofline object is the MFMA one (linears' flop / time of the linears).
 """
 import argparse
 import json
@@ -39,33 +49,21 @@ sys.path.insert(0, ROOT)
 MODEL = "Llama-2-7b-hf"
 TARGET_BITS = 3.0
 PROMPT = 64
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 measured with a plain copy)
+MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16
 
 
-def build_model(device, seed=0, max_seq=1024):
+def build_model(device, seed=0, max_seq=1024, model=MODEL, pinned=None):
     from amq_amd import arch
     from amq_amd.llama import QuantLlama
-    cfg = arch.MODEL_CONFIGS[MODEL]
-    a, usage = arch.synthesize_arch(cfg, TARGET_BITS, seed=0, pinned=arch.PINNED_7B)
+    cfg = arch.MODEL_CONFIGS[model]
+    a, usage = arch.synthesize_arch(cfg, TARGET_BITS, seed=0, pinned=arch.PINNED_7B if pinned is None else pinned)
     m = QuantLlama(cfg, a["linear"], device=device, max_seq=max_seq, seed=seed)
     return m, a, usage
 
 
-def gemv_roofline(m, reps=20):
-    """time a graph holding only the GEMV launches of one token (4 per block)"""
-    from amq_amd import ops
-    EPS = 1e-5
-    dev = m.dev
-    H, I = m.H, m.I
-
-    def launches():
-        for blk in m.blocks:
-            ops.gemv_grouped(m.x, [blk["self_attn.q_proj"].seg(m.q), blk["self_attn.k_proj"].seg(m.k),
-                                   blk["self_attn.v_proj"].seg(m.v)], H, prologue=ops.PRO_RMSNORM, gamma=blk["ln1"], eps=EPS)
-            ops.gemv_grouped(m.att, [blk["self_attn.o_proj"].seg(m.q)], H)
-            ops.gemv_grouped(m.x, [blk["mlp.gate_proj"].seg(m.gate), blk["mlp.up_proj"].seg(m.up)], H,
-                             prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=EPS)
-            ops.gemv_grouped(m.gate, [blk["mlp.down_proj"].seg(m.q)], I, prologue=ops.PRO_SILU_MUL, x2=m.up)
-
+def _graph_time(dev, launches, reps):
+    """seconds per replay of a hipGraph holding `launches()` (HIP events on the replay stream)"""
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     g = torch.cuda.CUDAGraph()
@@ -83,7 +81,24 @@ def gemv_roofline(m, reps=20):
         g.replay()
     e1.record()
     torch.cuda.synchronize(dev)
-    span_s = e0.elapsed_time(e1) * 1e-3 / reps
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def gemv_roofline(m, reps=20):
+    """time a graph holding only the GEMV launches of one token (4 per block)"""
+    from amq_amd import ops
+    H, I = m.H, m.I
+
+    def launches():
+        for blk in m.blocks:
+            ops.gemv_grouped(m.x, [blk["self_attn.q_proj"].seg(m.q), blk["self_attn.k_proj"].seg(m.k),
+                                   blk["self_attn.v_proj"].seg(m.v)], H, prologue=ops.PRO_RMSNORM, gamma=blk["ln1"], eps=m.eps)
+            ops.gemv_grouped(m.att, [blk["self_attn.o_proj"].seg(m.q)], H)
+            ops.gemv_grouped(m.x, [blk["mlp.gate_proj"].seg(m.gate), blk["mlp.up_proj"].seg(m.up)], H,
+                             prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=m.eps)
+            ops.gemv_grouped(m.gate, [blk["mlp.down_proj"].seg(m.q)], I, prologue=ops.PRO_SILU_MUL, x2=m.up)
+
+    span_s = _graph_time(m.dev, launches, reps)
     n_launch = 4 * m.nb
     # algorithmic bytes: packed weights + fp16 scale/zero (the native buffers are exactly that) + x + y per launch
     wbytes = m.linear_bytes_per_token()
@@ -91,6 +106,41 @@ def gemv_roofline(m, reps=20):
     alg = wbytes + xy
     return {"bytes_per_launch": alg / n_launch, "us_per_launch": span_s / n_launch * 1e6, "launches_per_token": n_launch,
             "gbps": alg / span_s / 1e9}
+
+
+def gemv_layer_table(dev, iters=96):
+    """Per-layer dequant-GEMV GB/s (the metric's second half): every decode launch shape of Llama-2-7B at uniform 2 / 3 /
+    4 bit, M = 1, replayed from a hipGraph over rotating cold weight copies (>= 512 MB per case, beyond the Infinity Cache).
+    us includes the inter-kernel boundary; bytes = N*K*b/8 + 4*N*K/128 + 2*K + 2*N."""
+    from amq_amd import ops
+    from amq_amd.llama import _synthetic_linear
+    gen = torch.Generator(device=dev).manual_seed(123)
+    H, I = 4096, 11008
+    shapes = [("q/k/v", [(H, H)] * 3, ops.PRO_RMSNORM), ("o_proj", [(H, H)], ops.PRO_NONE),
+              ("gate/up", [(I, H)] * 2, ops.PRO_RMSNORM), ("down_proj", [(H, I)], ops.PRO_SILU_MUL)]
+    rows = []
+    for name, segs, pro in shapes:
+        K = segs[0][1]
+        ntot = sum(n for n, _ in segs)
+        for bits in (4, 3, 2):
+            per = ntot * K * bits // 8 + 4 * ntot * K // 128
+            copies = max(2, min(48, (512 << 20) // per + 1))
+            w = [[_synthetic_linear(n, k, bits, gen, dev) for n, k in segs] for _ in range(copies)]
+            x = torch.randn(1, K, device=dev, generator=gen).half()
+            x2 = torch.randn(1, K, device=dev, generator=gen).half()
+            gamma = torch.ones(K, device=dev, dtype=torch.float16)
+            ys = [torch.empty(1, n, device=dev, dtype=torch.float16) for n, _ in segs]
+
+            def launches():
+                for i in range(iters):
+                    ops.gemv_grouped(x, [l.seg(y) for l, y in zip(w[i % copies], ys)], K, prologue=pro, x2=x2, gamma=gamma, eps=1e-5)
+
+            us = _graph_time(dev, launches, 3) / iters * 1e6
+            b = per + 2 * K * (2 if pro == ops.PRO_SILU_MUL else 1) + 2 * ntot
+            rows.append({"launch": name, "N": ntot, "K": K, "bits": bits, "us": round(us, 2), "GBps": round(b / us / 1e3, 1),
+                         "frac": round(b / us / 1e3 / HBM_PEAK_GBPS, 3)})
+            del w
+    return rows
 
 
 def cpu_baseline(seed=0):
@@ -105,12 +155,13 @@ def cpu_baseline(seed=0):
         h = random_hqq(n, k, bits, seed=seed + len(layers))
         layers.append({"W_q": h.W_q, "scale": h.scale, "zero": h.zero, "nbits": bits, "shape": (n, k)})
     lm_head = torch.randn(cfg["vocab_size"], cfg["hidden_size"]).to(torch.float16)
-    return cb.time_decode_linears(layers, cfg["n_block"], tokens=8, extra_dense=lm_head)
+    return cb.time_decode_linears(layers, cfg["n_block"], tokens=3, extra_dense=lm_head, sample_blocks=4)
 
 
 def load_traffic():
-    """HBM bytes per GEMV launch from the committed rocprofv3 PMC pass (profiles/), or None"""
-    p = os.path.join(ROOT, "profiles", "r01_gemv_pmc.json")
+    """HBM bytes per GEMV launch from this round's committed rocprofv3 PMC pass over the CURRENT kernels
+    (profiles/r02_gemv_pmc.json, tools/collect_pmc.sh), or None -- never a stale constant."""
+    p = os.path.join(ROOT, "profiles", "r02_gemv_pmc.json")
     if os.path.exists(p):
         try:
             return json.load(open(p)).get("hbm_bytes_per_launch")
@@ -119,23 +170,8 @@ def load_traffic():
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-    from amq_amd.replicas import Replicas
-    rep = Replicas(backend="nccl", device=dev)        # nccl == RCCL on ROCm; no-op for one process
+def run_decode(args, rep, dev):
     rank, n_gpus = rep.rank, rep.world
-
     max_seq = PROMPT + args.warmup + args.steps + 8
     m, a, usage = build_model(dev, seed=rank, max_seq=max_seq)
     ids = torch.randint(0, m.vocab - 1, (PROMPT,), generator=torch.Generator().manual_seed(rank)).to(dev)
@@ -144,43 +180,147 @@ def main():
     for _ in range(args.warmup):
         m.decode_step()
     elapsed = rep.timed(m.decode_step, args.steps, sync=lambda: torch.cuda.synchronize(dev))
+    per_rank = rep.gather(args.steps / rep.last_local)
+    m.check()                                       # no step ran past the KV cache
     ok = bool(torch.isfinite(m.logits.float()).all().item())
+    if rank != 0:
+        return
+    roof = gemv_roofline(m)
+    out = {
+        "metric": "decode tokens/s, Llama-2-7B AMQ mixed 2/3/4-bit avg-3-bit, batch 1",
+        "value": n_gpus * args.steps / elapsed,
+        "unit": "tokens/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16",
+        "data": "synthetic",
+        "config": {"workload": "Llama-2-7B shapes, synthesized avg-3.0-bit per-layer arch (bits_usage %.3f), "
+                               "batch 1 decode after a 64-token prefill, one stream per GPU" % usage,
+                   "parallelism": "replicas x%d" % n_gpus, "prompt": PROMPT, "group_size": 128},
+        "roofline": {"bound": "hbm", "achieved": roof["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": roof["gbps"] / HBM_PEAK_GBPS, "traffic": load_traffic(),
+                     "kernel": "amq::gemv_kernel (grouped 2/3/4-bit weight-streaming GEMV)",
+                     "bytes_per_launch": roof["bytes_per_launch"], "us_per_launch": roof["us_per_launch"],
+                     "launches_per_token": roof["launches_per_token"]},
+        "finite_logits": ok,
+        "rccl_world_size": n_gpus,
+        "per_rank_tokens_per_s": [round(v, 2) for v in per_rank],
+        "linear_gb_per_token": m.linear_bytes_per_token() / 1e9,
+        "model_gbps": m.total_bytes_per_token(PROMPT + args.warmup + args.steps // 2) / (elapsed / args.steps) / 1e9,
+    }
+    if n_gpus == 1 and not args.no_layer_table:
+        del m
+        torch.cuda.empty_cache()
+        out["gemv_layers"] = gemv_layer_table(dev)
+    if n_gpus == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline()
+        out["cpu_baseline"] = {"value": cb["tokens_per_s_predequantized"], "unit": "tokens/s", "cores": cb["cores"],
+                               "kind": "port", "sample": cb["sample"], "host_threads": cb["host_threads"],
+                               "thread_sweep_tokens_per_s": cb["thread_sweep"],
+                               "dequant_every_call_tokens_per_s": cb["tokens_per_s_dequant_every_call"]}
+    print(json.dumps(out), flush=True)
 
-    if rank == 0:
-        roof = gemv_roofline(m)
-        peak = 8000.0
-        out = {
-            "metric": "decode tokens/s, Llama-2-7B AMQ mixed 2/3/4-bit avg-3-bit, batch 1",
-            "value": n_gpus * args.steps / elapsed,
-            "unit": "tokens/s",
-            "n_gpus": n_gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f16",
-            "data": "synthetic",
-            "config": {"workload": "Llama-2-7B shapes, synthesized avg-3.0-bit per-layer arch (bits_usage %.3f), "
-                                   "batch 1 decode after a 64-token prefill, one stream per GPU" % usage,
-                       "parallelism": "replicas x%d" % n_gpus, "prompt": PROMPT, "group_size": 128},
-            "roofline": {"bound": "hbm", "achieved": roof["gbps"], "peak": peak, "unit": "GB/s",
-                         "frac": roof["gbps"] / peak, "traffic": load_traffic(),
-                         "kernel": "amq::gemv_kernel (grouped 2/3/4-bit weight-streaming GEMV)",
-                         "bytes_per_launch": roof["bytes_per_launch"], "us_per_launch": roof["us_per_launch"],
-                         "launches_per_token": roof["launches_per_token"]},
-            "finite_logits": ok,
-            "linear_gb_per_token": m.linear_bytes_per_token() / 1e9,
-            "model_gbps": m.total_bytes_per_token(PROMPT + args.warmup + args.steps // 2) / (elapsed / args.steps) / 1e9,
-        }
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline()
-            out["cpu_baseline"] = {"value": cb["tokens_per_s_predequantized"], "unit": "tokens/s", "cores": cb["cores"],
-                                   "kind": "port", "sample": cb["sample"],
-                                   "dequant_every_call_tokens_per_s": cb["tokens_per_s_dequant_every_call"]}
-        print(json.dumps(out), flush=True)
-    rep.close()
+
+def run_gemm_mode(args, rep, dev):
+    """BASELINE.json configs[3]: Llama-2-13B avg-3-bit, 16 x 2048 prompt rows per pass (GeMM mode)."""
+    from amq_amd import ops
+    rank, n_gpus = rep.rank, rep.world
+    B, S = 16, 2048
+    m, a, usage = build_model(dev, seed=rank, max_seq=S, model="Llama-2-13b-hf", pinned=())
+    ids = torch.randint(0, m.vocab - 1, (B, S), generator=torch.Generator().manual_seed(rank)).to(dev)
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            m.prefill_batch(ids)
+        elapsed = rep.timed(lambda: m.prefill_batch(ids), args.steps, sync=lambda: torch.cuda.synchronize(dev))
+        logits = m.prefill_batch(ids)
+    ok = bool(torch.isfinite(logits.float()).all().item())
+    if rank != 0:
+        return
+    # the dominant kernel family: the seven linears of every block at M = 32768 (what ops.gemm dispatches to),
+    # timed alone with HIP events on the launch stream
+    M = B * S
+    xs = {k: torch.randn(M, k, device=dev, dtype=torch.float16) * 0.05 for k in (m.H, m.I)}
+    flops = 0
+    with torch.inference_mode():
+        def linears():
+            for blk in m.blocks[:4]:
+                for name in m.cfg["linear"]:
+                    l = blk[name]
+                    ops.gemm(xs[l.K], l.qn, l.mn, l.bits, l.mode, l.N, l.K)
+        linears()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        linears()
+        e1.record()
+        torch.cuda.synchronize(dev)
+    for blk in m.blocks[:4]:
+        for name in m.cfg["linear"]:
+            flops += 2.0 * M * blk[name].N * blk[name].K
+    tf = flops / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    total_flops = sum(2.0 * M * blk[name].N * blk[name].K for blk in m.blocks for name in m.cfg["linear"])
+    out = {
+        "metric": "batched prompt passes/s (GeMM mode), Llama-2-13B AMQ mixed 2/3/4-bit avg-3-bit, 16 x 2048 rows",
+        "value": n_gpus * args.steps / elapsed, "unit": "passes/s", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "Llama-2-13B shapes, synthesized avg-3.0-bit arch (bits_usage %.3f), one batched prompt pass "
+                               "of 16 x 2048 rows (BASELINE.json configs[3])" % usage,
+                   "parallelism": "replicas x%d" % n_gpus, "group_size": 128, "gemm_route": ops.gemm_route_name(M)},
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+                     "traffic": None, "kernel": ops.gemm_route_name(M),
+                     "note": "the seven linears of 4 blocks at M = 32768 through ops.gemm, HIP events on the launch stream"},
+        "prompt_tokens_per_s": n_gpus * args.steps * M / elapsed,
+        "linear_tflop_per_pass": total_flops / 1e12,
+        "whole_pass_tflops": total_flops * args.steps / elapsed / 1e12,
+        "finite_logits": ok,
+    }
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=3, choices=(3, 4),
+                    help="3 (default): BASELINE.json configs[2], the headline decode metric; 4: configs[3], GeMM mode")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-layer-table", action="store_true")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 256 if args.config == 3 else 3
+    if args.warmup is None:
+        args.warmup = 16 if args.config == 3 else 1
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one.  Nothing above has touched the GPU (`import torch` does not), and the children are
+        # fresh processes -- never a re-exec of a process that holds a device context.
+        from amq_amd.replicas import launch_local
+        sys.exit(launch_local(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    from amq_amd.replicas import Replicas
+    rep = Replicas(backend="nccl", device=dev)        # nccl == RCCL on ROCm; no-op for one process
+    try:
+        if args.config == 4:
+            run_gemm_mode(args, rep, dev)
+        else:
+            run_decode(args, rep, dev)
+    finally:
+        rep.close()
 
 
 if __name__ == "__main__":

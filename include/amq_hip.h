@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AMQ_VERSION 100            /* 0.1.0 */
+#define AMQ_VERSION 200            /* 0.2.0 */
 
 #define AMQ_OK            0
 #define AMQ_EINVAL       -1        /* bad argument (null pointer, bits, mode ...) */
@@ -57,21 +57,28 @@ extern "C" {
 int amq_version(void);
 const char* amq_last_error(void);
 
-/* process-wide tuning / A-B knobs (not needed for normal use) */
-#define AMQ_OPT_GEMV_DOT   1       /* 1: M == 1 runs the v_dot2c + wavefront-shuffle body instead of the MFMA body */
-#define AMQ_OPT_GEMV_WAVES 2       /* waves per GEMV workgroup: 0 = auto (default), 4, 8 or 16 */
-#define AMQ_OPT_GEMV_DEPTH 3       /* tile loads in flight per wave: 0 = auto (default), 2 or 4 */
-#define AMQ_OPT_GEMV_RPT   4       /* row-tiles walked by one GEMV workgroup: 0 = auto (default), 1..64 */
-#define AMQ_OPT_GEMV_MATH  5       /* AMQ_MATH_EXACT (default) or AMQ_MATH_LINEAR */
-#define AMQ_OPT_GEMM_NSUB  6       /* 16-column sub-tiles per GEMM wave: 0 = auto (default), 2 or 4 */
-#define AMQ_OPT_GEMM_SKINNY_MAX 7  /* rows up to which GEMMs run the barrier-free K-split-by-wave kernel (default 32; 0 = never) */
 /* GEMV arithmetic.  EXACT reproduces the reference's dequantized fp16 weights (two fp16 roundings per
  * weight) and accumulates x*w in fp32.  LINEAR skips the per-weight roundings: y = sum_g s_g*(sum_k x_k q_k
  * - z_g sum_k x_k) in fp32 (scale / zero applied once per 128-group) -- the real-valued dequant; it is
  * ~3x cheaper in VALU work and lands within ~1e-3 of the output rms of the reference result (tests). */
 #define AMQ_MATH_EXACT  0
 #define AMQ_MATH_LINEAR 1
-int amq_set_option(int option, int value);
+
+/* Per-call launch options of amq_gemv_grouped_f16 (host struct; NULL or all-zero = defaults).  There is no
+ * process-wide option state in the library: what a call computes depends on its arguments only. */
+typedef struct amq_gemv_opts {
+    int math;    /* AMQ_MATH_EXACT (default) or AMQ_MATH_LINEAR */
+    int waves;   /* A/B: waves per workgroup, 0 = auto, 4, 8 or 16 */
+    int depth;   /* A/B: tile loads in flight per wave, 0 = auto, 2 or 4 */
+    int rpt;     /* A/B: row-tiles walked by one workgroup, 0 = auto, 1..64 */
+    int dot;     /* A/B: 1 = M == 1 runs the v_dot2c + wavefront-shuffle body instead of the MFMA body */
+} amq_gemv_opts;
+
+/* kernel family of amq_gemm_route_f16 (AUTO = what every other GEMM entry point uses: chosen by shape) */
+#define AMQ_GEMM_AUTO   0
+#define AMQ_GEMM_TILED  1          /* LDS-DMA double-buffered 64/128-row tiles (+ split-K for few rows) */
+#define AMQ_GEMM_SKINNY 2          /* barrier-free K-split-by-wave kernel, M <= 64 */
+#define AMQ_GEMM_RING   3          /* 256-row tiles, 3-slot LDS ring for x and packed W, counted waits */
 
 /* capabilities: writes up to `cap` ints {max_gemv_rows_for_K, lds_bytes, ...}; returns the count */
 int amq_query(int K, int* out, int cap);
@@ -145,7 +152,8 @@ typedef struct amq_segment {
 
 int amq_gemv_grouped_f16(const amq_segment* segments /* host */, int nseg,
                          const void* x, const void* x2, const void* gamma, float eps, int prologue,
-                         int M, int K, int group, int x_stride, void* stream);
+                         int M, int K, int group, int x_stride, const amq_gemv_opts* opts /* host, may be NULL */,
+                         void* stream);
 
 /* ---- entry points shaped like the reference's pybind functions ------------------------------------
  * They take the reference's own buffers (Format B / Format C) unchanged.  The HIP kernels read the native layout,
@@ -187,11 +195,15 @@ int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcach
 /* optional: fp16 [max_seq][64][2] (cos, sin) table for amq_attn_decode_f16 (NULL there = computed in-kernel, same values) */
 int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream);
 
-/* Decode attention for graph-replayed token steps.  step_state is a 260-byte device block
- *     { fp16 cos/sin [64][2] of the CURRENT position ; int32 position at byte offset 256 }
+/* Decode attention for graph-replayed token steps.  step_state is a 264-byte device block
+ *     { fp16 cos/sin [64][2] of the CURRENT position ; int32 position at byte 256 ; int32 sticky error word at byte 260 }
  * that amq_decode_tail_f16 keeps up to date (pass rope_cur = step_state, pos = step_state + 256 there): position and
  * rotation inputs are fetched by the kernel's first instructions instead of through the position -> table-row chain of
- * dependent loads of amq_attn_decode_f16. */
+ * dependent loads of amq_attn_decode_f16.
+ * Both attention entry points treat a device-side position outside 0 .. max_seq-1 as a no-op (no cache append, no
+ * output); this one also sets the error word to 1 (it is never cleared by the library: zero it when the state is
+ * created, read it back to learn that a replay ran past the cache).  amq_decode_tail_f16 saturates the position at
+ * rope_rows (= max_seq), so a runaway replay keeps hitting the no-op path. */
 int amq_attn_decode_cur_f16(const void* q, const void* k, const void* v, void* kcache, void* vcache, void* out,
                             const void* step_state, int batch, int n_heads, int n_kv_heads, int head_dim, int max_seq,
                             void* stream);
@@ -214,6 +226,12 @@ int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hi
 int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
                      const void* bias, const void* residual, void* y, int M, int N, int K, int group, int x_stride,
                      int y_stride, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the kernel family chosen by the caller (tests, A/B tools); amq_gemm_route_workspace_bytes is the
+ * matching workspace query (0: no workspace needed). */
+size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K);
+int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
+                       const void* bias, const void* residual, void* y, int M, int N, int K, int group, int x_stride,
+                       int y_stride, void* workspace, size_t workspace_bytes, void* stream);
 /* Fragment-ordered activations for few-row GEMMs.  For a few dozen rows the GEMM is bound by how fast a CU can pull x
  * in MFMA operand order; amq_xfrag_f16 lays x out so that every wave-load is one contiguous KiB that already IS an
  * operand:  xf[g][kt][mb*4 + t][lane = 16*o + r][8] = x[g*64 + mb*16 + r][kt*128 + 32*t + 8*o .. +8]  (rows >= M zero),

@@ -29,7 +29,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_version_sizes_and_validation():
     lib = _lib.load()
-    assert lib.amq_version() == 100
+    assert lib.amq_version() == 200
     # native sizes: N*K*bits/8 payload, 4 B of (scale, zero) per (row, group)
     for bits in (2, 3, 4):
         assert lib.amq_native_qweight_bytes(bits, 4096, 4096) == 4096 * 4096 * bits // 8
@@ -44,7 +44,15 @@ def test_version_sizes_and_validation():
     assert rc == -2 and b"group" in lib.amq_last_error()
     rc = lib.amq_gemv_f16(4, 0, one, one, one, None, one, 17, 4096, 4096, 128, 0, 0, None)
     assert rc == -2 and b"amq_gemm_f16" in lib.amq_last_error()
-    assert lib.amq_set_option(2, 5) == -1 and lib.amq_set_option(4, 65) == -1 and lib.amq_set_option(5, 2) == -1 and lib.amq_set_option(5, 0) == 0 and lib.amq_set_option(3, 3) == -1 and lib.amq_set_option(3, 0) == 0 and lib.amq_set_option(2, 0) == 0 and lib.amq_set_option(99, 0) == -1
+    # per-call options are validated too (host struct; the library holds no option state)
+    seg = (_lib.Segment * 1)(_lib.Segment(16, 16, None, None, 16, 4096, 4, 0, 0))
+    for bad in (_lib.GemvOpts(math=2), _lib.GemvOpts(waves=5), _lib.GemvOpts(depth=3), _lib.GemvOpts(rpt=65)):
+        rc = lib.amq_gemv_grouped_f16(seg, 1, one, None, None, 0.0, 0, 1, 4096, 128, 0, ctypes.byref(bad), None)
+        assert rc == -1 and b"opts." in lib.amq_last_error()
+    assert not hasattr(lib, "amq_set_option")
+    assert lib.amq_gemm_route_f16(9, 4, 0, one, one, one, None, None, one, 40, 4096, 4096, 128, 0, 0, None, 0, None) == -1
+    assert lib.amq_gemm_route_f16(2, 4, 0, one, one, one, None, None, one, 65, 4096, 4096, 128, 0, 0, None, 0, None) == -2
+    assert lib.amq_gemm_route_workspace_bytes(1, 64, 4096, 4096) > 0 and lib.amq_gemm_route_workspace_bytes(2, 64, 4096, 4096) == 0
     rc = lib.amq_gemm_f16(4, 7, one, one, one, None, one, 40, 4096, 4096, 128, 0, 0, None)
     assert rc == -1
     out = (ctypes.c_int * 4)()

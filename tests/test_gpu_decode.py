@@ -136,7 +136,7 @@ def test_attn_decode_long_context(pos):
     # the graph-replay form (cos/sin row of the current position handed over by the previous step) gives the same bits
     kc2, vc2, out2 = kc.clone(), vc.clone(), torch.zeros_like(out)
     kc2[0, :, pos] = 1000.0
-    cur, pos_state = ops.new_step_state(dev)
+    cur, pos_state, _err = ops.new_step_state(dev)
     cur.copy_(tab.view(max_seq, 128)[pos]); pos_state.fill_(pos)
     ops.attn_decode(q.reshape(1, -1), k.reshape(1, -1), v.reshape(1, -1), kc2, vc2, out2, pos_state, nh, nkv, cur=cur)
     assert torch.equal(out2, out) and torch.equal(kc2[0, :, pos], kc[0, :, pos])
@@ -408,3 +408,74 @@ def test_speed_harness_gemm_mode_batched():
     assert r["gemm"]["4.32.8"] > 0 and r["peak_memory"]["4.32.8"] > 0
     with pytest.raises(NotImplementedError):
         benchmark_speed(m, iteration=1, sizes=(4, 32, 8), mode="TPS", get_peak_memory=False)
+
+
+def test_decode_past_the_cache_is_refused_on_host_and_skipped_on_device():
+    """A decode step whose position is outside the KV cache must not touch the cache or LDS: decode_step() refuses on the
+    host; a raw graph replay (bypassing the host mirror) is a no-op in the attention kernel, which raises the sticky
+    error word of the step state; the position saturates at max_seq."""
+    from amq_amd import arch, ops
+    from amq_amd.llama import QuantLlama
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 2, 1, vocab=1024))
+    m = QuantLlama(cfg, None, device="cuda:0", max_seq=16, seed=4)
+    ids = torch.randint(0, 1024, (13,), generator=torch.Generator().manual_seed(1)).to(_dev())
+    m.prefill(ids)
+    guard = [torch.full((4096,), 7.0, dtype=torch.float16, device=_dev()) for _ in range(2)]   # neighbours in the allocator
+    for _ in range(3):                       # positions 13, 14, 15: the last rows of the cache
+        m.decode_step()
+    m.check()
+    assert int(m.pos.item()) == 16 and m.host_pos == 16
+    with pytest.raises(ValueError, match="does not fit the KV cache"):
+        m.decode_step()
+    kc = [b["kc"].clone() for b in m.blocks]
+    vc = [b["vc"].clone() for b in m.blocks]
+    for _ in range(3):                       # what a caller replaying the captured graph blindly would do
+        m.graph.replay()
+    torch.cuda.synchronize()
+    assert int(m.pos.item()) == 16           # saturated by the step's tail kernel
+    assert int(m.step_err.item()) == 1       # raised by the attention kernel
+    with pytest.raises(Exception, match="outside the KV cache"):
+        m.check()
+    for b, k0, v0 in zip(m.blocks, kc, vc):
+        assert torch.equal(b["kc"], k0) and torch.equal(b["vc"], v0)
+    assert all(torch.all(g == 7.0) for g in guard)
+    # the plain entry point (position from a device int) skips as well
+    nh, nkv, max_seq = 4, 2, 16
+    q = torch.randn(1, nh * 128, device=_dev()).half()
+    k = torch.randn(1, nkv * 128, device=_dev()).half()
+    kcache = torch.zeros(1, nkv, max_seq, 128, device=_dev(), dtype=torch.float16)
+    vcache = torch.zeros_like(kcache)
+    out = torch.full((1, nh * 128), 3.0, device=_dev(), dtype=torch.float16)
+    for bad in (16, 1000, -1):
+        ops.attn_decode(q, k, k.clone(), kcache, vcache, out, torch.tensor([bad], dtype=torch.int32, device=_dev()), nh, nkv)
+    torch.cuda.synchronize()
+    assert torch.all(out == 3.0) and torch.all(kcache == 0) and torch.all(vcache == 0)
+    with pytest.raises(ValueError):
+        ops.attn_decode(q, k, k.clone(), kcache, vcache, out, 16, nh, nkv)
+
+
+def test_prefill_graph_survives_scratch_growth():
+    """a per-length prefill graph has the split-K workspace / dequant scratch pointers baked in; a later, larger
+    request must not free what an older graph still writes.  prefill(64), prefill(300) (grows the workspace), empty_cache,
+    then the replayed 64-token graph must still equal the eager pass."""
+    from amq_amd import arch, ops
+    from amq_amd.llama import QuantLlama
+    cfg = dict(arch._cfg(2, 1024, 2816, 8, 8, 1, vocab=1024))
+    m = QuantLlama(cfg, None, device="cuda:0", max_seq=512, seed=6)
+    g = torch.Generator().manual_seed(3)
+    ids64 = torch.randint(0, 1024, (64,), generator=g).to(_dev())
+    ids300 = torch.randint(0, 1024, (300,), generator=g).to(_dev())
+    eager64 = m.prefill(ids64, use_graph=False).clone()
+    a = m.prefill(ids64).clone()
+    assert torch.equal(a, eager64)
+    ws_before = [t.data_ptr() for t in ops._SPLITK_WS._cur.values()]
+    m.prefill(ids300)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), float("nan"), device=_dev()) for _ in range(8)]     # reuse whatever was freed
+    b = m.prefill(ids64).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(b, eager64)
+    kept = {t.data_ptr() for t in ops._SPLITK_WS._keep} | {t.data_ptr() for t in ops._SPLITK_WS._cur.values()}
+    assert all(p in kept for p in ws_before)                   # nothing a graph may reference was released
+    del junk

@@ -71,3 +71,30 @@ def test_llama70b_block_shapes_grouped_decode_step():
     for _ in range(3):
         m2.decode_step(use_graph=False)
     assert torch.equal(m2.logits, m.logits)
+
+
+def test_llama13b_block_batched_prompt_pass_at_config4_size():
+    """BASELINE.json configs[3] at size: one 13B-shaped block, 16 x 2048 prompt rows through prefill_batch (every linear at
+    M = 32768).  Checked through properties: finite logits; the hand-written kernels and the dequantize + library route
+    agree; the batch is a batch (sequence b of the batched pass == the same sequence passed alone)."""
+    from amq_amd import arch, ops
+    from amq_amd.llama import QuantLlama
+    cfg = dict(arch.MODEL_CONFIGS["Llama-2-13b-hf"])
+    cfg["n_block"] = 1
+    cfg["vocab_size"] = 2048
+    al = {name: [b] for name, b in zip(cfg["linear"], [3, 2, 4, 3, 2, 3, 4])}
+    m = QuantLlama(cfg, al, max_seq=2048, seed=1)
+    ids = torch.randint(0, 2048, (16, 2048), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(2))
+    saved = ops.LIB_GEMM_ROWS
+    try:
+        ops.LIB_GEMM_ROWS = 0                     # hand-written MFMA kernels at every size
+        own = m.prefill_batch(ids).clone()
+        one = m.prefill_batch(ids[5:6]).clone()
+        ops.LIB_GEMM_ROWS = 1024                  # bit-exact dequantize kernel + library GEMM
+        lib = m.prefill_batch(ids).clone()
+    finally:
+        ops.LIB_GEMM_ROWS = saved
+    assert torch.isfinite(own.float()).all() and own.shape == (16, 2048)
+    scale = own.float().abs().max()
+    assert (own.float() - lib.float()).abs().max() <= 1e-2 * scale
+    assert (own[5].float() - one[0].float()).abs().max() <= 1e-2 * scale

@@ -225,20 +225,12 @@ def test_matmul_weights_equal_oracle_weights(bits):
 @pytest.mark.parametrize("opt", ["dot", "w4", "w8", "w16"])
 def test_gemv_variants_agree(opt):
     """the A/B knobs (dot-product body, waves per workgroup) change scheduling, not results beyond fp32 summation order"""
-    from amq_amd import ops, _lib
-    lib = _lib.load()
+    from amq_amd import ops
     h, qn, mn, w_ref = _random_case(3, 1024, 4096, seed=9)
     x = torch.randn(1, 4096, generator=torch.Generator().manual_seed(1)).to(torch.float16)
     y_ref = linear_ref.linear_f16(x.numpy(), w_ref)
-    try:
-        if opt == "dot":
-            _lib.check(lib.amq_set_option(_lib.OPT_GEMV_DOT, 1))
-        else:
-            _lib.check(lib.amq_set_option(_lib.OPT_GEMV_WAVES, int(opt[1:])))
-        y = ops.gemv(x.to(_dev()), qn, mn, 3, ops.MODE_HQQ, 1024, 4096).cpu().numpy()
-    finally:
-        lib.amq_set_option(_lib.OPT_GEMV_DOT, 0)
-        lib.amq_set_option(_lib.OPT_GEMV_WAVES, 0)
+    o = ops.GemvOpts(dot=1) if opt == "dot" else ops.GemvOpts(waves=int(opt[1:]))      # per-call options: no library state
+    y = ops.gemv(x.to(_dev()), qn, mn, 3, ops.MODE_HQQ, 1024, 4096, opts=o).cpu().numpy()
     _assert_close(y, y_ref, f"gemv variant {opt}")
 
 
@@ -249,8 +241,7 @@ def test_gemv_linear_math_and_persistent_rows(bits, n, k, m, rpt):
     several row-tiles per workgroup.  Linear math is compared (a) with the exact real-valued dequant
     sum_k x_k * (q_k - z) * s in fp64: fp32-accumulation accuracy; (b) with the reference's rounded-weight
     result: within 2e-3 of the output rms (the reference's own weight-rounding noise is ~3e-4 rms)."""
-    from amq_amd import ops, _lib
-    lib = _lib.load()
+    from amq_amd import ops
     h, qn, mn, w_ref = _random_case(bits, n, k, seed=11 * bits + m)
     x = torch.randn(m, k, generator=torch.Generator().manual_seed(n + m)).to(torch.float16)
     q = hqq_ref.unpack(h.W_q.numpy(), bits, (n, k)).astype(np.float64)
@@ -259,14 +250,11 @@ def test_gemv_linear_math_and_persistent_rows(bits, n, k, m, rpt):
     y_real = x.numpy().astype(np.float64) @ ((q - z64) * s64).T
     y_ref = linear_ref.linear_f16(x.numpy(), w_ref).astype(np.float64)
     rms = np.sqrt(np.mean(y_ref ** 2))
-    try:
-        _lib.check(lib.amq_set_option(_lib.OPT_GEMV_RPT, rpt))
-        y_exact = ops.gemv(x.to(_dev()), qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy()
-        _lib.check(lib.amq_set_option(_lib.OPT_GEMV_MATH, _lib.MATH_LINEAR))
-        y_lin = ops.gemv(x.to(_dev()), qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy().astype(np.float64)
-    finally:
-        lib.amq_set_option(_lib.OPT_GEMV_MATH, _lib.MATH_EXACT)
-        lib.amq_set_option(_lib.OPT_GEMV_RPT, 0)
+    y_exact = ops.gemv(x.to(_dev()), qn, mn, bits, ops.MODE_HQQ, n, k, opts=ops.GemvOpts(rpt=rpt)).cpu().numpy()
+    y_lin = ops.gemv(x.to(_dev()), qn, mn, bits, ops.MODE_HQQ, n, k,
+                     opts=ops.GemvOpts(rpt=rpt, math=ops.MATH_LINEAR)).cpu().numpy().astype(np.float64)
+    # options are per call: a default launch afterwards is the exact-math one again
+    assert np.array_equal(ops.gemv(x.to(_dev()), qn, mn, bits, ops.MODE_HQQ, n, k, opts=ops.GemvOpts(rpt=rpt)).cpu().numpy(), y_exact)
     _assert_close(y_exact, y_ref, "exact math, rpt=%d" % rpt)
     assert np.max(np.abs(y_lin - y_real) - 2.0 ** -10 * np.abs(y_real)) <= 1e-4 * rms      # (a)
     assert np.max(np.abs(y_lin - y_ref) - 2.0 ** -10 * np.abs(y_ref)) <= 2e-3 * rms   # (b) (+ one fp16 ulp of y: both are rounded)
@@ -403,18 +391,14 @@ def test_gemm_skinny(bits, m, n, k):
     res = torch.randn(m, n, generator=gen).to(torch.float16)
     bias = h.bias.to(dev)
     lib = _lib.load()
-    _lib.check(lib.amq_set_option(_lib.OPT_GEMM_SKINNY_MAX, 64))         # default limit is 32 rows; cover the 4-block variant too
-    try:
-        assert lib.amq_gemm_splitk_workspace_bytes(m, n, k) == 0
-        y = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias)
-        _assert_close(y.cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref, h.bias.numpy()), f"skinny {bits}b {n}x{k} M={m}")
-        assert torch.equal(ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias), y)
-        yr = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=res.to(dev))
-        assert torch.equal(yr, res.to(dev) + y)
-        _lib.check(lib.amq_set_option(_lib.OPT_GEMM_SKINNY_MAX, 0))
-        tiled = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias)
-    finally:
-        _lib.check(lib.amq_set_option(_lib.OPT_GEMM_SKINNY_MAX, 32))
+    SK = ops.GEMM_SKINNY                      # the default route takes this kernel up to 32 rows; forced here to cover the 4-block variant too
+    assert lib.amq_gemm_route_workspace_bytes(SK, m, n, k) == 0
+    y = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, route=SK)
+    _assert_close(y.cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref, h.bias.numpy()), f"skinny {bits}b {n}x{k} M={m}")
+    assert torch.equal(ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, route=SK), y)
+    yr = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=res.to(dev), route=SK)
+    assert torch.equal(yr, res.to(dev) + y)
+    tiled = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, route=ops.GEMM_TILED)
     ref = x.to(dev).float() @ ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).float().t()
     tol = 2.0 ** -9 * ref.abs() + 2.0 ** -9 * y.float().abs() + 1e-3 * ref.pow(2).mean().sqrt()
     assert torch.all((y.float() - tiled.float()).abs() <= tol)
@@ -500,3 +484,59 @@ def test_gemm_library_path_matches_fused_kernel(bits, m, n, k, monkeypatch):
     for got in (lib_r, own_r):                              # one rounding (library) / three roundings (fused), same target
         assert torch.all((got.float() - full).abs() <= 3 * 2.0 ** -10 * (ref.abs() + bias.float().abs() + res.float().abs()) + 1e-3 * rms)
     assert torch.all((lib_b.float() - (ref + bias.float())).abs() <= 2.0 ** -10 * (ref.abs() + bias.float().abs()) + 1e-3 * rms)
+
+
+def _sampled_rows_check(y, x, w_dev, rows, what):
+    """CPU oracle linear (fp16 x . fp16 W^T in fp32 -> fp16) on a row sample; W = the bit-exact dequantized weights"""
+    w = w_dev.cpu().numpy()
+    xs = x[rows].cpu().numpy()
+    _assert_close(y[rows].cpu().numpy(), linear_ref.linear_f16(xs, w), what)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("m,n,k,route", [(640, 12288, 512, 1), (2048, 3072, 256, 1), (517, 6144, 384, 1),
+                                         (640, 12288, 512, 3), (2048, 3072, 256, 3), (517, 6144, 384, 3), (300, 1040, 1152, 3)])
+def test_gemm_big_tiles(bits, m, n, k, route):
+    """the many-row MFMA kernels on shapes that select their LARGE tiles (route 1: gemm_kernel<.,.,128,2> needs
+    ceil(M/128) * ceil(N/128) >= 384 workgroups; route 3: the 256-row ring kernel), ragged M tails, bias and an in-place
+    residual, against the CPU oracle linear on the reference's dequantized weights."""
+    from amq_amd import ops
+    h, qn, mn, w_ref = _random_case(bits, n, k, seed=31 * bits + m, bias=True)
+    dev = _dev()
+    gen = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=gen).to(torch.float16)
+    res = torch.randn(m, n, generator=gen).to(torch.float16)
+    bias = h.bias.to(dev)
+    y = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, route=route)
+    _assert_close(y.cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref, h.bias.numpy()), f"route {route} {bits}b {m}x{n}x{k}")
+    assert torch.equal(ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, route=route), y)     # deterministic
+    inplace = res.to(dev).clone()
+    ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=inplace, out=inplace, route=route)
+    assert torch.equal(inplace, res.to(dev) + y)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k", [(5120, 5120), (13824, 5120), (5120, 13824)])
+@pytest.mark.parametrize("m", [512, 2048, 8192])
+def test_gemm_13b_shapes_at_size(bits, n, k, m):
+    """BASELINE.json configs[3] shapes (Llama-2-13B linears) at many rows through every hand-written many-row kernel
+    (the library hop disabled): a row sample against the CPU oracle linear on the bit-exactly dequantized weights, all
+    rows against an fp32 matmul on the same weights, and the two kernel families against each other."""
+    from amq_amd import ops
+    from amq_amd.llama import _synthetic_linear
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(n + k + bits + m)
+    l = _synthetic_linear(n, k, bits, g, dev)
+    x = (torch.randn(m, k, device=dev, generator=g) * 0.5).half()
+    w = ops.dequantize(l.qn, l.mn, bits, l.mode, n, k)
+    ref = x.float() @ w.float().t()
+    rms = ref.pow(2).mean().sqrt()
+    rows = torch.tensor(sorted({0, 1, m // 3, m // 2, m - 2, m - 1}), device=dev)
+    outs = {}
+    for route in (ops.GEMM_TILED, ops.GEMM_RING):
+        y = ops.gemm(x, l.qn, l.mn, bits, l.mode, n, k, route=route)
+        assert torch.all((y.float() - ref).abs() <= 1e-3 * ref.abs() + 1e-3 * rms), route
+        _sampled_rows_check(y, x, w, rows, f"13B {n}x{k} {bits}b M={m} route {route}")
+        outs[route] = y
+    d = (outs[ops.GEMM_TILED].float() - outs[ops.GEMM_RING].float()).abs()
+    assert torch.all(d <= 2.0 ** -9 * ref.abs() + 1e-3 * rms)

@@ -35,6 +35,66 @@ def test_two_replicas_gloo():
     assert abs(v0 - 2 * 5 / t0) < 1e-9
 
 
+_RANK_SCRIPT = """
+import json, os, sys, time
+sys.path.insert(0, {root!r})
+from amq_amd.replicas import Replicas
+r = Replicas(backend="gloo")
+t = r.timed(lambda: time.sleep(0.01 * (r.rank + 1)), steps=4)
+per = r.gather(4 / r.last_local)
+if r.rank == 0:
+    print(json.dumps({{"n": r.world, "t": t, "per_rank": per, "value": r.world * 4 / t}}), flush=True)
+r.close()
+"""
+
+
+def test_launch_local_spawns_ranks(tmp_path):
+    """what `bench.py --gpus N` does when no launcher set WORLD_SIZE: N fresh children, one result line from rank 0"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(root=root))
+    drv = tmp_path / "drv.py"
+    drv.write_text(f"import sys; sys.path.insert(0, {root!r})\nfrom amq_amd.replicas import launch_local\n"
+                   f"sys.exit(launch_local(2, [sys.executable, {str(script)!r}], timeout=120))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(drv)], capture_output=True, text=True, timeout=180, env=env)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n"] == 2 and len(d["per_rank"]) == 2 and d["per_rank"][0] > d["per_rank"][1]
+    assert d["t"] >= 4 * 0.02 and abs(d["value"] - 2 * 4 / d["t"]) < 1e-6
+    # a failing rank fails the launch (and does not hang it)
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\nsys.exit(3) if os.environ['RANK'] == '1' else time.sleep(30)\n")
+    drv.write_text(f"import sys; sys.path.insert(0, {root!r})\nfrom amq_amd.replicas import launch_local\n"
+                   f"sys.exit(launch_local(2, [sys.executable, {str(bad)!r}], timeout=60))\n")
+    out = subprocess.run([sys.executable, str(drv)], capture_output=True, text=True, timeout=90, env=env)
+    assert out.returncode != 0
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` with no launcher starts 2 ranks itself (here, without a GPU, both refuse loudly and the
+    launch fails instead of silently benchmarking one device)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert out.stderr.count("needs a GPU") >= 1          # (the second rank may be terminated before it prints)
+    # a launcher that started a different number of ranks is an error, not a silent 1-GPU run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=300, env=env2)
+    assert out.returncode != 0 and "launcher started 1 rank" in out.stderr
+
+
 def test_single_process_needs_no_process_group():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         os.environ.pop(k, None)

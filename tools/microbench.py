@@ -19,6 +19,7 @@ from amq_amd.hqq_format import random_hqq  # noqa: E402
 
 HOT = False
 ZERO = False
+ROUTE = 0
 
 
 def layer_bytes(n, k, bits, m=1):
@@ -39,6 +40,9 @@ def bench_case(n, k, bits, m, iters, fn_name="gemv"):
     x = torch.randn(m, k, device=dev).half()
     y = torch.empty(m, n, device=dev, dtype=torch.float16)
     fn = getattr(ops, fn_name)
+    if fn_name == "gemm" and ROUTE:
+        def fn(x_, q, mt, bits_, mode, n_, k_, out=None):
+            return ops.gemm(x_, q, mt, bits_, mode, n_, k_, out=out, route=ROUTE)
     if fn_name == "gemm_xfrag":                       # x pre-arranged in fragment order (ops.xfrag), as a fused producer would
         xf = ops.xfrag(x, m, k)
         ref = ops.gemm(x, qn0, mn0, bits, ops.MODE_HQQ, n, k)
@@ -86,7 +90,7 @@ def main():
     ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--rpt", type=int, default=0)
     ap.add_argument("--math", type=int, default=0)
-    ap.add_argument("--nsub", type=int, default=0)
+    ap.add_argument("--route", type=int, default=0, help="GEMM kernel family: 0 auto, 1 tiled, 2 skinny, 3 ring")
     ap.add_argument("--gemv", type=int, default=1)
     ap.add_argument("--gemm", type=int, default=1)
     ap.add_argument("--zero", type=int, default=0, help="1: all-zero packed weights (data-dependent clock check)")
@@ -103,12 +107,11 @@ def main():
     ZERO = bool(args.zero)
     from amq_amd import _lib
     ops.LIB_GEMM_ROWS = args.lib_gemm_rows
-    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DOT, args.dot))
-    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_WAVES, args.waves))
-    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_DEPTH, args.depth))
-    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_RPT, args.rpt))
-    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMV_MATH, args.math))
-    _lib.check(_lib.load().amq_set_option(_lib.OPT_GEMM_NSUB, args.nsub))
+    # per-call options, set explicitly from this tool's command line (the library has no option state)
+    if args.dot or args.waves or args.depth or args.rpt or args.math:
+        ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(math=args.math, waves=args.waves, depth=args.depth, rpt=args.rpt, dot=args.dot)
+    global ROUTE
+    ROUTE = args.route
     shapes = [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096)]
     if args.quick:
         shapes = shapes[:2]

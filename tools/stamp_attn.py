@@ -19,7 +19,7 @@ vcs = [torch.randn(1, nkv, max_seq, 128, device=dev).half() for _ in range(nlaye
 q = torch.randn(1, nh * 128, device=dev).half(); k = torch.randn(1, nkv * 128, device=dev).half(); v = torch.randn(1, nkv * 128, device=dev).half()
 out = torch.zeros(1, nh * 128, dtype=torch.float16, device=dev)
 tab = ops.rope_table(max_seq, 10000.0, dev)
-cur, posd = ops.new_step_state(dev)              # the graph-replay form: cos/sin row + position in one block
+cur, posd, _err = ops.new_step_state(dev)              # the graph-replay form: cos/sin row + position in one block
 cur.copy_(tab.view(max_seq, 128)[pos]); posd.fill_(pos)
 junk = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 stamps = torch.zeros(nlayer, nh, 16, dtype=torch.int64, device=dev)
