@@ -229,6 +229,31 @@ __device__ __forceinline__ void dequant_lane_sd(const uint32_t* w, h2 meta, h2* 
     }
 }
 
+// One pair of a lane's tile (compile-time pair index P = 4t + p), same arithmetic as dequant_lane_sd: lets a kernel spread
+// the unpack of a tile over its MFMA steps instead of doing all 16 pairs in one block.
+template <int BITS, int MODE, int P>
+__device__ __forceinline__ h2 dequant_pair_sd(const uint32_t* w, const SdMeta& m) {
+    if (BITS == 4) {
+        const uint32_t u = w[P / 4];
+        constexpr int p = P % 4;
+        return sd_pair<4, MODE, 6>(p == 0 ? u << 6 : p == 1 ? u << 2 : p == 2 ? u >> 2 : u >> 6, m);
+    } else if (BITS == 2) {
+        const uint32_t u = w[P / 8];
+        constexpr int q = P % 8;
+        const uint32_t t = q < 3 ? u << 4 : q < 6 ? u >> 2 : u >> 8;
+        constexpr int SH = 4 + 2 * (q % 3);
+        return sd_pair<2, MODE, SH>(t, m);
+    } else {
+        if (P == 15) {
+            const uint32_t e = ((w[0] >> 8) & 0x00800080u) | ((w[1] >> 7) & 0x01000100u) | ((w[2] >> 6) & 0x02000200u);
+            return sd_pair<3, MODE, 7>(e, m);
+        }
+        const uint32_t u = w[P / 5 < 3 ? P / 5 : 2];
+        constexpr int q = P % 5;
+        return sd_pair<3, MODE, 7>(q == 0 ? u << 7 : q == 1 ? u << 4 : q == 2 ? u << 1 : q == 3 ? u >> 2 : u >> 5, m);
+    }
+}
+
 // Integer-only view of the same map (used by the repack / reference-format
 // kernels): where does weight (t, j) of a lane live?
 __host__ __device__ __forceinline__ void native_slot(int bits, int t, int j, int* dword, int* shift) {

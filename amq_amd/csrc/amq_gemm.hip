@@ -449,6 +449,7 @@ int gemm_pick_splits(int M, int N, int K, int route) {
     const long wg = (long)((M + 63) / 64) * ((N + bn - 1) / bn);      // 64-row tiles (what such launches use)
     const int G = K >> 7;
     if (gemm_is_skinny(M, N, K, route)) return 1;                        // gemm_skinny_kernel: no partials
+    if (route == GEMM_ROUTE_RING || (route == GEMM_ROUTE_AUTO && gemm_takes_ring(M, N, K))) return 1;
     if (wg >= target * 3 / 4 || G < 4 || (N & 7)) return 1;
     int s = (int)((target + wg - 1) / wg);
     if (s > 8) s = 8;
@@ -486,7 +487,18 @@ static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
     return gemm_launch_cfg<BITS, MODE, 128, 2>(a, st);
 }
 
+// Many-row policy (profiles/r02_gemm_routes.txt, 3-bit, TFLOP/s tiled | ring): the 256 x 256 ring kernel wins once its tiles
+// fill most of the chip -- 172 tiles (11008x4096, M = 1024) 732 | 857, 216 tiles (13824x5120, M = 1024) 822 | 1060, 256 tiles
+// (4096^2, M = 4096) 876 | 1086, 6912 tiles (13824x5120, M = 32768) 969 | 1165-1250 -- and loses below: 128 tiles
+// (4096^2, M = 2048) 787 | 664, 108 tiles (13824x5120, M = 512) 731 | 599.
+bool gemm_takes_ring(int M, int N, int K) {
+    const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+    return tiles >= 150 && K >= 256;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route) {
+    if (route == GEMM_ROUTE_RING && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
+    if (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K) && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
     if (gemm_is_skinny(a.M, a.N, a.K, route)) {
         if (a.mode == MODE_HQQ) {
             if (a.bits == 4) return skinny_launch<4, MODE_HQQ>(a, st);

@@ -59,6 +59,9 @@ struct GemmArgs {
 // route: which kernel family serves the launch (AUTO: by shape; the others force one for tests / A-B tools)
 enum { GEMM_ROUTE_AUTO = 0, GEMM_ROUTE_TILED = 1, GEMM_ROUTE_SKINNY = 2, GEMM_ROUTE_RING = 3 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route = GEMM_ROUTE_AUTO);
+hipError_t launch_gemm_ring(const GemmArgs& a, hipStream_t st);      // amq_gemm_ring.hip: 256 x 256 tiles, LDS rings, counted waits
+bool gemm_ring_ok(const GemmArgs& a);
+bool gemm_takes_ring(int M, int N, int K);                          // GEMM_ROUTE_AUTO's choice for the shape
 hipError_t launch_gemm_xfrag(const GemmArgs& a, hipStream_t st);     // a.x in fragment order (launch_xfrag)
 hipError_t launch_xfrag(const void* src, void* xf, int M, int K, long stride_m, long stride_kt, hipStream_t st);
 int gemm_pick_splits(int M, int N, int K, int route = GEMM_ROUTE_AUTO);

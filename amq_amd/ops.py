@@ -183,12 +183,13 @@ def _splitk_workspace(device, nbytes):
     return _SPLITK_WS.get(device, (nbytes + 3) // 4)
 
 
-# Rows from which `gemm` hands the (bit-exactly) dequantized weights to the library GEMM instead of running the fused
-# unpack + MFMA kernel.  In the MFMA-bound regime the unpack is pure overhead: the dequantize kernel costs 10-30 us per
-# layer once, hipBLASLt then runs at 1.45-1.5 PFLOP/s where the fused kernel reaches 1.0-1.05 (tools/lib_gemm_crossover.py:
-# 5120x5120, M = 1024 / 2048 / 4096 / 32768: 69 / 104 / 189 / 1196 us against 76 / 137 / 224 / 1708).  This is also what the
-# reference does from 128 rows on (GPTQLinear.forward: torch unpack + matmul, hqq/backends/autogptq.py:245-283).  0 disables.
-LIB_GEMM_ROWS = 1024
+# OPT-IN alternative for many rows: from LIB_GEMM_ROWS rows on (0 = never, the default) `gemm` runs the bit-exact dequantize
+# kernel into a scratch and hands the plain fp16 GEMM to the library (torch.matmul -> hipBLASLt) -- what the reference itself
+# does from 128 rows on (GPTQLinear.forward: torch unpack + matmul, hqq/backends/autogptq.py:245-283).  The product path is
+# the hand-written kernels at every size (profiles/r02_gemm_routes.txt: the fused ring kernel reaches 1.15-1.3 PFLOP/s at
+# BASELINE configs[3] sizes against 1.43-1.52 for dequantize + hipBLASLt, and beats it on several mid-size shapes);
+# bench.py --config 4 reports the library route next to it.
+LIB_GEMM_ROWS = 0
 _DEQ_SCRATCH = _ScratchPool(torch.float16)
 
 
@@ -201,7 +202,7 @@ def gemm_route_name(M):
     """what :func:`gemm` runs for M rows under the current settings (for result files)"""
     if LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
         return "amq::dequant_kernel + library GEMM (torch.matmul -> hipBLASLt)"
-    return "amq::gemm_kernel family (fused unpack + MFMA, hand-written)"
+    return "amq::gemm_ring_kernel / amq::gemm_kernel (fused unpack + MFMA, hand-written; 256x256 ring tiles when they fill the chip)"
 
 
 def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=GEMM_AUTO):
