@@ -65,6 +65,7 @@ SIGNATURES = {
     "amq_xfrag_f16": (_i, [_vp, _vp, _i, _i, ctypes.c_longlong, ctypes.c_longlong, _vp]),
     "amq_rmsnorm_xfrag_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "amq_gemm_xfrag_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "amq_attn_prefill_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 10 + [_vp]),
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_silu_mul_f16": (_i, [_vp, _vp, _vp, _sz, _vp]),
@@ -109,8 +110,12 @@ def check(rc):
 
 
 def current_stream():
+    """raw handle of torch's current HIP stream on the current device"""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    except AttributeError:                      # (older / newer torch without the private fast path)
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def ptr(t):

@@ -374,6 +374,25 @@ int amq_attn_decode_cur_f16(const void* q, const void* k, const void* v, void* k
     return check_hip(amq::launch_attn_decode(a, batch, (hipStream_t)stream), "attn_decode_cur");
 }
 
+int amq_attn_prefill_f16(const void* q, const void* k, const void* v, void* out, int batch, int S, int pos0, int n_heads,
+                         int n_kv_heads, int head_dim, long long q_rstride, long long q_bstride, long long k_rstride,
+                         long long k_bstride, long long k_hstride, long long v_rstride, long long v_bstride, long long v_hstride,
+                         long long o_rstride, long long o_bstride, void* stream) {
+    if (!q || !k || !v || !out) return fail(AMQ_EINVAL, "null pointer");
+    if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
+    if (batch < 1 || batch > 65535 || S < 1 || pos0 < 0 || n_heads < 1 || n_heads > 65535 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0)
+        return fail(AMQ_ESHAPE, "bad sizes (batch %d, S %d, pos0 %d, %d q heads, %d kv heads)", batch, S, pos0, n_heads, n_kv_heads);
+    const long long strides[] = {q_rstride, q_bstride, k_rstride, k_bstride, k_hstride, v_rstride, v_bstride, v_hstride, o_rstride, o_bstride};
+    for (long long sv : strides)
+        if (sv < 0 || (sv % 8) != 0) return fail(AMQ_ESHAPE, "strides must be non-negative multiples of 8 halves (16-byte vector access)");
+    if (q_rstride < (long long)n_heads * 128 || o_rstride < (long long)n_heads * 128 || k_rstride < 128 || v_rstride < 128)
+        return fail(AMQ_ESHAPE, "row strides smaller than the rows they separate");
+    amq::AttnPrefillArgs a{q, k, v, out, S, pos0, n_heads, n_kv_heads, batch, (long)q_rstride, (long)q_bstride, (long)k_rstride,
+                           (long)k_bstride, (long)k_hstride, (long)v_rstride, (long)v_bstride, (long)v_hstride, (long)o_rstride,
+                           (long)o_bstride};
+    return check_hip(amq::launch_attn_prefill(a, (hipStream_t)stream), "attn_prefill");
+}
+
 int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
                         const void* rope_table, void* rope_cur, int rope_rows, void* stream) {
     if (!logits || !embed || !token || !pos || !x) return fail(AMQ_EINVAL, "null pointer");

@@ -86,6 +86,16 @@ hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st);
 hipError_t launch_rmsnorm(const void* x, const void* gamma, void* y, int M, int K, float eps, hipStream_t st);
 hipError_t launch_rmsnorm_xfrag(const void* x, const void* gamma, void* xf, int M, int K, float eps, hipStream_t st);
+// causal attention over a whole prompt (amq_attn_prefill.hip).  Element (b, s, head, d) of q / out sits at
+// base + b*bstride + s*rstride + head*128 + d; key / value row t of kv head g at base + b*bstride + t*rstride + g*hstride + d.
+struct AttnPrefillArgs {
+    const void* q; const void* k; const void* v; void* out;
+    int S;                  // query rows per sequence (query s is at position pos0 + s and attends keys 0 .. pos0 + s)
+    int pos0;               // keys already in k / v before this prompt chunk
+    int n_heads, n_kv_heads, batch;
+    long q_rstride, q_bstride, k_rstride, k_bstride, k_hstride, v_rstride, v_bstride, v_hstride, o_rstride, o_bstride;
+};
+hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
 // prefill glue (amq_decode.hip)
 hipError_t launch_rope_cache(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
                              int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int max_seq, hipStream_t st);

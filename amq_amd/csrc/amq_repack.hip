@@ -137,25 +137,47 @@ __global__ __launch_bounds__(256) void dequant_native_kernel(const uint32_t* qn,
 }
 
 // HQQ Format A -> fp16 W[N,K] without going through the native layout:
-// W = ((unpack(W_q) - zero) * scale)  (quantize.py:184-199).  8 outputs / thread.
+// W = ((unpack(W_q) - zero) * scale)  (quantize.py:184-199), the standalone dequant the search-time proxy evaluation runs
+// thousands of times (amq/evaluation/evaluator.py:71-100; reference counterpart hqq/kernels/hqq_aten_cuda_kernel.cu:36-418,
+// axis=0 only there).  Format A packs C row-chunks of the grouped view [R = N*K/128, 128] into one element
+// (bitpack.py:24-110: C = 2 / 4 / 10 for 4 / 2 / 3 bit), so ONE packed row of 128 elements expands to C output rows.
+// A thread takes 8 consecutive columns of one packed row -- one 8-byte (32-byte for 3 bit) load, no per-element index
+// arithmetic -- and writes the C output rows' 8 halves as 16-byte stores; 16 threads cover a packed row, so every load
+// instruction reads whole 128-byte lines and every store instruction writes 256 contiguous bytes per output row.
 template <int BITS>
 __global__ __launch_bounds__(256) void dequant_hqq_kernel(const void* wq, const _Float16* scale, const _Float16* zero,
-                                                          int N, int K, _Float16* out) {
+                                                          int R, _Float16* out) {
+    constexpr int C = BITS == 4 ? 2 : BITS == 2 ? 4 : 10;
+    const int step = BITS == 3 ? (R + 9) / 10 : R / C;     // packed rows (3 bit: rows zero-padded to a multiple of 10)
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)N * K / 8;
-    if (gid >= total) return;
-    const size_t e0 = gid * 8;
-    const int n = (int)(e0 / K), k0 = (int)(e0 % K);
-    const size_t row = (size_t)n * (K >> 7) + (k0 >> 7);
-    const _Float16 s = scale[row], z = zero[row];
-    h8 v;
+    const int i = (int)(gid >> 4), c8 = (int)(gid & 15) * 8;
+    if (i >= step) return;
+    uint32_t q[8];                                         // the 8 packed elements, widened
+    if (BITS == 3) {
+        const u4 a = *(const u4*)((const uint32_t*)wq + (size_t)i * 128 + c8);
+        const u4 b = *(const u4*)((const uint32_t*)wq + (size_t)i * 128 + c8 + 4);
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    } else {
+        const u2 p = *(const u2*)((const uint8_t*)wq + (size_t)i * 128 + c8);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const _Float16 q = (_Float16)(float)fetch_q<FMT_HQQ, BITS>(wq, n, k0 + i, N, K);
-        const _Float16 d = q - z;
-        v[i] = d * s;
+        for (int e = 0; e < 4; ++e) { q[e] = (p.x >> (8 * e)) & 0xFFu; q[4 + e] = (p.y >> (8 * e)) & 0xFFu; }
     }
-    *(h8*)(out + e0) = v;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int row = c * step + i;
+        if (BITS == 3 && row >= R) continue;               // padding rows of the last chunks
+        const _Float16 s = scale[row], z = zero[row];
+        constexpr int width = BITS == 3 ? 3 : BITS;
+        const int shift = BITS == 3 ? 27 - 3 * c : 8 - width * (c + 1);      // chunk 0 sits in the top bits
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const _Float16 f = (_Float16)(float)((q[e] >> shift) & ((1u << width) - 1u));
+            const _Float16 d = f - z;                      // fp16 rounding #1
+            v[e] = d * s;                                  // fp16 rounding #2
+        }
+        *(h8*)(out + (size_t)row * 128 + c8) = v;
+    }
 }
 
 // mul[i] += (float)y[i]  -- the in-place fp32 accumulation of vecquant*matmul_faster_old (auto_gptq_kernel.cu:224)
@@ -203,11 +225,12 @@ hipError_t launch_dequantize(int bits, int mode, const void* qn, const void* mn,
 
 hipError_t launch_dequantize_hqq(int bits, const void* wq, const void* scale, const void* zero, int N, int K,
                                  void* w, hipStream_t st) {
-    const size_t threads = (size_t)N * K / 8;
-    const unsigned blocks = (unsigned)((threads + 255) / 256);
-    if (bits == 4) hipLaunchKernelGGL((dequant_hqq_kernel<4>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, N, K, (_Float16*)w);
-    else if (bits == 3) hipLaunchKernelGGL((dequant_hqq_kernel<3>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, N, K, (_Float16*)w);
-    else hipLaunchKernelGGL((dequant_hqq_kernel<2>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, N, K, (_Float16*)w);
+    const int R = (int)((size_t)N * K / 128);
+    const int step = bits == 3 ? (R + 9) / 10 : bits == 4 ? R / 2 : R / 4;
+    const unsigned blocks = (unsigned)(((size_t)step * 16 + 255) / 256);
+    if (bits == 4) hipLaunchKernelGGL((dequant_hqq_kernel<4>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w);
+    else if (bits == 3) hipLaunchKernelGGL((dequant_hqq_kernel<3>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w);
+    else hipLaunchKernelGGL((dequant_hqq_kernel<2>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w);
     return hipGetLastError();
 }
 

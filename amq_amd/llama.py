@@ -212,10 +212,10 @@ class QuantLlama:
         # a step past the cache is skipped there and raises the sticky error word, see check())
         if self.host_pos >= self.max_seq:
             raise ValueError(f"decode step at position {self.host_pos} does not fit the KV cache (max_seq={self.max_seq})")
+        if use_graph and self.graph is None:
+            self.capture()
         self.host_pos += 1
         if use_graph:
-            if self.graph is None:
-                self.capture()
             self.graph.replay()
         else:
             self._step()
@@ -258,6 +258,7 @@ class QuantLlama:
         g, static_ids = ent
         static_ids.copy_(ids.to(self.dev))
         g.replay()
+        self.host_pos = S                       # (the replay sets the device-side position; the host mirror is not part of it)
         return self.logits
 
     def _prefill_eager(self, ids):
@@ -293,8 +294,8 @@ class QuantLlama:
                 q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
             ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, 0, nh, nkv)
             if frag:
-                a = self._prefill_attention(q, blk, S, heads_first=True)            # [nh, S, 128], any strides
-                x = lin_xf(blk["self_attn.o_proj"], ops.xfrag(a, S, H, stride_m=a.stride(1), stride_kt=a.stride(0)), residual=x)
+                a = self._prefill_attention(q, blk, S)                             # [S, nh*128]
+                x = lin_xf(blk["self_attn.o_proj"], ops.xfrag(a, S, H), residual=x)
                 h2 = ops.rmsnorm_xfrag(x, blk["ln2"], self.eps)
                 g = lin_xf(blk["mlp.gate_proj"], h2)
                 act = lin_xf(blk["mlp.up_proj"], h2, gate=g)                       # silu(gate) * up in up_proj's epilogue
@@ -322,16 +323,11 @@ class QuantLlama:
         x = self.embed.index_select(0, ids.reshape(-1).to(self.dev))
 
         lin = self._rows_linear
-        sdpa = torch.nn.functional.scaled_dot_product_attention
         for blk in self.blocks:
             h = ops.rmsnorm(x, blk["ln1"], self.eps)
             q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
             ops.rope_rows(q, k, self.rope_tab, S, nh, nkv)
-            qh = q.view(B, S, nh, 128).transpose(1, 2)
-            kh, vh = k.view(B, S, nkv, 128).transpose(1, 2), v.view(B, S, nkv, 128).transpose(1, 2)
-            if nkv != nh:
-                kh, vh = kh.repeat_interleave(nh // nkv, dim=1), vh.repeat_interleave(nh // nkv, dim=1)
-            a = sdpa(qh, kh, vh, is_causal=True).transpose(1, 2).reshape(M, H).contiguous()
+            a = ops.attn_prefill(q, k, v, torch.empty_like(q), S, nh, nkv, batch=B)      # reads the projections in place
             x = lin(blk["self_attn.o_proj"], a, residual=x)
             h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
@@ -342,8 +338,12 @@ class QuantLlama:
             ops.gemv_f16w(last[b], self.lm_head, gamma=self.norm, eps=self.eps, out=logits[b])
         return logits
 
-    def _prefill_attention(self, q, blk, S, heads_first=False):
-        # q: [S, nh*128] rotated; K/V: the cache rows just written
+    def _prefill_attention(self, q, blk, S):
+        """causal attention of the prompt rows: q [S, nh*128] rotated, K / V = the cache rows just written -> [S, nh*128]"""
+        return ops.attn_prefill(q, blk["kc"], blk["vc"], torch.empty_like(q), S, self.nh, self.nkv, batch=1, kv_cache=True)
+
+    def _prefill_attention_sdpa(self, q, blk, S):
+        """the same through the framework's SDPA (comparison point for tests / tools; not on the product path)"""
         nh, nkv = self.nh, self.nkv
         qh = q.view(S, nh, 128).transpose(0, 1)
         kh, vh = blk["kc"][0, :, :S], blk["vc"][0, :, :S]
@@ -351,8 +351,6 @@ class QuantLlama:
             kh = kh.repeat_interleave(nh // nkv, dim=0)
             vh = vh.repeat_interleave(nh // nkv, dim=0)
         a = torch.nn.functional.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
-        if heads_first:
-            return a if a.stride(2) == 1 else a.contiguous()
         return a.transpose(0, 1).reshape(S, self.H).contiguous()
 
     def _prefill_finish(self, x, S):
@@ -384,7 +382,7 @@ class QuantLlama:
             q, k = self._rope(q, positions), self._rope(k, positions)
             blk["kc"][0, :, :S] = k.transpose(0, 1)
             blk["vc"][0, :, :S] = v.transpose(0, 1)
-            x = x + lin(blk["self_attn.o_proj"], self._prefill_attention(q.reshape(S, nh * 128), blk, S))
+            x = x + lin(blk["self_attn.o_proj"], self._prefill_attention_sdpa(q.reshape(S, nh * 128).contiguous(), blk, S))
             h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
             x = x + lin(blk["mlp.down_proj"], torch.nn.functional.silu(g) * u)

@@ -410,6 +410,33 @@ def rope_cache(q, k, v, kcache, vcache, table, pos0, n_heads, n_kv_heads):
                                               kcache.shape[1], _lib.current_stream()))
 
 
+def attn_prefill(q, k, v, out, S, n_heads, n_kv_heads, batch=1, pos0=0, kv_cache=False):
+    """Causal attention over a prompt (amq_attn_prefill_f16).  q / out: fp16 [batch*S, n_heads*128] (q rotated).
+    kv_cache=False: k / v are projection outputs [batch*S, n_kv_heads*128] (rotated keys); kv_cache=True: k / v are cache
+    tensors [batch, n_kv_heads, max_seq, 128] whose rows 0 .. pos0+S-1 are valid."""
+    H = n_heads * 128
+    _need(q, torch.float16, "q", batch * S * H)
+    _need(out, torch.float16, "out", batch * S * H)
+    if kv_cache:
+        if k.dim() != 4 or k.shape[0] != batch or k.shape[1] != n_kv_heads or k.shape[3] != 128 or v.shape != k.shape:
+            raise ValueError("caches must be [batch, n_kv_heads, max_seq, 128]")
+        max_seq = k.shape[2]
+        if pos0 + S > max_seq:
+            raise ValueError(f"keys 0..{pos0 + S - 1} do not fit the cache (max_seq={max_seq})")
+        _need(k, torch.float16, "kcache")
+        _need(v, torch.float16, "vcache")
+        kr, kb, kh = 128, n_kv_heads * max_seq * 128, max_seq * 128
+    else:
+        if pos0 != 0:
+            raise ValueError("pos0 needs a cache")
+        _need(k, torch.float16, "k", batch * S * n_kv_heads * 128)
+        _need(v, torch.float16, "v", batch * S * n_kv_heads * 128)
+        kr, kb, kh = n_kv_heads * 128, S * n_kv_heads * 128, 128
+    _lib.check(_lib.load().amq_attn_prefill_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(out), batch, S, int(pos0), n_heads,
+                                                n_kv_heads, 128, H, S * H, kr, kb, kh, kr, kb, kh, H, S * H, _lib.current_stream()))
+    return out
+
+
 def rope_rows(q, k, table, seq_len, n_heads, n_kv_heads, pos0=0):
     """RoPE in place on q [rows, n_heads*128] and k [rows, n_kv_heads*128], rows = batch * seq_len (no cache)."""
     rows = q.shape[0]

@@ -247,6 +247,19 @@ int amq_rmsnorm_xfrag_f16(const void* x, const void* gamma, void* xf, int M, int
 int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qweight_native, const void* meta_native,
                        const void* bias, const void* gate, const void* residual, void* y, int M, int N, int K, int group,
                        int y_stride, void* stream);
+/* Causal self-attention over a prompt: for every sequence b < batch, query row s < S (position pos0 + s) and head h,
+ *     out[b, s, h, :] = softmax(q[b, s, h, :] . K[b, 0 .. pos0 + s, g, :]^T / sqrt(128)) . V[b, 0 .. pos0 + s, g, :],   g = h / (n_heads / n_kv_heads)
+ * as one flash-style MFMA kernel (fp32 scores and softmax, fp16 probabilities, like the eager HF path).  q must already be
+ * rotated (amq_rope_cache_f16 / amq_rope_rows_f16), k rotated keys.  Layouts are given by strides in halves (multiples of 8):
+ * element (b, s, h, d) of q / out at b*bstride + s*rstride + h*128 + d; key / value row t of kv head g at
+ * b*bstride + t*rstride + g*hstride + d -- so the KV cache [n_kv_heads, max_seq, 128] (rstride 128, hstride max_seq*128) and
+ * a projection output [rows, n_kv_heads*128] (rstride n_kv_heads*128, hstride 128) are both read in place, and out can be the
+ * [rows, n_heads*128] matrix o_proj consumes.  Replaces the eager attention of the reference's prefill branch
+ * (amq/kernel/monkeypatch/ftllama_modeling.py:88-126). */
+int amq_attn_prefill_f16(const void* q, const void* k, const void* v, void* out, int batch, int S, int pos0, int n_heads,
+                         int n_kv_heads, int head_dim, long long q_rstride, long long q_bstride, long long k_rstride,
+                         long long k_bstride, long long k_hstride, long long v_rstride, long long v_bstride, long long v_hstride,
+                         long long o_rstride, long long o_bstride, void* stream);
 /* RoPE + KV-cache write for S new rows at positions pos0 .. pos0+S-1 of ONE sequence: q fp16 [S, n_heads*128] is
  * rotated in place; k [S, n_kv_heads*128] is rotated into kcache[h][pos0+s][:], v copied into vcache (both
  * [n_kv_heads, max_seq, 128]); rope_table from amq_rope_table_f16 (rows past rope_rows-1 clamp).  Same numerics as the

@@ -479,3 +479,47 @@ def test_prefill_graph_survives_scratch_growth():
     kept = {t.data_ptr() for t in ops._SPLITK_WS._keep} | {t.data_ptr() for t in ops._SPLITK_WS._cur.values()}
     assert all(p in kept for p in ws_before)                   # nothing a graph may reference was released
     del junk
+
+
+@pytest.mark.parametrize("S,nh,nkv,batch,pos0", [(5, 4, 4, 1, 0), (64, 4, 2, 1, 0), (65, 8, 2, 2, 0), (200, 4, 4, 1, 0),
+                                                  (130, 4, 1, 3, 0), (33, 4, 2, 1, 70), (257, 2, 2, 1, 0)])
+def test_attn_prefill_matches_eager_formula(S, nh, nkv, batch, pos0):
+    """amq_attn_prefill_f16 (flash-style MFMA kernel: transposed products, hardware transpose read of V, online softmax)
+    against the eager HF formula in fp32: softmax(mask(q k^T / sqrt(d))) v, GQA, ragged prompt lengths, several sequences,
+    and a prompt chunk appended behind pos0 cached keys (cache layout) -- element-wise to fp16 accuracy."""
+    from amq_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(S * 7 + nh + pos0)
+    H, KV = nh * 128, nkv * 128
+    q = torch.randn(batch * S, H, generator=g).half().to(dev)
+    T = pos0 + S
+    if pos0:
+        max_seq = T + 9
+        kc = torch.zeros(batch, nkv, max_seq, 128, dtype=torch.float16, device=dev)
+        vc = torch.zeros_like(kc)
+        kc[:, :, :T] = torch.randn(batch, nkv, T, 128, generator=g).half().to(dev)
+        vc[:, :, :T] = torch.randn(batch, nkv, T, 128, generator=g).half().to(dev)
+        kc[:, :, T:] = 1e4; vc[:, :, T:] = 1e4                      # rows past the context must never be read into the result
+        out = ops.attn_prefill(q, kc, vc, torch.empty_like(q), S, nh, nkv, batch=batch, pos0=pos0, kv_cache=True)
+        kf = kc[:, :, :T].float()                                   # [B, nkv, T, 128]
+        vf = vc[:, :, :T].float()
+    else:
+        k = torch.randn(batch * S, KV, generator=g).half().to(dev)
+        v = torch.randn(batch * S, KV, generator=g).half().to(dev)
+        out = ops.attn_prefill(q, k, v, torch.empty_like(q), S, nh, nkv, batch=batch)
+        kf = k.view(batch, S, nkv, 128).transpose(1, 2).float()
+        vf = v.view(batch, S, nkv, 128).transpose(1, 2).float()
+    qf = q.view(batch, S, nh, 128).transpose(1, 2).float()          # [B, nh, S, 128]
+    kf = kf.repeat_interleave(nh // nkv, dim=1)
+    vf = vf.repeat_interleave(nh // nkv, dim=1)
+    sc = qf @ kf.transpose(-1, -2) / (128 ** 0.5)
+    mask = torch.arange(T, device=dev)[None, :] > (pos0 + torch.arange(S, device=dev))[:, None]
+    sc = sc.masked_fill(mask[None, None], float("-inf"))
+    ref = (torch.softmax(sc, dim=-1) @ vf).transpose(1, 2).reshape(batch * S, H)
+    err = (out.float() - ref).abs()
+    assert torch.isfinite(out.float()).all()
+    assert err.max() <= 4e-3 * ref.abs().max() + 1e-3, err.max()    # fp16 probabilities + fp16 output rounding
+    # deterministic
+    again = ops.attn_prefill(q, kc if pos0 else k, vc if pos0 else v, torch.empty_like(q), S, nh, nkv, batch=batch, pos0=pos0,
+                             kv_cache=bool(pos0))
+    assert torch.equal(again, out)

@@ -152,3 +152,43 @@ def test_reference_ffi_shaped_entry_points(path):
             _lib.check(fn(vp(x), vp(kq), vp(sc), vp(sz), vp(y), m, n, k, 128, vp(ws), ws.numel(), 0, st))
             ref = linear_ref.linear_f16(g["gptq_x"][:m], w).astype(np.float32)
             assert np.all(np.abs(y.float().cpu().numpy() - ref) <= 1e-3 * np.abs(ref) + 1e-3 * np.sqrt(np.mean(ref ** 2)))
+
+
+def test_module_walk_decode_matches_runner():
+    """The drop-in shape of the decode loop (HF-style walk over HIPQuantLinear.forward calls, one launch per module) and
+    the fused runner produce the same tokens on the same weights / caches; eager and hipGraph replays of the walk are
+    bit-identical; the per-module argument cache survives deepcopy and notices moved buffers."""
+    import copy
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama
+    from amq_amd.module_walk import ModuleWalkLlama
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 2, 1, vocab=1024))
+    al = {name: [b, c] for name, b, c in zip(cfg["linear"], [2, 3, 4, 3, 2, 4, 3], [4, 2, 3, 3, 4, 2, 2])}
+    m = QuantLlama(cfg, al, device="cuda:0", max_seq=64, seed=8)
+    mw = ModuleWalkLlama(m)
+    ids = torch.randint(0, 1024, (9,), generator=torch.Generator().manual_seed(2)).to("cuda:0")
+    m.prefill(ids)
+    ref_tokens, ref_logits = [], []
+    for _ in range(5):
+        m.decode_step()
+        ref_tokens.append(int(m.token.item())); ref_logits.append(m.logits.float().clone())
+    for use_graph in (False, True):
+        m.prefill(ids)
+        same = True
+        for i in range(5):
+            mw.decode_step(use_graph=use_graph)
+            scale = ref_logits[i].abs().max()
+            if same:                                              # (a flipped argmax would send the two runs down different sequences)
+                assert (m.logits.float() - ref_logits[i]).abs().max() <= 2e-2 * scale    # differently fused roundings
+            same = same and int(m.token.item()) == ref_tokens[i]
+            if i == 0:
+                first = m.logits.clone() if not use_graph else first
+                if use_graph:
+                    assert torch.equal(m.logits, first)          # graph replay == eager launches of the same walk
+        m.check()
+    lin = mw.layers[0].self_attn.q_proj
+    x = torch.randn(1, 512, device="cuda:0").half()
+    y = lin(x)
+    lin2 = copy.deepcopy(lin)                                    # amq_speed_benchmark.py:231 deep-copies the patched model
+    assert lin2.qweight.data_ptr() != lin.qweight.data_ptr() and torch.equal(lin2(x), y)
+    assert torch.equal(lin(x.reshape(1, 1, 512)).reshape(1, -1), y) and lin(x.float()).dtype == torch.float32
