@@ -160,7 +160,7 @@ def cpu_baseline(seed=0):
 
 def load_traffic():
     """HBM bytes per GEMV launch from this round's committed rocprofv3 PMC pass over the CURRENT kernels
-    (profiles/r02_gemv_pmc.json, tools/collect_pmc.sh), or None -- never a stale constant."""
+    (profiles/r02_gemv_pmc.json, tools/collect_round.sh), or None -- never a stale constant."""
     p = os.path.join(ROOT, "profiles", "r02_gemv_pmc.json")
     if os.path.exists(p):
         try:
@@ -263,6 +263,17 @@ def run_gemm_mode(args, rep, dev):
         for name in m.cfg["linear"]:
             flops += 2.0 * M * blk[name].N * blk[name].K
     tf = flops / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    # comparison only (not the product path): the opt-in dequantize + library GEMM route on the same launches
+    ops.LIB_GEMM_ROWS = 1024
+    with torch.inference_mode():
+        linears()
+        torch.cuda.synchronize(dev)
+        e0.record()
+        linears()
+        e1.record()
+        torch.cuda.synchronize(dev)
+    ops.LIB_GEMM_ROWS = 0
+    tf_lib = flops / (e0.elapsed_time(e1) * 1e-3) / 1e12
     total_flops = sum(2.0 * M * blk[name].N * blk[name].K for blk in m.blocks for name in m.cfg["linear"])
     out = {
         "metric": "batched prompt passes/s (GeMM mode), Llama-2-13B AMQ mixed 2/3/4-bit avg-3-bit, 16 x 2048 rows",
@@ -278,6 +289,7 @@ def run_gemm_mode(args, rep, dev):
         "prompt_tokens_per_s": n_gpus * args.steps * M / elapsed,
         "linear_tflop_per_pass": total_flops / 1e12,
         "whole_pass_tflops": total_flops * args.steps / elapsed / 1e12,
+        "comparison_library_route_tflops": tf_lib,
         "finite_logits": ok,
     }
     print(json.dumps(out), flush=True)
