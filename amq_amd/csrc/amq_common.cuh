@@ -146,14 +146,14 @@ __device__ __forceinline__ void dequant_lane(const uint32_t* w, h2 meta, h2* out
 //
 // Scaling by a power of two commutes with fp16 rounding, so w is bit-identical
 // to the reference's two-rounding dequant (quantize.py:198) as long as
-// z * 2^E and (q - z) * 2^E are normal fp16 numbers: E = -3 / -2 / -5 for
-// 4 / 3 / 2 bit, i.e. for |z|, |q - z| >= 2^-11 / 2^-12 / 2^-9; below that the
+// z * 2^E and (q - z) * 2^E are normal fp16 numbers: E = -3 / -5 / -5 for
+// 4 / 3 / 2 bit, i.e. for |z|, |q - z| >= 2^-11 / 2^-9 / 2^-9; below that the
 // value involved is < 1e-3 of a quantization step and may differ by
 // <= 2^-24 * 2^-E (tests bound it).  Requires |s| * 2^-E < 65504.
 // MODE_FMA: w = fma(sub * 2^B, s * 2^-E, c)   (q * 2^E is exact).
 template <int BITS> struct SdCfg;
 template <> struct SdCfg<4> { static constexpr int E = -3; };
-template <> struct SdCfg<3> { static constexpr int E = -2; };
+template <> struct SdCfg<3> { static constexpr int E = -5; };   // (two field positions per shifted copy: 3 shifts per 5 pairs)
 template <> struct SdCfg<2> { static constexpr int E = -5; };
 
 struct SdMeta { h2 zc, sc; };
@@ -212,15 +212,16 @@ __device__ __forceinline__ void dequant_lane_sd(const uint32_t* w, h2 meta, h2* 
             out[8 * d + 6] = sd_pair<2, MODE, 4>(c, m);
             out[8 * d + 7] = sd_pair<2, MODE, 6>(c, m);
         }
-    } else {                    // fields at bits 3i -> bits 7..9
+    } else {                    // fields at bits 3i: three shifted copies put them at bit 4 or 7 (two positions per copy)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const uint32_t u = w[d];
-            out[5 * d + 0] = sd_pair<3, MODE, 7>(u << 7, m);
-            out[5 * d + 1] = sd_pair<3, MODE, 7>(u << 4, m);
-            out[5 * d + 2] = sd_pair<3, MODE, 7>(u << 1, m);
-            out[5 * d + 3] = sd_pair<3, MODE, 7>(u >> 2, m);
-            out[5 * d + 4] = sd_pair<3, MODE, 7>(u >> 5, m);
+            const uint32_t a = u << 4, b = u >> 2, c = u >> 8;
+            out[5 * d + 0] = sd_pair<3, MODE, 4>(a, m);
+            out[5 * d + 1] = sd_pair<3, MODE, 7>(a, m);
+            out[5 * d + 2] = sd_pair<3, MODE, 4>(b, m);
+            out[5 * d + 3] = sd_pair<3, MODE, 7>(b, m);
+            out[5 * d + 4] = sd_pair<3, MODE, 4>(c, m);
         }
         // pair 15: value bit b of the (low, high) weight = bit (15, 31) of dword b -> bits 7+b
         const uint32_t e = ((w[0] >> 8) & 0x00800080u) | ((w[1] >> 7) & 0x01000100u) |
@@ -250,7 +251,9 @@ __device__ __forceinline__ h2 dequant_pair_sd(const uint32_t* w, const SdMeta& m
         }
         const uint32_t u = w[P / 5 < 3 ? P / 5 : 2];
         constexpr int q = P % 5;
-        return sd_pair<3, MODE, 7>(q == 0 ? u << 7 : q == 1 ? u << 4 : q == 2 ? u << 1 : q == 3 ? u >> 2 : u >> 5, m);
+        const uint32_t t = q < 2 ? u << 4 : q < 4 ? u >> 2 : u >> 8;
+        constexpr int SH = (q & 1) && q < 4 ? 7 : 4;
+        return sd_pair<3, MODE, SH>(t, m);
     }
 }
 

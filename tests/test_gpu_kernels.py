@@ -545,3 +545,25 @@ def test_gemm_13b_shapes_at_size(bits, n, k, m):
         outs[route] = y
     d = (outs[ops.GEMM_TILED].float() - outs[ops.GEMM_RING].float()).abs()
     assert torch.all(d <= 2.0 ** -9 * ref.abs() + 1e-3 * rms)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("m,n,k", [(300, 1040, 1152), (1024, 4096, 256)])
+def test_gemm_ring_fma_mode(bits, m, n, k):
+    """the ring kernel on MODE_FMA weights (w = fma(q, s, c): what GPTQ / AWQ imports carry): against an fp32 product on the
+    bit-exactly dequantized weights and against the tiled kernel (same fp16 weights, different summation order)"""
+    from amq_amd import ops
+    h, qn, mn, _ = _random_case(bits, n, k, seed=3 * bits + m)
+    dev = _dev()
+    meta = mn.view(-1, 2).clone()
+    meta[:, 1] = -(meta[:, 1] * meta[:, 0])                 # (s, z) -> (s, c = -z*s), the FMA form
+    mf = meta.reshape(-1).contiguous()
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(m + k)).half().to(dev)
+    w = ops.dequantize(qn, mf, bits, ops.MODE_FMA, n, k)
+    ref = x.float() @ w.float().t()
+    rms = ref.pow(2).mean().sqrt()
+    ring = ops.gemm(x, qn, mf, bits, ops.MODE_FMA, n, k, route=ops.GEMM_RING)
+    tiled = ops.gemm(x, qn, mf, bits, ops.MODE_FMA, n, k, route=ops.GEMM_TILED)
+    assert torch.all((ring.float() - ref).abs() <= 1e-3 * ref.abs() + 1e-3 * rms)
+    assert torch.all((ring.float() - tiled.float()).abs() <= 2.0 ** -9 * ref.abs() + 1e-3 * rms)
+    assert torch.equal(ops.gemm(x, qn, mf, bits, ops.MODE_FMA, n, k, route=ops.GEMM_RING), ring)
