@@ -135,6 +135,8 @@ def _prep_x(x, K):
 
 def gemv(x, qn, mn, bits, mode, N, K, bias=None, out=None, opts=None):
     """y = x . W^T for few rows (weight-streaming kernels).  ``opts``: a :class:`GemvOpts` (per-call A/B / math options)."""
+    if opts is None:
+        opts = DEFAULT_GEMV_OPTS
     if opts is not None:
         x2 = _prep_x(x, K)
         y = out if out is not None else torch.empty(x2.shape[0], N, dtype=torch.float16, device=x.device)

@@ -331,6 +331,7 @@ def main():
             run_gemm_mode(args, rep, dev)
         else:
             run_decode(args, rep, dev)
+        rep.barrier()               # rank 0 finishes its extra measurements before anyone tears the process group down
     finally:
         rep.close()
 
