@@ -434,7 +434,7 @@ static hipError_t skinny_launch(const GemmArgs& a, hipStream_t st) {
 // short (measured above: at 64 rows the kernel wins for 4096x4096, loses for N = 11008 -- 688 workgroups, 2.7 rounds --
 // and for K = 11008 -- 1.4 MB of x per workgroup)
 static bool gemm_is_skinny(int M, int N, int K, int route) {
-    if (route == GEMM_ROUTE_TILED || route == GEMM_ROUTE_RING) return false;
+    if (route == GEMM_ROUTE_TILED || route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128) return false;
     if (route == GEMM_ROUTE_SKINNY) return M <= 64;
     return M <= GEMM_SKINNY_MAX || (M <= 2 * GEMM_SKINNY_MAX && M <= 64 && (N >> 4) <= 320 && K <= 6144);
 }
@@ -449,7 +449,7 @@ int gemm_pick_splits(int M, int N, int K, int route) {
     const long wg = (long)((M + 63) / 64) * ((N + bn - 1) / bn);      // 64-row tiles (what such launches use)
     const int G = K >> 7;
     if (gemm_is_skinny(M, N, K, route)) return 1;                        // gemm_skinny_kernel: no partials
-    if (route == GEMM_ROUTE_RING || (route == GEMM_ROUTE_AUTO && gemm_takes_ring(M, N, K))) return 1;
+    if (route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128 || (route == GEMM_ROUTE_AUTO && gemm_takes_ring(M, N, K))) return 1;
     if (wg >= target * 3 / 4 || G < 4 || (N & 7)) return 1;
     int s = (int)((target + wg - 1) / wg);
     if (s > 8) s = 8;
@@ -487,17 +487,14 @@ static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
     return gemm_launch_cfg<BITS, MODE, 128, 2>(a, st);
 }
 
-// Many-row policy (profiles/r02_gemm_routes.txt, 3-bit, TFLOP/s tiled | ring): the 256 x 256 ring kernel wins once its tiles
-// fill most of the chip -- 172 tiles (11008x4096, M = 1024) 732 | 857, 216 tiles (13824x5120, M = 1024) 822 | 1060, 256 tiles
-// (4096^2, M = 4096) 876 | 1086, 6912 tiles (13824x5120, M = 32768) 969 | 1165-1250 -- and loses below: 128 tiles
-// (4096^2, M = 2048) 787 | 664, 108 tiles (13824x5120, M = 512) 731 | 599.
-bool gemm_takes_ring(int M, int N, int K) {
-    const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-    return tiles >= 150 && K >= 256;
-}
+// Many-row policy: the ring kernel (amq_gemm_ring.hip) whenever one of its tile shapes fills the chip (gemm_ring_rows),
+// else the kernels of this file (profiles/r02_gemm_routes.txt, 3-bit, TFLOP/s tiled | ring: 13824x5120 M = 1024 822 | 1060,
+// 4096^2 M = 4096 876 | 1086, M = 2048 (128-row tiles) 814 | 910, M = 1024 615 | 531 -> stays tiled).
+bool gemm_takes_ring(int M, int N, int K) { return K >= 256 && gemm_ring_rows(M, N) != 0; }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route) {
     if (route == GEMM_ROUTE_RING && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
+    if (route == GEMM_ROUTE_RING128 && gemm_ring_ok(a)) return launch_gemm_ring(a, st, 128);
     if (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K) && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
     if (gemm_is_skinny(a.M, a.N, a.K, route)) {
         if (a.mode == MODE_HQQ) {

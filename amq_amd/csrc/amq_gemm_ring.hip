@@ -38,12 +38,11 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int RG_THREADS = 512;
-constexpr int RG_BM = 256, RG_BN = 256;
+constexpr int RG_BN = 256;                        // (rows per tile: template parameter BM = 256, or 128 for launches of 50-150 big tiles)
 constexpr int RG_NA = 3;                          // x ring slots (half-tiles of 64 k)
-constexpr int RG_ABYTES = RG_BM * 64 * 2;         // 32 KiB
 constexpr int RG_WSLOT = 16 * 1024;               // packed W of one 128-k group: 16 column blocks x 64 lanes x 4*BITS B <= 16 KiB
 constexpr int RG_MSLOT = 8 * 256;                 // (scale, zero): 8 waves x 64 lanes x 4 B (upper 32 lanes: duplicates)
-constexpr int RG_LDS = RG_NA * RG_ABYTES + 2 * RG_WSLOT + 2 * RG_MSLOT;      // 135,168 B: one workgroup per CU
+constexpr int rg_lds(int bm) { return RG_NA * bm * 128 + 2 * RG_WSLOT + 2 * RG_MSLOT; }   // 135,168 B at 256 rows: one workgroup per CU
 
 // LDS-DMA as inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in a kernel hipcc (ROCm 7.2) turns EVERY
 // ds_read wait into `s_waitcnt lgkmcnt(0)` (it books the DMA as a flat access that may return out of order with LDS
@@ -65,14 +64,25 @@ __device__ __forceinline__ void rg_glds4(const void* gsrc, unsigned lds_dst) {
 #else
 #define RG_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
+// all but the youngest x half-tile (NXI DMA instructions of this wave) have landed
+#define RG_WAIT_X()                                                              \
+    do {                                                                         \
+        if constexpr (NXI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                    \
+    } while (0)
 #define RG_GLDS(src_, dst_, size_)                                                                                   \
     do {                                                                                                             \
         const unsigned d_ = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(dst_) - (unsigned)(size_t)smem + lds0); \
         if ((size_) == 16) rg_glds16((src_), d_); else rg_glds4((src_), d_);                                         \
     } while (0)
 
-template <int BITS, int MODE>
+template <int BITS, int MODE, int BM>
 __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int ntm, int ntn) {
+    constexpr int RG_BM = BM;
+    constexpr int RG_ABYTES = BM * 64 * 2;            // one x half-tile: 32 KiB (16 KiB at 128 rows)
+    constexpr int NRB = BM / 16;                      // row blocks = steps of a half-tile
+    constexpr int NXI = BM / 64;                      // LDS-DMA instructions per wave and x half-tile
+    constexpr int PPS = BM == 256 ? 2 : 3;            // weight pairs unpacked per step (16 pairs over steps 2 ..)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address of smem
     unsigned char* const a_ring = smem;
@@ -109,9 +119,9 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
     // ---- DMA sources
     // x: instruction i (0..31) of a half-tile fills rows 8i .. 8i+7 (128 B each); wave w issues i = w + 8j.
     // lane l -> row 8i + (l >> 3), LDS chunk position l & 7  <-  global chunk (l & 7) ^ ((row >> 1) & 7)
-    const _Float16* asrc[4];
+    const _Float16* asrc[NXI];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NXI; ++j) {
         const int row = 8 * (wave + 8 * j) + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         int m = m0 + row;
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
         const int hc = h < NH ? h : NH - 1;                // past the end: harmless re-read into a consumed slot (keeps the counts uniform)
         unsigned char* dst = a_ring + slot * RG_ABYTES + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) RG_GLDS(asrc[j] + hc * 64, dst + j * 8192, 16);
+        for (int j = 0; j < NXI; ++j) RG_GLDS(asrc[j] + hc * 64, dst + j * 8192, 16);
     };
     auto issue_w = [&](int g, int slot) {                  // NWI + 1 DMA instructions
         const int gc = g < G ? g : G - 1;
@@ -165,9 +175,9 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
         RG_GLDS(msrc + (size_t)gc * 64, m_ring + slot * RG_MSLOT + wave * 256, 4);
     };
 
-    f4 acc[16][2];
+    f4 acc[NRB][2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < NRB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
@@ -233,10 +243,10 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
             fx[d][1] = *(const h8*)(ab + d * 2048 + aoff1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        static_for<16>([&](auto rb_c) {
+        static_for<NRB>([&](auto rb_c) {
             constexpr int rb = decltype(rb_c)::value;
 #ifndef AMQ_RING_ABL_NOLDSX        /* timing-only ablation: operands are not re-read per row block */
-            if constexpr (rb + RD - 1 < 16) {
+            if constexpr (rb + RD - 1 < NRB) {
                 fx[(rb + RD - 1) % RD][0] = *(const h8*)(ab + (rb + RD - 1) * 2048 + aoff0);
                 fx[(rb + RD - 1) % RD][1] = *(const h8*)(ab + (rb + RD - 1) * 2048 + aoff1);
             }
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
                 if constexpr (rb == NDW - 1) RG_GLDS(msrc + (size_t)gc * 64, m_ring + dma_wslot * RG_MSLOT + wave * 256, 4);
                 else if constexpr (BITS == 2) RG_GLDS(wsrc[0] + (size_t)gc * TB, wdst, 16);
                 else RG_GLDS(wsrc[rb] + (size_t)gc * TB, wdst + rb * 1024, 16);
-            } else if constexpr (rb < NDW + 4) {
+            } else if constexpr (rb < NDW + NXI) {
                 constexpr int j = rb - NDW;
 #ifdef AMQ_RING_ABL_NOXDMA         /* timing-only ablation: the x image is never refreshed (a 4-byte DMA keeps the vmcnt counts) */
                 RG_GLDS(msrc + (size_t)gc * 64, m_ring + dma_wslot * RG_MSLOT + wave * 256, 4);
@@ -288,20 +298,17 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
             }
             if constexpr (false) {
 #else
-            if constexpr (rb >= 2 && rb < 10) {
+            if constexpr (rb >= 2 && PPS * (rb - 2) < 16) {
 #endif
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    constexpr int base = 2 * (rb - 2);
-                    const int idx = base + e;               // 0..15: [column block][pair of the half]
-                    const int nb = idx >> 3, pp = idx & 7;
-                    h2 v;
-                    // (compile-time pair index: spelled out per e because the template argument must be a constant)
-                    if (e == 0) v = dequant_pair_sd<BITS, MODE, 8 * NS + (base & 7)>(pk.w[base >> 3], pk.m[base >> 3]);
-                    else v = dequant_pair_sd<BITS, MODE, 8 * NS + ((base + 1) & 7)>(pk.w[(base + 1) >> 3], pk.m[(base + 1) >> 3]);
-                    wn.f[nb][pp >> 2][2 * (pp & 3)] = v.x;
-                    wn.f[nb][pp >> 2][2 * (pp & 3) + 1] = v.y;
-                }
+                static_for<PPS>([&](auto e_c) {
+                    constexpr int idx = PPS * (rb - 2) + decltype(e_c)::value;       // 0..15: [column block][pair of the half]
+                    if constexpr (idx < 16) {
+                        constexpr int nb = idx >> 3, pp = idx & 7;
+                        const h2 v = dequant_pair_sd<BITS, MODE, 8 * NS + pp>(pk.w[nb], pk.m[nb]);
+                        wn.f[nb][pp >> 2][2 * (pp & 3)] = v.x;
+                        wn.f[nb][pp >> 2][2 * (pp & 3) + 1] = v.y;
+                    }
+                });
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -314,7 +321,8 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
     issue_a(0, 0);
     issue_a(1, 1);
     WHalf w0, w1;
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // W(0) landed
+    if constexpr (NXI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // W(0) landed (two x half-tiles may be in flight)
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     {
         WPacked pk;
         read_packed(0, pk);
@@ -336,12 +344,12 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
         // clobber) must all be issued BEFORE this wave arrives at the barrier -- an MFMA issues only once its ds_read
         // operands have returned, so "every wave has passed compute_half" makes the vacated slot safe to refill (WAR).
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        RG_WAIT_X();
         RG_BARRIER();                                      // every wave's pieces landed; every wave is done reading half-tile 2g - 1
         asm volatile("" ::: "memory");                     // (compiler fence: no DMA issue / LDS read may move above the barrier)
         compute_half(std::integral_constant<int, 0>{}, sa, w0, g & 1, w1, 2 * g + 2, s2, g + 1, (g + 1) & 1);
         // half-tile 2g + 1
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        RG_WAIT_X();
         RG_BARRIER();
         asm volatile("" ::: "memory");
         compute_half(std::integral_constant<int, 1>{}, s1, w1, (g + 1) & 1, w0, 2 * g + 3, sa, 0, 0);
@@ -359,17 +367,17 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
         const int n = (cb0 + nb) * 16 + 4 * o;
         h4 bv = {0, 0, 0, 0};
         if (bias) bv = *(const h4*)(bias + n);
-        h4 rv[16];
+        h4 rv[NRB];
         if (res) {                                         // all residual loads of the column block first, ONE wait (not one per row block)
 #pragma unroll
-            for (int rb = 0; rb < 16; ++rb) {
+            for (int rb = 0; rb < NRB; ++rb) {
                 int m = m0 + 16 * rb + r;
                 m = m < a.M ? m : a.M - 1;
                 rv[rb] = *(const h4*)(res + (size_t)m * a.y_stride + n);
             }
         }
 #pragma unroll
-        for (int rb = 0; rb < 16; ++rb) {
+        for (int rb = 0; rb < NRB; ++rb) {
             const int m = m0 + 16 * rb + r;
             h4 v;
 #pragma unroll
@@ -381,14 +389,20 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
     }
 }
 
-template <int BITS, int MODE>
-static hipError_t ring_launch(const GemmArgs& a, hipStream_t st) {
-    auto k = gemm_ring_kernel<BITS, MODE>;
-    static hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+template <int BITS, int MODE, int BM>
+static hipError_t ring_launch_bm(const GemmArgs& a, hipStream_t st) {
+    auto k = gemm_ring_kernel<BITS, MODE, BM>;
+    static hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds(BM));
     if (attr != hipSuccess) return attr;
-    const int ntm = (a.M + RG_BM - 1) / RG_BM, ntn = (a.N + RG_BN - 1) / RG_BN;
-    hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(RG_THREADS), RG_LDS, st, a, ntm, ntn);
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + RG_BN - 1) / RG_BN;
+    hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(RG_THREADS), rg_lds(BM), st, a, ntm, ntn);
     return hipGetLastError();
+}
+
+template <int BITS, int MODE>
+static hipError_t ring_launch(const GemmArgs& a, hipStream_t st, int bm) {
+    if (bm == 128) return ring_launch_bm<BITS, MODE, 128>(a, st);
+    return ring_launch_bm<BITS, MODE, 256>(a, st);
 }
 
 bool gemm_ring_ok(const GemmArgs& a) {
@@ -396,15 +410,30 @@ bool gemm_ring_ok(const GemmArgs& a) {
     return (a.y_stride & 3) == 0 && a.splits <= 1 && a.K >= 128;
 }
 
-hipError_t launch_gemm_ring(const GemmArgs& a, hipStream_t st) {
+// Rows per tile (0: the launch is too small for this kernel).  All tiles of a launch cost the same, so a launch runs in
+// rounds of 256 workgroups: a tile shape is scored by its last-round fill, t / (256 ceil(t / 256)), times 0.85 for 128-row
+// tiles (twice the unpack work per MFMA); a shape needs >= 150 tiles to be considered (profiles/r02_gemm_routes.txt:
+// 128 tiles lose to the round-1 kernel, 160+ win; 11008x4096 at 2048 rows: 344 big tiles 0.89 PFLOP/s, 688 small ones 0.96).
+int gemm_ring_rows(int M, int N) {
+    const long nt = (N + RG_BN - 1) / RG_BN;
+    const long t256 = (long)((M + 255) / 256) * nt, t128 = (long)((M + 127) / 128) * nt;
+    auto fill = [](long t) { return (double)t / (256.0 * (double)((t + 255) / 256)); };
+    const double s256 = t256 >= 150 ? fill(t256) : 0.0, s128 = t128 >= 150 ? 0.85 * fill(t128) : 0.0;
+    if (s256 == 0.0 && s128 == 0.0) return 0;
+    return s256 >= s128 ? 256 : 128;
+}
+
+hipError_t launch_gemm_ring(const GemmArgs& a, hipStream_t st, int bm) {
+    if (bm != 128 && bm != 256) bm = gemm_ring_rows(a.M, a.N);
+    if (bm == 0) bm = 128;                                  // (forced onto a small launch: GEMM_ROUTE_RING in tests / tools)
     if (a.mode == MODE_HQQ) {
-        if (a.bits == 4) return ring_launch<4, MODE_HQQ>(a, st);
-        if (a.bits == 3) return ring_launch<3, MODE_HQQ>(a, st);
-        return ring_launch<2, MODE_HQQ>(a, st);
+        if (a.bits == 4) return ring_launch<4, MODE_HQQ>(a, st, bm);
+        if (a.bits == 3) return ring_launch<3, MODE_HQQ>(a, st, bm);
+        return ring_launch<2, MODE_HQQ>(a, st, bm);
     }
-    if (a.bits == 4) return ring_launch<4, MODE_FMA>(a, st);
-    if (a.bits == 3) return ring_launch<3, MODE_FMA>(a, st);
-    return ring_launch<2, MODE_FMA>(a, st);
+    if (a.bits == 4) return ring_launch<4, MODE_FMA>(a, st, bm);
+    if (a.bits == 3) return ring_launch<3, MODE_FMA>(a, st, bm);
+    return ring_launch<2, MODE_FMA>(a, st, bm);
 }
 
 }  // namespace amq

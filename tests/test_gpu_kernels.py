@@ -496,10 +496,12 @@ def _sampled_rows_check(y, x, w_dev, rows, what):
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("m,n,k,route", [(640, 12288, 512, 1), (2048, 3072, 256, 1), (517, 6144, 384, 1),
-                                         (640, 12288, 512, 3), (2048, 3072, 256, 3), (517, 6144, 384, 3), (300, 1040, 1152, 3)])
+                                         (640, 12288, 512, 3), (2048, 3072, 256, 3), (517, 6144, 384, 3), (300, 1040, 1152, 3),
+                                         (640, 12288, 512, 4), (517, 6144, 384, 4), (300, 1040, 1152, 4), (129, 2048, 256, 4)])
 def test_gemm_big_tiles(bits, m, n, k, route):
     """the many-row MFMA kernels on shapes that select their LARGE tiles (route 1: gemm_kernel<.,.,128,2> needs
-    ceil(M/128) * ceil(N/128) >= 384 workgroups; route 3: the 256-row ring kernel), ragged M tails, bias and an in-place
+    ceil(M/128) * ceil(N/128) >= 384 workgroups; route 3: the ring kernel, 256-row tiles when they fill the chip; route 4: the
+    ring kernel forced to 128-row tiles), ragged M tails, bias and an in-place
     residual, against the CPU oracle linear on the reference's dequantized weights."""
     from amq_amd import ops
     h, qn, mn, w_ref = _random_case(bits, n, k, seed=31 * bits + m, bias=True)
@@ -538,7 +540,7 @@ def test_gemm_13b_shapes_at_size(bits, n, k, m):
     rms = ref.pow(2).mean().sqrt()
     rows = torch.tensor(sorted({0, 1, m // 3, m // 2, m - 2, m - 1}), device=dev)
     outs = {}
-    for route in (ops.GEMM_TILED, ops.GEMM_RING):
+    for route in (ops.GEMM_TILED, ops.GEMM_RING, ops.GEMM_RING128):
         y = ops.gemm(x, l.qn, l.mn, bits, l.mode, n, k, route=route)
         assert torch.all((y.float() - ref).abs() <= 1e-3 * ref.abs() + 1e-3 * rms), route
         _sampled_rows_check(y, x, w, rows, f"13B {n}x{k} {bits}b M={m} route {route}")

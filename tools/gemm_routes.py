@@ -13,7 +13,7 @@ ap.add_argument("--shapes", default="13824,5120;5120,5120;5120,13824")
 ap.add_argument("--m", default="2048,32768")
 ap.add_argument("--bits", default="3,4")
 ap.add_argument("--rounds", type=int, default=5)
-ap.add_argument("--routes", default="1,3,lib")
+ap.add_argument("--routes", default="1,3,lib", help="1 tiled, 3 ring (rows by shape), 4 ring 128-row tiles, lib")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(0)
