@@ -482,7 +482,8 @@ def test_prefill_graph_survives_scratch_growth():
 
 
 @pytest.mark.parametrize("S,nh,nkv,batch,pos0", [(5, 4, 4, 1, 0), (64, 4, 2, 1, 0), (65, 8, 2, 2, 0), (200, 4, 4, 1, 0),
-                                                  (130, 4, 1, 3, 0), (33, 4, 2, 1, 70), (257, 2, 2, 1, 0)])
+                                                  (130, 4, 1, 3, 0), (33, 4, 2, 1, 70), (257, 2, 2, 1, 0),
+                                                  (300, 32, 8, 3, 0), (200, 32, 32, 4, 100)])      # (many workgroups: several per CU)
 def test_attn_prefill_matches_eager_formula(S, nh, nkv, batch, pos0):
     """amq_attn_prefill_f16 (flash-style MFMA kernel: transposed products, hardware transpose read of V, online softmax)
     against the eager HF formula in fp32: softmax(mask(q k^T / sqrt(d))) v, GQA, ragged prompt lengths, several sequences,
