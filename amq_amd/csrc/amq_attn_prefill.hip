@@ -16,6 +16,7 @@
 // The online softmax is per lane (one query row per lane): the running max needs two cross-lane steps per tile (the four
 // 16-lane groups hold different keys of the same rows), the running sum is kept per lane and reduced once at the end.
 // HF-Llama numerics as in the decode kernel: fp16 q/k/v, fp32 scores and softmax, probabilities rounded to fp16 before P.V.
+#include <type_traits>
 #include "amq_common.cuh"
 #include "amq_kernels.h"
 
@@ -24,18 +25,37 @@ namespace amq {
 constexpr int AP_BKV = 64, AP_D = 128;
 constexpr int AP_TILE = AP_BKV * AP_D * 2;             // 16 KiB per K or V tile
 typedef __fp16 ap_v4h __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// LDS-DMA (global -> LDS, no registers) as inline assembly: with the builtin anywhere in a kernel hipcc (ROCm 7.2) makes every LDS
+// read wait lgkmcnt(0) (see amq_gemm_ring.hip).  sbase = wave-uniform 64-bit base, voff = this lane's byte offset, lds_dst =
+// wave-uniform LDS byte address; lane l's 16 bytes land at lds_dst + 16 l.  M0 is compiler-reserved: saved and restored.
+__device__ __forceinline__ void ap_glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 
 // QB = 16-row query blocks per wave (1: 64 query rows per workgroup; 2: 128 -- every K / V fragment read from LDS then feeds two
-// MFMAs and a staged tile serves twice the rows: at 1 the kernel is LDS-bound, 1 KB read per MFMA)
+// MFMAs and a staged tile serves twice the rows)
 template <int QB>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a) {
     constexpr int BQ = 64 * QB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2 buffers][K tile | V tile]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int r = lane & 15, o = lane >> 4;
-    // heaviest query blocks first (a causal block walks keys 0 .. its last row): the launch does not end on a few long workgroups
-    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x, h = (int)blockIdx.y, b = (int)blockIdx.z;
+    // Workgroup -> (sequence, head, query block).  The dispatcher deals workgroups round-robin over the 8 XCDs, each with its own
+    // L2: the query blocks of one (sequence, head) all walk the same K / V, so they are given to ONE XCD (that XCD's share of the
+    // launch is a contiguous run of (head, block) ids) -- with blocks dealt across XCDs every L2 sees every head in flight and
+    // the tiles come from the memory side instead.  Within a head the heaviest blocks go first (a causal block walks keys
+    // 0 .. its last row): the launch does not end on a few long workgroups.
+    const int nqb = (a.S + BQ - 1) / BQ;
+    const int total = (int)gridDim.x, L = (int)blockIdx.x;
+    const int xcd = L & 7, per = total >> 3, rem = total & 7;
+    const int vid = xcd * per + (xcd < rem ? xcd : rem) + (L >> 3);      // bijective: XCD x owns per (+1 if x < rem) consecutive ids
+    const int hb = vid / nqb;
+    const int qb = nqb - 1 - (vid - hb * nqb), b = hb / a.n_heads, h = hb - b * a.n_heads;
     const int kvh = h / (a.n_heads / a.n_kv_heads);
     const int q0 = qb * BQ;
     const int n_keys_seq = a.pos0 + a.S;                // keys of this sequence visible to its last query
@@ -60,31 +80,49 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
     if (last_key > n_keys_seq - 1) last_key = n_keys_seq - 1;
     const int n_tiles = last_key / AP_BKV + 1;
 
-    // staging: 1024 16-byte chunks per tile, 4 per thread; chunk id c = tid + 256 j -> key row c >> 4, 16-byte chunk c & 15
-    h8 kreg[4], vreg[4];
-    auto load_tile = [&](int kt) {
+    // Staging: LDS-DMA, no registers.  A tile is 16 pieces of 1 KiB = 4 key rows; wave w moves pieces w, w + 4, w + 8, w + 12 of K
+    // and of V (8 DMA instructions per tile): lane l -> row 4 piece + (l >> 4), 16-byte position p = l & 15.  The swizzles are
+    // applied on the SOURCE side:
+    //   K: position p of a row holds chunk p ^ (row & 15)            (conflict-free ds_read_b128 of 16 rows x 4 chunks)
+    //   V: position p holds chunk 2 ((p >> 1) ^ (row & 7)) + (p & 1)  (32-byte segments: the transpose read of a 32-lane half
+    //      touches 8 rows x 32 bytes: distinct segments -> distinct banks)
+    // Lane offsets are loop invariants (the tile start is a multiple of 16 rows, so row & 15 does not depend on the tile) and
+    // the tile advances a scalar base: no vector work per tile.  Only a tile that reaches past the sequence's last key (rows
+    // there may hold anything, and 0 * NaN is NaN in P.V) takes the clamped per-lane path.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned krs2 = (unsigned)a.k_rstride * 2, vrs2 = (unsigned)a.v_rstride * 2;       // row strides in bytes
+    const unsigned rit = 4 * wave + (lane >> 4), pp = lane & 15;                             // row in tile (piece j: + 16 j), position
+    const unsigned kswz = (pp ^ (rit & 15)) << 4, vswz = ((((pp >> 1) ^ (rit & 7)) << 1) | (pp & 1)) << 4;
+    unsigned koff[4], voff[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = (int)threadIdx.x + 256 * j;
-            int key = kt * AP_BKV + (c >> 4);
-            key = key < n_keys_seq ? key : n_keys_seq - 1;      // clamp: masked below
-            kreg[j] = *(const h8*)(kp + (size_t)key * a.k_rstride + (c & 15) * 8);
-            vreg[j] = *(const h8*)(vp + (size_t)key * a.v_rstride + (c & 15) * 8);
+    for (int j = 0; j < 4; ++j) {
+        koff[j] = __umul24(rit + 16 * j, krs2) + kswz;
+        voff[j] = __umul24(rit + 16 * j, vrs2) + vswz;
+    }
+    auto load_tile = [&](int kt, int buf) {
+        const unsigned dst = lds0 + buf * (2 * AP_TILE) + wave * 1024;
+        if ((kt + 1) * AP_BKV <= n_keys_seq) {
+            const unsigned char* kb = (const unsigned char*)kp + (size_t)kt * AP_BKV * krs2;
+            const unsigned char* vb = (const unsigned char*)vp + (size_t)kt * AP_BKV * vrs2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ap_glds16(kb, koff[j], dst + j * 4096);
+                ap_glds16(vb, voff[j], dst + AP_TILE + j * 4096);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned key = (unsigned)(kt * AP_BKV) + rit + 16 * j;
+                key = key < (unsigned)n_keys_seq ? key : (unsigned)n_keys_seq - 1;      // clamp: masked below
+                ap_glds16(kp, __umul24(key, krs2) + kswz, dst + j * 4096);
+                ap_glds16(vp, __umul24(key, vrs2) + vswz, dst + AP_TILE + j * 4096);
+            }
         }
     };
-    auto store_tile = [&](int buf) {
-        unsigned char* kb_ = smem + buf * (2 * AP_TILE);
-        unsigned char* vb_ = kb_ + AP_TILE;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = (int)threadIdx.x + 256 * j;
-            const int row = c >> 4, ch = c & 15;
-            // K: 16-byte chunk ch of row at position ch ^ (row & 15)        (conflict-free ds_read_b128 of 16 rows x 4 chunks)
-            *(h8*)(kb_ + row * 256 + ((ch ^ (row & 15)) << 4)) = kreg[j];
-            // V: 32-byte segment (ch >> 1) of row at position (ch >> 1) ^ (row & 7)  (the transpose read of a 32-lane half
-            //    touches 8 rows x 32 bytes: distinct segments -> distinct banks)
-            *(h8*)(vb_ + row * 256 + ((((ch >> 1) ^ (row & 7)) << 5) | ((ch & 1) << 4))) = vreg[j];
-        }
+    // this wave's DMA has landed, then every wave's
+    auto tile_ready = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
 
     f4 oacc[QB][8];
@@ -96,12 +134,23 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
         for (int d = 0; d < 8; ++d) oacc[qi][d] = (f4){0.f, 0.f, 0.f, 0.f};
     }
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < n_tiles; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < n_tiles) load_tile(kt + 1);        // in flight under this tile's MFMAs
+    load_tile(0, 0);
+    tile_ready();
+    // The Q fragments must have LANDED before the loop: hipcc's wait-count pass merges the loop header's state with the
+    // prologue's, so with the Q loads still counted as outstanding there it waits vmcnt(0) at the first MFMA of EVERY
+    // tile -- i.e. for the next tile's global loads issued just above it, the full memory latency once per tile.
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(qf[qi][t]));
+    // One key tile.  BUF (the LDS buffer) and DIAG (the tile reaches past the workgroup's first query row: causal mask) are
+    // compile-time: every LDS address is then a loop-invariant register + an immediate, and the compare / select pair of the
+    // mask exists only in the one or two last tiles of a workgroup.
+    const float sl2 = 0.08838834764831845f * 1.4426950408889634f;           // 1 / sqrt(128) * log2(e): scores live in the exp2 domain
+    auto tile = [&](auto BUFC, auto DIAGC, int kt) {
+        const int buf = BUFC;                           // an integral_constant (addresses fold into immediates) or a plain int
+        constexpr bool DIAG = decltype(DIAGC)::value;
+        if (kt + 1 < n_tiles) load_tile(kt + 1, buf ^ 1);   // in flight under this tile's MFMAs (the other buffer was last read before the previous barrier)
         const unsigned char* kb_ = smem + buf * (2 * AP_TILE);
         const unsigned char* vb_ = kb_ + AP_TILE;
         const int k0 = kt * AP_BKV;
@@ -120,40 +169,38 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
                 for (int qi = 0; qi < QB; ++qi) st[qi][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qi][t], st[qi][kb], 0, 0, 0);
             }
         }
-        // ---- scale, causal mask, running max.  Scores are kept in the exp2 domain (scale * log2(e) folded into one multiply).
-        // Only tiles that reach past a row block's first query row need the mask (wave-uniform test): for a 2048-row prompt
-        // that is one tile in 16 on average.
-        const float sl2 = 0.08838834764831845f * 1.4426950408889634f;       // 1 / sqrt(128) * log2(e)
+        // ---- causal mask, running max (on the raw scores: the scale is positive), then p = exp2(s * sl2 - m * sl2) as one
+        // packed fma + exp per score; the row sum is packed too
         h8 pb[QB][2];                                    // P^T as the B operand of O^T = V^T . P^T, per 32-key step
 #pragma unroll
         for (int qi = 0; qi < QB; ++qi) {
-            const bool diag = k0 + AP_BKV - 1 > a.pos0 + q0 + 16 * (QB * wave + qi);   // some key may be masked for some row of the block
             float mt = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float s = st[qi][kb][i] * sl2;
-                    if (diag) s = (k0 + 16 * kb + 4 * o + i) <= qpos[qi] ? s : -INFINITY;
-                    st[qi][kb][i] = s;
-                    mt = fmaxf(mt, s);
+                    if (DIAG) st[qi][kb][i] = (k0 + 16 * kb + 4 * o + i) <= qpos[qi] ? st[qi][kb][i] : -INFINITY;
+                    mt = fmaxf(mt, st[qi][kb][i]);
                 }
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float m_new = fmaxf(m_run[qi], mt);    // key 0 is visible to every query: finite from the first tile on
             const bool grew = __any(m_new != m_run[qi]); // wave-uniform: no row's maximum moved -> no rescale pass
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qi] - m_new);   // exp2(-inf) = 0 on the first tile
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * sl2);   // exp2(-inf) = 0 on the first tile
             m_run[qi] = m_new;
-            float ls = 0.f;
+            const f2 nm = {-m_new * sl2, -m_new * sl2}, sc = {sl2, sl2};
+            f2 ls = {0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const _Float16 p16 = (_Float16)__builtin_amdgcn_exp2f(st[qi][kb][i] - m_new);   // softmax(...).to(fp16), normalised at the end
-                    ls += (float)p16;
-                    pb[qi][kb >> 1][4 * (kb & 1) + i] = p16;
+                for (int i = 0; i < 4; i += 2) {
+                    const f2 e = __builtin_elementwise_fma((f2){st[qi][kb][i], st[qi][kb][i + 1]}, sc, nm);
+                    const f2 p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                    ls += p;                                                  // fp32 softmax denominator (HF: softmax in fp32, then .to(fp16))
+                    pb[qi][kb >> 1][4 * (kb & 1) + i] = (_Float16)p[0];       // normalised at the end
+                    pb[qi][kb >> 1][4 * (kb & 1) + i + 1] = (_Float16)p[1];
                 }
-            l_run[qi] = l_run[qi] * alpha + ls;
+            l_run[qi] = l_run[qi] * alpha + (ls[0] + ls[1]);
             if (grew) {
 #pragma unroll
                 for (int d = 0; d < 8; ++d)
@@ -187,8 +234,27 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
                 for (int qi = 0; qi < QB; ++qi) oacc[qi][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[qi][ks], oacc[qi][d], 0, 0, 0);
             }
         }
-        if (kt + 1 < n_tiles) store_tile(buf ^ 1);       // the other buffer was last read before the previous barrier
-        __syncthreads();
+        tile_ready();
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    // tiles 0 .. n_plain-1 end at or before the workgroup's first query position: no mask for any row
+    int n_plain = (a.pos0 + q0 + 1) / AP_BKV;
+    n_plain = n_plain < n_tiles ? n_plain : n_tiles;
+    int kt = 0;
+    if (QB == 1) {
+        for (; kt + 2 <= n_plain; kt += 2) {
+            tile(B0{}, std::false_type{}, kt);
+            tile(B1{}, std::false_type{}, kt + 1);
+        }
+        for (; kt < n_tiles; ++kt) {                     // at most one unmasked tile, then the masked ones (one or two)
+            if (kt < n_plain) tile(B0{}, std::false_type{}, kt);             // kt is even here
+            else if (kt & 1) tile(B1{}, std::true_type{}, kt);
+            else tile(B0{}, std::true_type{}, kt);
+        }
+    } else {                                             // two tile bodies in one loop do not fit the register file at QB = 2
+        for (; kt < n_plain; ++kt) tile(kt & 1, std::false_type{}, kt);
+        for (; kt < n_tiles; ++kt) tile(kt & 1, std::true_type{}, kt);
     }
 
     // ---- normalise and store: lane holds O[q = qrow][d = 16 db + 4o + i]
@@ -214,11 +280,22 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs a) {
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
     const int lds = 2 * 2 * AP_TILE;                    // 64 KiB
     static hipError_t attr1 = hipFuncSetAttribute((const void*)attn_prefill_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static hipError_t attr2 = hipFuncSetAttribute((const void*)attn_prefill_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (attr1 != hipSuccess) return attr1;
-    // QB = 2 (128-row workgroups, every K / V fragment feeding two MFMAs) was built and measured: 244 registers, and SLOWER --
-    // 16 x 2048 x 40 heads 194 vs 261 TFLOP/s, 1 x 2048 x 32 heads 194 vs 226 (profiles/r02_attn_prefill_vs_sdpa.txt) -- the
-    // kernel is bound by the per-tile dependency chain (barrier, S^T, two cross-lane max steps, exp, P.V), not by LDS bytes.
-    hipLaunchKernelGGL(attn_prefill_kernel<1>, dim3((a.S + 63) / 64, a.n_heads, a.batch), dim3(256), lds, st, a);
+    if (attr2 != hipSuccess) return attr2;
+    // 128-row workgroups (QB = 2: every K / V fragment read from LDS feeds two MFMAs, a staged tile serves twice the rows) once
+    // they still fill the chip several times over (2 workgroups per CU = 512 in flight); 64-row workgroups otherwise.
+    // Measured (profiles/r02_attn_prefill_vs_sdpa.txt): 16 x 2048 x 40 heads 681 vs 577 TFLOP/s, 1 x 2048 x 32 heads 419 vs 427,
+    // 1 x 512 x 32 heads 106 vs 138.
+#ifdef AP_QB
+    const int qb = AP_QB;                               // A/B builds
+#else
+    const long wg2 = (long)((a.S + 127) / 128) * a.n_heads * a.batch;
+    const int qb = wg2 >= 2048 ? 2 : 1;
+#endif
+    const int nwg = ((a.S + 64 * qb - 1) / (64 * qb)) * a.n_heads * a.batch;
+    if (qb == 2) hipLaunchKernelGGL(attn_prefill_kernel<2>, dim3(nwg), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(attn_prefill_kernel<1>, dim3(nwg), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 

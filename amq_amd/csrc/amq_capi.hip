@@ -387,6 +387,10 @@ int amq_attn_prefill_f16(const void* q, const void* k, const void* v, void* out,
         if (sv < 0 || (sv % 8) != 0) return fail(AMQ_ESHAPE, "strides must be non-negative multiples of 8 halves (16-byte vector access)");
     if (q_rstride < (long long)n_heads * 128 || o_rstride < (long long)n_heads * 128 || k_rstride < 128 || v_rstride < 128)
         return fail(AMQ_ESHAPE, "row strides smaller than the rows they separate");
+    // the kernel forms key * row stride in bytes as a 24 x 24 -> 32-bit product (byte offset inside one sequence's k / v)
+    const long long keys = (long long)pos0 + S;
+    if (2 * k_rstride >= (1 << 24) || 2 * v_rstride >= (1 << 24) || keys >= (1 << 24) || 2 * keys * k_rstride >= (1ll << 32) || 2 * keys * v_rstride >= (1ll << 32))
+        return fail(AMQ_ESHAPE, "k / v of one sequence must span fewer than 2^32 bytes (keys %lld, row strides %lld / %lld halves)", keys, k_rstride, v_rstride);
     amq::AttnPrefillArgs a{q, k, v, out, S, pos0, n_heads, n_kv_heads, batch, (long)q_rstride, (long)q_bstride, (long)k_rstride,
                            (long)k_bstride, (long)k_hstride, (long)v_rstride, (long)v_bstride, (long)v_hstride, (long)o_rstride,
                            (long)o_bstride};

@@ -483,7 +483,8 @@ def test_prefill_graph_survives_scratch_growth():
 
 @pytest.mark.parametrize("S,nh,nkv,batch,pos0", [(5, 4, 4, 1, 0), (64, 4, 2, 1, 0), (65, 8, 2, 2, 0), (200, 4, 4, 1, 0),
                                                   (130, 4, 1, 3, 0), (33, 4, 2, 1, 70), (257, 2, 2, 1, 0),
-                                                  (300, 32, 8, 3, 0), (200, 32, 32, 4, 100)])      # (many workgroups: several per CU)
+                                                  (300, 32, 8, 3, 0), (200, 32, 32, 4, 100),      # (many workgroups: several per CU)
+                                                  (300, 32, 8, 24, 0), (200, 32, 32, 36, 100)])    # (>= 2048 128-row workgroups: QB = 2 kernel)
 def test_attn_prefill_matches_eager_formula(S, nh, nkv, batch, pos0):
     """amq_attn_prefill_f16 (flash-style MFMA kernel: transposed products, hardware transpose read of V, online softmax)
     against the eager HF formula in fp32: softmax(mask(q k^T / sqrt(d))) v, GQA, ragged prompt lengths, several sequences,
@@ -500,7 +501,7 @@ def test_attn_prefill_matches_eager_formula(S, nh, nkv, batch, pos0):
         vc = torch.zeros_like(kc)
         kc[:, :, :T] = torch.randn(batch, nkv, T, 128, generator=g).half().to(dev)
         vc[:, :, :T] = torch.randn(batch, nkv, T, 128, generator=g).half().to(dev)
-        kc[:, :, T:] = 1e4; vc[:, :, T:] = 1e4                      # rows past the context must never be read into the result
+        kc[:, :, T:] = float("nan"); vc[:, :, T:] = float("nan")    # rows past the context must never be read into the result
         out = ops.attn_prefill(q, kc, vc, torch.empty_like(q), S, nh, nkv, batch=batch, pos0=pos0, kv_cache=True)
         kf = kc[:, :, :T].float()                                   # [B, nkv, T, 128]
         vf = vc[:, :, :T].float()
