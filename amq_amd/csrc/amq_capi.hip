@@ -197,6 +197,34 @@ int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void*
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream, route), "gemm");
 }
 
+int amq_gemm_gated_fused(int route, int M, int N, int K, int use_workspace) {
+    if (M < 1 || N < 16 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_RING128) return 0;
+    amq::GemmArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, M, N, K, 4, AMQ_MODE_HQQ, K, N, nullptr,
+                    use_workspace ? amq::gemm_pick_splits(M, N, K, route) : 1};
+    return amq::gemm_gate_fused(a, route) ? 1 : 0;
+}
+
+int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
+                       const void* gate, void* y, int M, int N, int K, int group, int x_stride, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_RING128) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
+    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (int rc = check_mode(mode)) return rc;
+    if (!x || !qn || !mn || !y || !gate) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
+    if (N % 8) return fail(AMQ_ESHAPE, "the gated product needs N %% 8 == 0 (got %d)", N);
+    if (route == AMQ_GEMM_SKINNY && M > 64) return fail(AMQ_ESHAPE, "the few-row kernel takes at most 64 rows (got %d)", M);
+    const size_t need = amq_gemm_route_workspace_bytes(route, M, N, K);
+    const bool split = need != 0 && workspace != nullptr;
+    if (split && workspace_bytes < need)
+        return fail(AMQ_EINVAL, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, N,
+                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, route) : 1, nullptr, gate};
+    if (gate == y && !amq::gemm_gate_fused(a, route))
+        return fail(AMQ_EINVAL, "gate may alias y only where the kernel applies it in its epilogue (amq_gemm_gated_fused)");
+    return check_hip(amq::launch_gemm(a, (hipStream_t)stream, route), "gemm_gated");
+}
+
 int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, const void* residual,
                      void* y, int M, int N, int K, int group, int x_stride, int y_stride, void* workspace,
                      size_t workspace_bytes, void* stream) {

@@ -492,7 +492,26 @@ static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
 // 4096^2 M = 4096 876 | 1086, M = 2048 (128-row tiles) 814 | 910, M = 1024 615 | 531 -> stays tiled).
 bool gemm_takes_ring(int M, int N, int K) { return K >= 256 && gemm_ring_rows(M, N) != 0; }
 
+static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route);
+
+// a.gate (y = fp16(silu(gate)) * fp16(x . W^T (+ bias)), no residual): formed in the epilogue by the ring and the few-row
+// kernels; the tiled kernel (with or without split-K) is followed by the element-wise launch instead -- same expression, same bits.
+bool gemm_gate_fused(const GemmArgs& a, int route) {
+    const bool ring = (route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128 ||
+                       (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K))) && gemm_ring_ok(a);
+    return ring || gemm_is_skinny(a.M, a.N, a.K, route);
+}
+
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route) {
+    if (!a.gate) return launch_gemm_nogate(a, st, route);
+    if (gemm_gate_fused(a, route)) return launch_gemm_nogate(a, st, route);
+    GemmArgs b = a;
+    b.gate = nullptr;
+    if (hipError_t e = launch_gemm_nogate(b, st, route)) return e;
+    return launch_silu_mul(a.gate, a.y, a.y, (long)a.M * a.N, st);       // (contiguous y and gate: checked by the caller)
+}
+
+static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route) {
     if (route == GEMM_ROUTE_RING && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
     if (route == GEMM_ROUTE_RING128 && gemm_ring_ok(a)) return launch_gemm_ring(a, st, 128);
     if (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K) && gemm_ring_ok(a)) return launch_gemm_ring(a, st);

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
     // ---- epilogue: acc[rb][nb][i] = y[m0 + 16 rb + r][n0 + 32 wave + 16 nb + 4 o + i]
     const _Float16* bias = (const _Float16*)a.bias;
     const _Float16* res = (const _Float16*)a.residual;
+    const _Float16* gate = (const _Float16*)a.gate;
     _Float16* y = (_Float16*)a.y;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -368,12 +369,13 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
         h4 bv = {0, 0, 0, 0};
         if (bias) bv = *(const h4*)(bias + n);
         h4 rv[NRB];
-        if (res) {                                         // all residual loads of the column block first, ONE wait (not one per row block)
+        const _Float16* const side = res ? res : gate;     // (a launch carries a residual or a gate, not both: checked by the caller)
+        if (side) {                                        // all residual / gate loads of the column block first, ONE wait (not one per row block)
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
                 int m = m0 + 16 * rb + r;
                 m = m < a.M ? m : a.M - 1;
-                rv[rb] = *(const h4*)(res + (size_t)m * a.y_stride + n);
+                rv[rb] = *(const h4*)(side + (size_t)m * a.y_stride + n);
             }
         }
 #pragma unroll
@@ -384,6 +386,13 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
             for (int i = 0; i < 4; ++i) v[i] = (_Float16)acc[rb][nb][i];
             if (bias) v = v + bv;
             if (res) v = rv[rb] + v;
+            else if (gate) {                               // act = fp16(silu(gate)) * up   (silu_mul_kernel's expression)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float gf = (float)rv[rb][i];
+                    v[i] = (_Float16)(gf / (1.0f + __expf(-gf))) * v[i];
+                }
+            }
             if (m < a.M) *(h4*)(y + (size_t)m * a.y_stride + n) = v;
         }
     }

@@ -59,6 +59,7 @@ struct GemmArgs {
 // route: which kernel family serves the launch (AUTO: by shape; the others force one for tests / A-B tools)
 enum { GEMM_ROUTE_AUTO = 0, GEMM_ROUTE_TILED = 1, GEMM_ROUTE_SKINNY = 2, GEMM_ROUTE_RING = 3, GEMM_ROUTE_RING128 = 4 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route = GEMM_ROUTE_AUTO);
+bool gemm_gate_fused(const GemmArgs& a, int route);                 // a.gate applied in the kernel's epilogue (else: element-wise launch behind it)
 hipError_t launch_gemm_ring(const GemmArgs& a, hipStream_t st, int bm = 0);      // amq_gemm_ring.hip: 256 (or 128) x 256 tiles, LDS rings, counted waits; bm 0 = by shape
 bool gemm_ring_ok(const GemmArgs& a);
 int gemm_ring_rows(int M, int N);                                   // 256 / 128 rows per ring tile, 0: launch too small

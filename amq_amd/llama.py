@@ -302,14 +302,22 @@ class QuantLlama:
             else:
                 x = lin(blk["self_attn.o_proj"], self._prefill_attention(q, blk, S), residual=x)
                 h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
-                g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
-                act = ops.silu_mul(g, u, out=g)
+                g = lin(blk["mlp.gate_proj"], h2)
+                if S > 8:
+                    u = blk["mlp.up_proj"]                                         # silu(gate) * up in up_proj's epilogue
+                    act = ops.gemm(h2, u.qn, u.mn, u.bits, u.mode, u.N, u.K, gate=g, out=g)
+                else:
+                    act = ops.silu_mul(g, lin(blk["mlp.up_proj"], h2), out=g)
             x = lin(blk["mlp.down_proj"], act, residual=x)
         return self._prefill_finish(x, S)
 
     def _rows_linear(self, l, inp, residual=None):
         # y = inp . W^T (+ residual, in place) for many rows
         return ops.gemm(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, residual=residual, out=residual)
+
+    def _rows_up_gated(self, l, inp, gate):
+        # silu(gate) * (inp . W^T), in place on gate: the LlamaMLP product formed in up_proj's epilogue
+        return ops.gemm(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, gate=gate, out=gate)
 
     def prefill_batch(self, ids):
         """ids: int64 [B, S].  The many-row pass over B prompts at once (B*S rows through every linear): what the reference
@@ -330,8 +338,8 @@ class QuantLlama:
             a = ops.attn_prefill(q, k, v, torch.empty_like(q), S, nh, nkv, batch=B)      # reads the projections in place
             x = lin(blk["self_attn.o_proj"], a, residual=x)
             h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
-            g, u = lin(blk["mlp.gate_proj"], h2), lin(blk["mlp.up_proj"], h2)
-            x = lin(blk["mlp.down_proj"], ops.silu_mul(g, u, out=g), residual=x)
+            act = self._rows_up_gated(blk["mlp.up_proj"], h2, lin(blk["mlp.gate_proj"], h2))
+            x = lin(blk["mlp.down_proj"], act, residual=x)
         last = x.view(B, S, H)[:, S - 1].contiguous()
         logits = torch.empty(B, self.vocab, dtype=torch.float16, device=self.dev)
         for b in range(B):
@@ -478,6 +486,9 @@ class DenseLlama(QuantLlama):
         if residual is None:
             return torch.nn.functional.linear(inp, w)
         return torch.addmm(residual, inp, w.t(), out=residual)
+
+    def _rows_up_gated(self, w, inp, gate):
+        return ops.silu_mul(gate, torch.nn.functional.linear(inp, w), out=gate)
 
     def _prefill_eager(self, ids):
         F = torch.nn.functional

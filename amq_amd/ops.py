@@ -207,11 +207,13 @@ def gemm_route_name(M):
     return "amq::gemm_ring_kernel / amq::gemm_kernel (fused unpack + MFMA, hand-written; 256x256 ring tiles when they fill the chip)"
 
 
-def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=GEMM_AUTO):
+def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=GEMM_AUTO, gate=None):
     """y = x . W^T for any number of rows: few-row kernel, tiled MFMA kernel (split-K when few rows would leave the chip
     idle), or -- from LIB_GEMM_ROWS rows -- dequantize kernel + library GEMM.
     ``residual`` (fp16 [M, N], may be ``out``) is added in the epilogue: y = residual + fp16(x . W^T (+ bias))
-    (the library path rounds the sum once).  ``route`` != GEMM_AUTO forces one hand-written kernel family (tests, tools)."""
+    (the library path rounds the sum once).  ``gate`` (fp16 [M, N] contiguous, may be ``out``; not with ``residual``):
+    y = fp16(silu(gate)) * fp16(x . W^T (+ bias)), i.e. :func:`silu_mul` of the two projections with this one as ``up``.
+    ``route`` != GEMM_AUTO forces one hand-written kernel family (tests, tools)."""
     _check_shape(bits, N, K)
     _check_native(qn, mn, bits, N, K)
     x2 = _prep_x(x, K)
@@ -220,9 +222,25 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=
         _need(bias, torch.float16, "bias", N)
     if residual is not None:
         _need(residual, torch.float16, "residual", M * N)
+    if gate is not None:
+        if residual is not None:
+            raise ValueError("gate and residual are exclusive")
+        _need(gate, torch.float16, "gate", M * N)
     y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=x.device)
     _need(y, torch.float16, "y", M * N)
     lib = _lib.load()
+    if gate is not None:
+        need = lib.amq_gemm_route_workspace_bytes(route, M, N, K)
+        if y.data_ptr() == gate.data_ptr() and not lib.amq_gemm_gated_fused(route, M, N, K, 1 if need else 0):
+            # the tiled kernel cannot apply the gate itself: in place on the gate needs the projection somewhere else first
+            up = gemm(x, qn, mn, bits, mode, N, K, bias=bias, route=route)
+            silu_mul(gate, up.view(-1), out=y)
+            return y.reshape(*x.shape[:-1], N)
+        ws = _splitk_workspace(x.device, need) if need else None
+        _lib.check(lib.amq_gemm_gated_f16(route, bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
+                                          _lib.ptr(gate), _lib.ptr(y), M, N, K, GROUP, 0, _lib.ptr(ws),
+                                          ws.numel() * 4 if need else 0, _lib.current_stream()))
+        return y.reshape(*x.shape[:-1], N)
     if route == GEMM_AUTO and LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
         w = dequantize(qn, mn, bits, mode, N, K, out=_dequant_scratch(x.device, N * K).view(N, K))
         y2 = y.view(M, N)

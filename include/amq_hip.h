@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define AMQ_VERSION 200            /* 0.2.0 */
+#define AMQ_VERSION 201            /* 0.2.0 */
 
 #define AMQ_OK            0
 #define AMQ_EINVAL       -1        /* bad argument (null pointer, bits, mode ...) */
@@ -233,6 +233,16 @@ size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K);
 int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
                        const void* bias, const void* residual, void* y, int M, int N, int K, int group, int x_stride,
                        int y_stride, void* workspace, size_t workspace_bytes, void* stream);
+/* The LlamaMLP product act_fn(gate_proj(x)) * up_proj(x) with up_proj as this GEMM:
+ *     y = fp16(silu(gate)) * fp16(x . W^T (+ bias)),   gate fp16 [M, N] contiguous, y [M, N] contiguous,
+ * formed in the epilogue of the kernel that serves the shape (256-row ring and few-row kernels) or by the element-wise
+ * launch behind it (tiled kernel) -- the same expression as amq_silu_mul_f16 on the separate outputs, bit for bit.
+ * gate may alias y only in the first case: amq_gemm_gated_fused(route, M, N, K, use_workspace) says which it is
+ * (use_workspace: whether a split-K workspace will be passed).  route / workspace as amq_gemm_route_f16. */
+int amq_gemm_gated_fused(int route, int M, int N, int K, int use_workspace);
+int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
+                       const void* bias, const void* gate, void* y, int M, int N, int K, int group, int x_stride,
+                       void* workspace, size_t workspace_bytes, void* stream);
 /* Fragment-ordered activations for few-row GEMMs.  For a few dozen rows the GEMM is bound by how fast a CU can pull x
  * in MFMA operand order; amq_xfrag_f16 lays x out so that every wave-load is one contiguous KiB that already IS an
  * operand:  xf[g][kt][mb*4 + t][lane = 16*o + r][8] = x[g*64 + mb*16 + r][kt*128 + 32*t + 8*o .. +8]  (rows >= M zero),

@@ -29,7 +29,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_version_sizes_and_validation():
     lib = _lib.load()
-    assert lib.amq_version() == 200
+    assert lib.amq_version() == 201
     # native sizes: N*K*bits/8 payload, 4 B of (scale, zero) per (row, group)
     for bits in (2, 3, 4):
         assert lib.amq_native_qweight_bytes(bits, 4096, 4096) == 4096 * 4096 * bits // 8

@@ -523,6 +523,31 @@ def test_gemm_big_tiles(bits, m, n, k, route):
 
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("m,n,k,route", [(20, 1024, 512, 0), (64, 2048, 256, 2), (300, 1040, 1152, 0), (300, 1040, 1152, 1),
+                                         (200, 2048, 4096, 0),                       # tiled kernel + split-K, then the element-wise launch
+                                         (2048, 3072, 256, 3), (517, 6144, 384, 4), (2500, 4096, 512, 0)])
+def test_gemm_gated_equals_separate_silu_mul(bits, m, n, k, route):
+    """y = fp16(silu(gate)) * fp16(x . W^T + bias) formed by the GEMM (ring / few-row epilogue, or the element-wise launch
+    behind the tiled kernel) == amq_silu_mul_f16 on the separately computed projection, bit for bit; in place on the gate."""
+    from amq_amd import ops
+    h, qn, mn, _ = _random_case(bits, n, k, seed=17 * bits + m, bias=True)
+    dev = _dev()
+    gen = torch.Generator().manual_seed(m * 3 + n)
+    x = torch.randn(m, k, generator=gen).to(torch.float16).to(dev)
+    gate = (torch.randn(m, n, generator=gen) * 2).to(torch.float16).to(dev)
+    bias = h.bias.to(dev)
+    up = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, route=route)
+    want = ops.silu_mul(gate, up)
+    got = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, gate=gate, route=route)
+    assert torch.equal(got, want)
+    inplace = gate.clone()
+    ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, gate=inplace, out=inplace, route=route)
+    assert torch.equal(inplace, want)
+    with pytest.raises(ValueError):
+        ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, gate=gate, residual=gate)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("n,k", [(5120, 5120), (13824, 5120), (5120, 13824)])
 @pytest.mark.parametrize("m", [512, 2048, 8192])
 def test_gemm_13b_shapes_at_size(bits, n, k, m):
