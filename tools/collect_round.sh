@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: the round's bench lines, the rocprofv3 kernel-trace summary of the same bench command, and the PMC
 # passes (HBM traffic of the decode GEMV launches: FETCH_SIZE and WRITE_SIZE in separate runs, no trace domains mixed in).
+# (before calling it through gpurun, delete the local gpurun_out/<round>: gpurun MERGES, so files of an earlier call would be averaged in)
 # usage: tools/collect_round.sh r02   -> gpurun_out/<round>/...; tools/make_profile_summary.py <round> turns it into profiles/<round>_*
 set -u
 R=${1:-r02}
