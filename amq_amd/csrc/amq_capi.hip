@@ -402,6 +402,33 @@ int amq_attn_decode_cur_f16(const void* q, const void* k, const void* v, void* k
     return check_hip(amq::launch_attn_decode(a, batch, (hipStream_t)stream), "attn_decode_cur");
 }
 
+size_t amq_attn_decode_split_workspace_bytes(int batch, int n_heads, int n_splits) {
+    if (batch < 1 || n_heads < 1 || n_splits < 1) return 0;
+    return (size_t)batch * n_heads * n_splits * 132 * sizeof(float);
+}
+
+int amq_attn_decode_split_f16(const void* q, const void* k, const void* v, void* kcache, void* vcache, void* out,
+                              const void* step_state, const int* pos_dev, int pos, int batch, int n_heads, int n_kv_heads,
+                              int head_dim, int max_seq, float rope_theta, const void* rope_table, int n_splits,
+                              void* workspace, size_t workspace_bytes, void* tickets, void* stream) {
+    if (!q || !k || !v || !kcache || !vcache || !out || !workspace || !tickets) return fail(AMQ_EINVAL, "null pointer");
+    if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
+    if (batch < 1 || batch > 65535 || n_heads < 1 || n_heads > 255 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0)
+        return fail(AMQ_ESHAPE, "bad head configuration (batch %d, %d q heads, %d kv heads)", batch, n_heads, n_kv_heads);
+    if (n_splits < 1 || n_splits > 1024) return fail(AMQ_EINVAL, "n_splits must be 1..1024 (got %d)", n_splits);
+    if (max_seq < 1 || (!step_state && !pos_dev && (pos < 0 || pos >= max_seq)))
+        return fail(AMQ_ESHAPE, "position %d outside the cache (max_seq=%d)", pos, max_seq);
+    int chunk = (((max_seq + n_splits - 1) / n_splits) + 31) & ~31;
+    chunk = chunk < amq::ATT_MIN_CHUNK ? amq::ATT_MIN_CHUNK : chunk;
+    if (6 * 128 + (size_t)chunk * 4 + 17 * 1024 > LDS_LIMIT)
+        return fail(AMQ_ESHAPE, "max_seq=%d over %d splits leaves chunks of %d keys: too long", max_seq, n_splits, chunk);
+    const size_t need = amq_attn_decode_split_workspace_bytes(batch, n_heads, n_splits);
+    if (workspace_bytes < need) return fail(AMQ_EINVAL, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    amq::AttnArgs a{q, k, v, kcache, vcache, out, step_state ? nullptr : pos_dev, pos, n_heads, n_kv_heads, max_seq,
+                    step_state ? 10000.0f : rope_theta, step_state ? nullptr : rope_table, step_state};
+    return check_hip(amq::launch_attn_decode_split(a, batch, n_splits, workspace, tickets, (hipStream_t)stream), "attn_decode_split");
+}
+
 int amq_attn_prefill_f16(const void* q, const void* k, const void* v, void* out, int batch, int S, int pos0, int n_heads,
                          int n_kv_heads, int head_dim, long long q_rstride, long long q_bstride, long long k_rstride,
                          long long k_bstride, long long k_hstride, long long v_rstride, long long v_bstride, long long v_hstride,

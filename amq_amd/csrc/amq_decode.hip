@@ -497,6 +497,227 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
     ATT_STAMP(6);
 }
 
+// ------------------------------------------ the same step with the cached keys split over several workgroups per head
+// attn_decode_kernel walks a head's whole context on ONE CU: fine for the few hundred keys of the reference's default
+// benchmark, but a CU pulls its K / V rows at 15-60 GB/s, so at 4000 cached keys a 7B token spent 4.2 of its 5.4 ms there
+// (profiles/r02_decode_context.txt).  Here grid.z workgroups share a head: the context 0 .. pos is cut into n_act <= grid.z
+// chunks of >= 256 keys (a multiple of 32; at most 384 when grid.z = ceil(max_seq / 384): the register-prefetch path), the
+// workgroup of chunk z computes its scores, its own softmax statistics (m_z, l_z) and its un-normalised fp32 output O_z;
+// the chunk holding the new token rotates / appends it.  With one active chunk the arithmetic and the result are those of
+// attn_decode_kernel bit for bit (same expressions, probabilities rounded to fp16 after normalisation).  With several, every
+// workgroup leaves (O_z, m_z, l_z) in the workspace as agent-scope stores, takes a ticket, and the LAST one to arrive -- no
+// workgroup waits -- combines them in chunk order: out = sum_z O_z e^(m_z - M) / sum_z l_z e^(m_z - M).  That is the exact
+// softmax with UNROUNDED probabilities (HF's eager path rounds them to fp16 first): within fp16 output rounding of the
+// one-chunk result, tests bound it.  Tickets are zero before and after every launch.
+struct AttnSplit { float* ws; int* tickets; int n_splits; };
+constexpr int ATT_WS_STRIDE = ATT_D + 4;       // floats per (head, chunk): O[128], m, l, pad
+
+__global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_kc, void* p_vc, const void* p_state, int p_heads,
+                                                                         int p_max_seq, const void* p_q, const void* p_k,
+                                                                         const void* p_v, AttnRest rest, AttnSplit sp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* qs = (_Float16*)smem;                 // [128] rotated q
+    _Float16* ks = (_Float16*)smem + ATT_D;         // [128] rotated new key (also what is appended)
+    _Float16* vs = (_Float16*)smem + 2 * ATT_D;     // [128] new value
+    float* sc = (float*)(smem + 6 * ATT_D);         // [chunk] scores / probabilities of this workgroup's keys
+    __shared__ float red[2 * ATT_THREADS / 64];
+    __shared__ float part[ATT_GROUPS][ATT_D];
+    __shared__ int last_flag;
+    const int h = blockIdx.x, b = blockIdx.y, z = blockIdx.z, tid = threadIdx.x;
+    const int n_heads = p_heads & 0xFF, n_kv_heads = (p_heads >> 8) & 0xFF, max_seq = p_max_seq;
+    const bool cur_mode = (p_heads >> 16) & 1;
+    const void* p_cur = cur_mode ? p_state : nullptr;
+    int pos;
+    if (cur_mode) pos = *(const int*)((const char*)p_state + 256);
+    else if (p_state) pos = *(const int*)p_state;
+    else pos = rest.pos;
+    const int group = n_heads / n_kv_heads;
+    const int kvh = h / group;
+    const int grp = tid >> 4, l16 = tid & 15;
+    const _Float16* q = (const _Float16*)p_q + ((size_t)b * n_heads + h) * ATT_D;
+    const _Float16* kn = (const _Float16*)p_k + ((size_t)b * n_kv_heads + kvh) * ATT_D;
+    const _Float16* vn = (const _Float16*)p_v + ((size_t)b * n_kv_heads + kvh) * ATT_D;
+    _Float16* kc = (_Float16*)p_kc + ((size_t)b * n_kv_heads + kvh) * (size_t)max_seq * ATT_D;
+    _Float16* vc = (_Float16*)p_vc + ((size_t)b * n_kv_heads + kvh) * (size_t)max_seq * ATT_D;
+
+    _Float16 q0 = 0, q1 = 0, k0 = 0, k1 = 0, v0 = 0, v1 = 0;
+    h2 cs_cur = {(_Float16)1.f, (_Float16)0.f}, cs_tab = {(_Float16)1.f, (_Float16)0.f};
+    if (tid < 64) {
+        q0 = q[tid]; q1 = q[tid + 64];
+        k0 = kn[tid]; k1 = kn[tid + 64];
+        if (p_cur) cs_cur = ((const h2*)p_cur)[tid];
+        v0 = vn[tid]; v1 = vn[tid + 64];
+    }
+    // a position outside the cache: nothing is appended or written (attn_decode_kernel's guard)
+    if (pos < 0 || pos >= max_seq) {
+        if (cur_mode && tid == 0 && z == 0) *(int*)((char*)const_cast<void*>(p_state) + 260) = 1;
+        return;
+    }
+    const int T = pos + 1;
+    int chunk = (((T + sp.n_splits - 1) / sp.n_splits) + 31) & ~31;
+    chunk = chunk < ATT_MIN_CHUNK ? ATT_MIN_CHUNK : chunk;
+    const int n_act = (T + chunk - 1) / chunk;       // chunks that hold keys: workgroups z >= n_act have nothing to do
+    if (z >= n_act) return;
+    const int t0 = z * chunk;
+    const int t1 = t0 + chunk < T ? t0 + chunk : T;  // this workgroup's keys: t0 .. t1 - 1
+    const int Tl = t1 - t0;
+    const bool has_new = t1 == T;                    // the chunk that holds the new token (the last active one)
+    if (tid < 64 && !p_cur && rest.rope_table) cs_tab = ((const h2*)rest.rope_table)[(size_t)pos * 64 + tid];
+    const int last_old = pos > 0 ? pos - 1 : 0;      // rows >= pos are never read from the cache
+    h8 krow[ATT_PF], vrow[ATT_PF];
+#pragma unroll
+    for (int i = 0; i < ATT_PF; ++i) {
+        if (ATT_GROUPS * i < Tl) {
+            int t = t0 + grp + ATT_GROUPS * i;
+            t = t < last_old ? t : last_old;
+            krow[i] = *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ATT_PF; ++i) {
+        if (ATT_GROUPS * i < Tl) {
+            int t = t0 + grp + ATT_GROUPS * i;
+            t = t < last_old ? t : last_old;
+            vrow[i] = *(const h8*)(vc + (size_t)t * ATT_D + 8 * l16);
+        }
+    }
+    if (tid < 64) {
+        _Float16 c16, s16;
+        if (p_cur) { c16 = cs_cur.x; s16 = cs_cur.y; }
+        else {
+            c16 = cs_tab.x; s16 = cs_tab.y;
+            if (!rest.rope_table) rope_cs(rest.rope_theta, pos, tid, &c16, &s16);
+        }
+        const int i = tid;                          // rotary pair (i, i + 64): attn_decode_kernel's rotate_and_append
+        qs[i] = q0 * c16 + (-q1) * s16;
+        qs[i + 64] = q1 * c16 + q0 * s16;
+        const _Float16 r0 = k0 * c16 + (-k1) * s16, r1 = k1 * c16 + k0 * s16;
+        ks[i] = r0;
+        ks[i + 64] = r1;
+        vs[i] = v0;
+        vs[i + 64] = v1;
+        if (has_new && h % group == 0) {            // one workgroup per kv head appends to the cache
+            kc[(size_t)pos * ATT_D + i] = r0;
+            kc[(size_t)pos * ATT_D + i + 64] = r1;
+            vc[(size_t)pos * ATT_D + i] = v0;
+            vc[(size_t)pos * ATT_D + i + 64] = v1;
+        }
+    }
+    __syncthreads();
+
+    const float scale = rsqrtf((float)ATT_D);
+    const h8 qv = *(const h8*)(qs + 8 * l16);
+    const h8 knew = *(const h8*)(ks + 8 * l16);
+    auto score = [&](const h8& kv) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            s = __builtin_amdgcn_fdot2((h2){qv[2 * e], qv[2 * e + 1]}, (h2){kv[2 * e], kv[2 * e + 1]}, s, false);
+        s = row16_sum(s);
+        return (float)(_Float16)((float)(_Float16)s * scale);
+    };
+#pragma unroll
+    for (int i = 0; i < ATT_PF; ++i) {
+        if (ATT_GROUPS * i < Tl) {
+            const int t = t0 + grp + ATT_GROUPS * i;
+            const float sv = score(t == pos ? knew : krow[i]);
+            if (t < t1 && l16 == 0) sc[t - t0] = sv;
+        }
+    }
+    for (int t = t0 + grp + ATT_GROUPS * ATT_PF; t < t1; t += ATT_GROUPS) {       // chunks beyond the register prefetch
+        const h8 kv = (t == pos) ? knew : *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
+        const float sv = score(kv);
+        if (l16 == 0) sc[t - t0] = sv;
+    }
+    __syncthreads();
+    float lmax = -INFINITY;
+    for (int t = tid; t < Tl; t += ATT_THREADS) lmax = fmaxf(lmax, sc[t]);
+    lmax = wave_max_dpp(lmax);
+    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    __syncthreads();
+    float gmax = red[0];
+#pragma unroll
+    for (int w = 1; w < ATT_THREADS / 64; ++w) gmax = fmaxf(gmax, red[w]);
+    float lsum = 0.f;
+    for (int t = tid; t < Tl; t += ATT_THREADS) {
+        const float e = __expf(sc[t] - gmax);
+        sc[t] = e;
+        lsum += e;
+    }
+    lsum = wave_sum_dpp(lsum);
+    if ((tid & 63) == 0) red[ATT_THREADS / 64 + (tid >> 6)] = lsum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < ATT_THREADS / 64; ++w) tot += red[ATT_THREADS / 64 + w];
+    const bool single = n_act == 1;                 // wave-uniform
+    const float inv = 1.0f / tot;
+
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const h8 vnew = *(const h8*)(vs + 8 * l16);
+    auto weight = [&](int tl) {                     // one chunk: softmax(...).to(fp16) as HF's eager path; several: exp(s - m_z), unrounded
+        return single ? (float)(_Float16)(sc[tl] * inv) : sc[tl];
+    };
+#pragma unroll
+    for (int i = 0; i < ATT_PF; ++i) {
+        const int t = t0 + grp + ATT_GROUPS * i;
+        if (ATT_GROUPS * i < Tl && t < t1) {
+            const float p = weight(t - t0);
+            const h8 vv = (t == pos) ? vnew : vrow[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += p * (float)vv[e];
+        }
+    }
+    for (int t = t0 + grp + ATT_GROUPS * ATT_PF; t < t1; t += ATT_GROUPS) {
+        const float p = weight(t - t0);
+        const h8 vv = (t == pos) ? vnew : *(const h8*)(vc + (size_t)t * ATT_D + 8 * l16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += p * (float)vv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[grp][8 * l16 + e] = o[e];
+    __syncthreads();
+    float acc = 0.f;
+    if (tid < ATT_D) {
+#pragma unroll
+        for (int g = 0; g < ATT_GROUPS; ++g) acc += part[g][tid];
+    }
+    _Float16* out = (_Float16*)rest.out + ((size_t)b * n_heads + h) * ATT_D;
+    if (single) {
+        if (tid < ATT_D) out[tid] = (_Float16)acc;
+        return;
+    }
+    // ---- several chunks: publish (O_z, m_z, l_z), take a ticket, the last arriver combines
+    float* const wsh = sp.ws + ((size_t)b * n_heads + h) * (size_t)sp.n_splits * ATT_WS_STRIDE;
+    if (tid < ATT_D) __hip_atomic_store(wsh + (size_t)z * ATT_WS_STRIDE + tid, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == ATT_D) __hip_atomic_store(wsh + (size_t)z * ATT_WS_STRIDE + ATT_D, gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == ATT_D + 1) __hip_atomic_store(wsh + (size_t)z * ATT_WS_STRIDE + ATT_D + 1, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the stores have completed (vmcnt) before the ticket is taken
+    __syncthreads();
+    if (tid == 0) {
+        int* const ticket = sp.tickets + (size_t)b * n_heads + h;
+        const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == n_act - 1;
+        if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every other chunk has taken its ticket
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    if (tid < ATT_D) {
+        float M = -INFINITY;
+        for (int c = 0; c < n_act; ++c)
+            M = fmaxf(M, __hip_atomic_load(wsh + (size_t)c * ATT_WS_STRIDE + ATT_D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        float L = 0.f, O = 0.f;
+        for (int c = 0; c < n_act; ++c) {           // chunk order: deterministic whatever the arrival order
+            const float* const wc = wsh + (size_t)c * ATT_WS_STRIDE;
+            const float f = __expf(__hip_atomic_load(wc + ATT_D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - M);
+            L += __hip_atomic_load(wc + ATT_D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * f;
+            O += __hip_atomic_load(wc + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * f;
+        }
+        out[tid] = (_Float16)(O / L);
+    }
+}
+
 // cos/sin table for positions 0..max_seq-1 (HF LlamaRotaryEmbedding values, fp32 math, fp16 storage)
 __global__ void rope_table_kernel(_Float16* tab, int max_seq, float theta) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -590,6 +811,30 @@ hipError_t launch_silu_mul(const void* gate, const void* up, void* out, long n, 
     const long n8 = n >> 3;
     hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const h8*)gate, (const h8*)up,
                        (h8*)out, n8);
+    return hipGetLastError();
+}
+
+// chunk length bound of the split kernel for a cache of max_seq rows cut n_splits ways
+static int att_chunk_max(int max_seq, int n_splits) {
+    int c = (((max_seq + n_splits - 1) / n_splits) + 31) & ~31;
+    return c < ATT_MIN_CHUNK ? ATT_MIN_CHUNK : c;
+}
+
+hipError_t launch_attn_decode_split(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, hipStream_t st) {
+    const size_t lds = 6 * ATT_D + (size_t)att_chunk_max(a.max_seq, n_splits) * 4;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_decode_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    AttnRest rest{a.out, a.rope_table, a.pos, a.rope_theta};
+#ifdef AMQ_STAMP
+    rest.stamps = nullptr;
+#endif
+    AttnSplit sp{(float*)ws, (int*)tickets, n_splits};
+    const bool cur = a.rope_cur != nullptr;
+    hipLaunchKernelGGL(attn_decode_split_kernel, dim3(a.n_heads, batch, n_splits), dim3(ATT_THREADS), lds, st, a.kcache, a.vcache,
+                       cur ? a.rope_cur : (const void*)a.pos_dev, a.n_heads | (a.n_kv_heads << 8) | ((int)cur << 16), a.max_seq,
+                       a.q, a.k, a.v, rest, sp);
     return hipGetLastError();
 }
 

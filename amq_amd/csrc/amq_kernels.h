@@ -86,6 +86,13 @@ struct AttnArgs {
 };
 hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st);
+#ifndef AMQ_ATT_MIN_CHUNK
+#define AMQ_ATT_MIN_CHUNK 256
+#endif
+constexpr int ATT_MIN_CHUNK = AMQ_ATT_MIN_CHUNK;      // fewest keys a workgroup of the split kernel takes (multiple of 32)
+// the same step with the context split over n_splits workgroups per head: ws = fp32 [batch][n_heads][n_splits][132],
+// tickets = int32 [batch][n_heads], zero before (and after) every launch
+hipError_t launch_attn_decode_split(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, hipStream_t st);
 hipError_t launch_rmsnorm(const void* x, const void* gamma, void* y, int M, int K, float eps, hipStream_t st);
 hipError_t launch_rmsnorm_xfrag(const void* x, const void* gamma, void* xf, int M, int K, float eps, hipStream_t st);
 // causal attention over a whole prompt (amq_attn_prefill.hip).  Element (b, s, head, d) of q / out sits at

@@ -497,12 +497,46 @@ def rope_table(max_seq, rope_theta, device):
     return tab
 
 
-def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_theta=10000.0, table=None, cur=None):
+class _ZeroedPool:
+    """Zeroed int32 ticket arrays (split decode attention), one per (device, stream), grow-only like :class:`_ScratchPool`:
+    every launch leaves its tickets zero, so one array serves all launches of a stream."""
+
+    def __init__(self):
+        self._cur = {}
+        self._keep = []
+
+    def get(self, device, n):
+        key = (device.index if device.index is not None else torch.cuda.current_device(),
+               torch.cuda.current_stream(device).cuda_stream)
+        t = self._cur.get(key)
+        if t is None or t.numel() < n:
+            if t is not None:
+                self._keep.append(t)
+            t = self._cur[key] = torch.zeros(max(n, 1024), dtype=torch.int32, device=device)
+        return t
+
+
+_ATTN_WS = _ScratchPool(torch.float32)
+_ATTN_TICKETS = _ZeroedPool()
+ATTN_SPLIT_FROM = 512      # caches longer than this use the split kernel (n_splits = 0 / auto)
+ATTN_CHUNK = 384           # keys per workgroup at a full cache: the kernel's register-prefetch depth
+
+
+def attn_decode_splits(max_seq):
+    """workgroups per head the auto policy gives a cache of ``max_seq`` rows (1: the single-workgroup kernel)"""
+    return 1 if max_seq <= ATTN_SPLIT_FROM else (max_seq + ATTN_CHUNK - 1) // ATTN_CHUNK
+
+
+def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_theta=10000.0, table=None, cur=None, n_splits=0):
     """One new token per sequence.  q [B, n_heads*128], k/v [B, n_kv_heads*128],
     caches [B, n_kv_heads, max_seq, 128]; ``pos`` is an int or a device int32 tensor.  ``cur``: fp16 [128] cos/sin row
-    of the current position (maintained by decode_tail) -- needs ``pos`` as a device tensor."""
+    of the current position (maintained by decode_tail) -- needs ``pos`` as a device tensor.
+    ``n_splits``: workgroups per head (include/amq_hip.h: amq_attn_decode_split_f16); 0 = by cache length, 1 = the
+    single-workgroup kernel."""
     B = kcache.shape[0]
     max_seq = kcache.shape[2]
+    if n_splits == 0:
+        n_splits = attn_decode_splits(max_seq)
     _need(q, torch.float16, "q", B * n_heads * 128)
     _need(k, torch.float16, "k", B * n_kv_heads * 128)
     _need(v, torch.float16, "v", B * n_kv_heads * 128)
@@ -521,12 +555,23 @@ def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_the
         _need(cur, torch.float16, "rope_cur", 128)
         if pos_dev is None or pos.data_ptr() != cur.data_ptr() + 256:
             raise ValueError("cur / pos must be the two views of one step-state block (ops.new_step_state)")
+    if table is not None:
+        _need(table, torch.float16, "rope table", max_seq * 128)
+    if n_splits > 1:
+        lib = _lib.load()
+        wsb = lib.amq_attn_decode_split_workspace_bytes(B, n_heads, n_splits)
+        ws = _ATTN_WS.get(q.device, wsb // 4)
+        tk = _ATTN_TICKETS.get(q.device, B * n_heads)
+        _lib.check(lib.amq_attn_decode_split_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(kcache), _lib.ptr(vcache),
+                                                 _lib.ptr(out), _lib.ptr(cur), pos_dev, pos_i, B, n_heads, n_kv_heads, 128,
+                                                 max_seq, ctypes.c_float(rope_theta), _lib.ptr(table), n_splits,
+                                                 _lib.ptr(ws), wsb, _lib.ptr(tk), _lib.current_stream()))
+        return out
+    if cur is not None:
         _lib.check(_lib.load().amq_attn_decode_cur_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(kcache), _lib.ptr(vcache),
                                                        _lib.ptr(out), _lib.ptr(cur), B, n_heads, n_kv_heads, 128, max_seq,
                                                        _lib.current_stream()))
-        return
-    if table is not None:
-        _need(table, torch.float16, "rope table", max_seq * 128)
+        return out
     _lib.check(_lib.load().amq_attn_decode_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(kcache), _lib.ptr(vcache),
                                                _lib.ptr(out), pos_dev, pos_i, B, n_heads, n_kv_heads, 128, max_seq,
                                                ctypes.c_float(rope_theta), _lib.ptr(table), _lib.current_stream()))

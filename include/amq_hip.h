@@ -209,6 +209,23 @@ int amq_attn_decode_cur_f16(const void* q, const void* k, const void* v, void* k
                             const void* step_state, int batch, int n_heads, int n_kv_heads, int head_dim, int max_seq,
                             void* stream);
 
+/* The same attention step for LONG contexts: n_splits workgroups share a head (grid = heads x batch x n_splits); the context
+ * 0 .. pos is cut into at most n_splits chunks of >= 256 keys, each workgroup computes its chunk's scores, softmax statistics
+ * and un-normalised output, leaves them in `workspace`, takes a ticket, and the last one to arrive (nobody waits) combines
+ * them in chunk order.  amq_attn_decode_f16 walks a head's whole context on one CU -- right for a few hundred keys, 4.2 ms of
+ * a 5.4 ms 7B token at 4000.  While the context fits ONE chunk (pos < 256, or n_splits == 1) the result is that of
+ * amq_attn_decode_f16 / _cur_f16 bit for bit; with several chunks the probabilities are not rounded to fp16 before P.V
+ * (exact softmax; within output rounding of the one-chunk result).  n_splits = ceil(max_seq / 384) keeps every chunk on the
+ * kernel's register-prefetch path.  step_state != NULL: position / rotation from the step-state block (as _cur_f16; pos_dev,
+ * pos, rope_theta, rope_table ignored); else as amq_attn_decode_f16.  workspace: amq_attn_decode_split_workspace_bytes bytes,
+ * no initialisation; tickets: int32 [batch * n_heads], ZERO before the first launch, left zero by every launch; neither may
+ * be shared by launches that can run concurrently.  The out-of-range position guard is the same (no-op, error word). */
+size_t amq_attn_decode_split_workspace_bytes(int batch, int n_heads, int n_splits);
+int amq_attn_decode_split_f16(const void* q, const void* k, const void* v, void* kcache, void* vcache, void* out,
+                              const void* step_state, const int* pos_dev, int pos, int batch, int n_heads, int n_kv_heads,
+                              int head_dim, int max_seq, float rope_theta, const void* rope_table, int n_splits,
+                              void* workspace, size_t workspace_bytes, void* tickets, void* stream);
+
 /* End of a greedy token step in one launch: token[0] = argmax(logits[0..vocab)) (first maximum), pos[0] += 1,
  * x[0..hidden) = embed[token][0..hidden); when rope_table / rope_cur are given (both or neither) also
  * rope_cur[0..128) = rope_table[min(pos, rope_rows - 1)][0..128), the cos/sin row amq_attn_decode_cur_f16 reads in the next step.  Replaces the `torch.argmax` / position increment / embedding gather that follow

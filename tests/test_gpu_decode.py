@@ -110,6 +110,83 @@ def test_attn_decode_sequence(nh, nkv):
         assert torch.equal(kc[0, :, pos], ks[-1]) and torch.equal(vc[0, :, pos], vs[-1])
 
 
+@pytest.mark.parametrize("pos,max_seq,nh,nkv,batch,n_splits", [
+    (100, 2048, 8, 2, 2, 6),          # one active chunk: bit-identical to the single-workgroup kernel
+    (255, 2048, 8, 8, 1, 0),          # T = 256: still one chunk
+    (256, 2048, 8, 2, 1, 0),          # T = 257: second chunk holds only the new token
+    (511, 2048, 4, 4, 3, 0), (1500, 2048, 8, 2, 2, 0), (2047, 2048, 8, 4, 1, 0),
+    (4000, 4096, 4, 1, 1, 0),         # 11 chunks of 384
+    (3000, 4096, 4, 2, 1, 4)])        # chunks of 768 keys: beyond the register prefetch, remainder loop per chunk
+def test_attn_decode_split_context(pos, max_seq, nh, nkv, batch, n_splits):
+    """amq_attn_decode_split_f16 (several workgroups per head, last-arriver combine) against the single-workgroup kernel and
+    the eager fp32 formula; cache append, determinism across launches, tickets left zero; both position sources."""
+    from amq_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(7 * pos + max_seq)
+    kc = torch.zeros(batch, nkv, max_seq, 128, dtype=torch.float16, device=dev)
+    vc = torch.zeros_like(kc)
+    kc[:, :, :pos] = torch.randn(batch, nkv, pos, 128, generator=g).half().to(dev)
+    vc[:, :, :pos] = torch.randn(batch, nkv, pos, 128, generator=g).half().to(dev)
+    kc[:, :, pos + 1:] = float("nan"); vc[:, :, pos + 1:] = float("nan")        # rows that must never contribute
+    q = torch.randn(batch, nh * 128, generator=g).half().to(dev)
+    k = torch.randn(batch, nkv * 128, generator=g).half().to(dev)
+    v = torch.randn(batch, nkv * 128, generator=g).half().to(dev)
+    tab = ops.rope_table(max_seq, 10000.0, dev)
+    posd = torch.full((1,), pos, dtype=torch.int32, device=dev)
+
+    def run(ns, cur_mode):
+        kc_, vc_ = kc.clone(), vc.clone()
+        out = torch.zeros(batch, nh * 128, dtype=torch.float16, device=dev)
+        if cur_mode:
+            cur, pos_state, err = ops.new_step_state(dev)
+            cur.copy_(tab.view(max_seq, 128)[pos]); pos_state.fill_(pos)
+            ops.attn_decode(q, k, v, kc_, vc_, out, pos_state, nh, nkv, cur=cur, n_splits=ns)
+            assert int(err.item()) == 0
+        else:
+            ops.attn_decode(q, k, v, kc_, vc_, out, posd, nh, nkv, table=tab, n_splits=ns)
+        return out, kc_, vc_
+
+    one, kc1, vc1 = run(1, False)
+    got, kc2, vc2 = run(n_splits, False)
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(kc2[:, :, :pos + 1], kc1[:, :, :pos + 1]) and torch.equal(vc2[:, :, :pos + 1], vc1[:, :, :pos + 1])   # appended once, same row
+    ns = n_splits or ops.attn_decode_splits(max_seq)
+    chunk = max(256, (((pos + 1 + ns - 1) // ns) + 31) // 32 * 32)
+    if pos + 1 <= chunk:
+        assert torch.equal(got, one)                       # one active chunk: the single-workgroup kernel's bits
+    else:
+        assert (got.float() - one.float()).abs().max() <= 2e-3 * one.float().abs().max() + 1e-3
+    again, _, _ = run(n_splits, False)
+    assert torch.equal(again, got)                         # chunk-order combine: deterministic
+    cur_out, _, _ = run(n_splits, True)
+    assert torch.equal(cur_out, got)                       # step-state position / rotation source: same bits
+    assert all(int(t.abs().sum().item()) == 0 for t in ops._ATTN_TICKETS._cur.values())
+    # eager fp32 formula over the cache after the append
+    K = kc2[:, :, :pos + 1].repeat_interleave(nh // nkv, 1).float()                 # [B, nh, T, 128]
+    V = vc2[:, :, :pos + 1].repeat_interleave(nh // nkv, 1).float()
+    qr = torch.stack([_rope_ref(q[b].view(nh, 128), pos) for b in range(batch)]).float()   # [B, nh, 128]
+    w = torch.einsum("bhd,bhtd->bht", qr, K) * (128 ** -0.5)
+    ref = torch.einsum("bht,bhtd->bhd", torch.softmax(w, -1), V).reshape(batch, -1)
+    assert (got.float() - ref).abs().max() <= 4e-3 * ref.abs().max() + 1e-3
+
+
+def test_attn_decode_split_position_guard():
+    """a device-side position outside the cache: no append, no output, sticky error word (as the single-workgroup kernel)"""
+    from amq_amd import ops
+    dev = _dev()
+    nh, nkv, max_seq = 4, 2, 1024
+    kc = torch.zeros(1, nkv, max_seq, 128, dtype=torch.float16, device=dev)
+    vc = torch.zeros_like(kc)
+    q = torch.randn(1, nh * 128).half().to(dev); k = torch.randn(1, nkv * 128).half().to(dev); v = torch.randn(1, nkv * 128).half().to(dev)
+    out = torch.full((1, nh * 128), 7.0, dtype=torch.float16, device=dev)
+    cur, pos_state, err = ops.new_step_state(dev)
+    pos_state.fill_(max_seq)
+    ops.attn_decode(q, k, v, kc, vc, out, pos_state, nh, nkv, cur=cur, n_splits=3)
+    torch.cuda.synchronize()
+    assert int(err.item()) == 1 and bool((out == 7.0).all()) and float(kc.abs().sum()) == 0.0
+    assert all(int(t.abs().sum().item()) == 0 for t in ops._ATTN_TICKETS._cur.values())
+
+
 @pytest.mark.parametrize("pos", [0, 1, 31, 127, 128, 383, 384, 385, 700, 1023])
 def test_attn_decode_long_context(pos):
     """one step at a given position over a pre-filled cache: covers the speculative prefetch (first 128 keys), the
