@@ -523,8 +523,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_
     __shared__ float red[2 * ATT_THREADS / 64];
     __shared__ float part[ATT_GROUPS][ATT_D];
     __shared__ int last_flag;
-    const int h = blockIdx.x, b = blockIdx.y, z = blockIdx.z, tid = threadIdx.x;
+    const int b = blockIdx.y, z = blockIdx.z, tid = threadIdx.x;
     const int n_heads = p_heads & 0xFF, n_kv_heads = (p_heads >> 8) & 0xFF, max_seq = p_max_seq;
+    // Grouped-query models: the query heads of one kv head read the same K / V chunk.  Workgroups are dealt round-robin over
+    // the 8 XCDs (linear id % 8 = blockIdx.x % 8 when the head count is a multiple of 8), so the heads of a kv group are given
+    // ids with the same residue: the chunk is then fetched into ONE XCD's L2 instead of eight.  (kv heads % 8 != 0: identity.)
+    int h = blockIdx.x;
+    if (n_kv_heads != n_heads && (n_kv_heads & 7) == 0) {
+        const int G = n_heads / n_kv_heads, x = h & 7, j = h >> 3;
+        h = (x + 8 * (j / G)) * G + j % G;
+    }
     const bool cur_mode = (p_heads >> 16) & 1;
     const void* p_cur = cur_mode ? p_state : nullptr;
     int pos;

@@ -115,6 +115,7 @@ def test_attn_decode_sequence(nh, nkv):
     (255, 2048, 8, 8, 1, 0),          # T = 256: still one chunk
     (256, 2048, 8, 2, 1, 0),          # T = 257: second chunk holds only the new token
     (511, 2048, 4, 4, 3, 0), (1500, 2048, 8, 2, 2, 0), (2047, 2048, 8, 4, 1, 0),
+    (1500, 2048, 16, 8, 1, 0),        # 8 kv heads: the kv-group -> XCD head mapping
     (4000, 4096, 4, 1, 1, 0),         # 11 chunks of 384
     (3000, 4096, 4, 2, 1, 4)])        # chunks of 768 keys: beyond the register prefetch, remainder loop per chunk
 def test_attn_decode_split_context(pos, max_seq, nh, nkv, batch, n_splits):
