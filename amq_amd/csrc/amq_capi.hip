@@ -280,7 +280,7 @@ int amq_rope_rows_f16(void* q, void* k, const void* rope_table, int rope_rows, i
     if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
     if (rows < 1 || seq_len < 1 || (rows % seq_len) != 0 || n_heads < 1 || n_kv_heads < 1 || rope_rows < 1 || pos0 < 0)
         return fail(AMQ_ESHAPE, "bad sizes (rows=%d must be a multiple of seq_len=%d)", rows, seq_len);
-    if (rows > 65535) return fail(AMQ_ESHAPE, "rows=%d exceeds one launch (65535)", rows);
+    if ((long long)rows * (n_heads + n_kv_heads) > (1ll << 36)) return fail(AMQ_ESHAPE, "rows=%d exceeds one launch", rows);
     return check_hip(amq::launch_rope_rows(q, k, rope_table, rope_rows, pos0, rows, seq_len, n_heads, n_kv_heads,
                                            (hipStream_t)stream), "rope_rows");
 }

@@ -780,23 +780,37 @@ hipError_t launch_rope_cache(void* q, const void* k, const void* v, void* kcache
 
 // RoPE in place on q AND k for `rows` rows that are `rows / seq_len` sequences of seq_len positions each (batched prompt
 // pass without a cache: the reference harness' GeMM mode at batch > 1): position of row s = pos0 + s % seq_len.
-__global__ __launch_bounds__(64) void rope_rows_kernel(_Float16* q, _Float16* k, const h2* tab, int rope_rows, int pos0, int seq_len,
-                                                       int nh, int nkv) {
-    const int i = threadIdx.x, hx = blockIdx.x;
-    const long s = blockIdx.y;
+// Eight threads per (row, head): thread c rotates elements [8c, 8c + 8) with their partners [64 + 8c, 64 + 8c + 8) -- 16-byte
+// accesses, 32 (row, head) units per 256-thread workgroup (the first version ran one 64-thread workgroup of 2-byte accesses
+// per unit: 2.3 TB/s on the 1.3 GB of a 16 x 2048 x 40-head pass).  Same fp16 expression per element.
+__global__ __launch_bounds__(256) void rope_rows_kernel(_Float16* q, _Float16* k, const h2* tab, int rope_rows, int pos0, int seq_len,
+                                                        int nh, int nkv, long units) {
+    const long u = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (u >= units) return;
+    const int c = threadIdx.x & 7, nhk = nh + nkv;
+    const long s = u / nhk;
+    const int hx = (int)(u - s * nhk);
     const int pos = pos0 + (int)(s % seq_len);
-    const h2 cs = tab[(size_t)(pos < rope_rows ? pos : rope_rows - 1) * 64 + i];
-    const _Float16 c16 = cs.x, s16 = cs.y;
+    const h2* cs = tab + (size_t)(pos < rope_rows ? pos : rope_rows - 1) * 64 + 8 * c;
+    const h8 cs0 = *(const h8*)cs, cs1 = *(const h8*)(cs + 4);                 // (cos, sin) of pairs 8c .. 8c+3 and 8c+4 .. 8c+7
     _Float16* row = hx < nh ? q + ((size_t)s * nh + hx) * ATT_D : k + ((size_t)s * nkv + (hx - nh)) * ATT_D;
-    const _Float16 a0 = row[i], a1 = row[i + 64];
-    row[i] = a0 * c16 + (-a1) * s16;
-    row[i + 64] = a1 * c16 + a0 * s16;
+    const h8 a0 = *(const h8*)(row + 8 * c), a1 = *(const h8*)(row + 64 + 8 * c);
+    h8 r0, r1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 c16 = e < 4 ? cs0[2 * e] : cs1[2 * (e - 4)], s16 = e < 4 ? cs0[2 * e + 1] : cs1[2 * (e - 4) + 1];
+        r0[e] = a0[e] * c16 + (-a1[e]) * s16;
+        r1[e] = a1[e] * c16 + a0[e] * s16;
+    }
+    *(h8*)(row + 8 * c) = r0;
+    *(h8*)(row + 64 + 8 * c) = r1;
 }
 
 hipError_t launch_rope_rows(void* q, void* k, const void* rope_table, int rope_rows, int pos0, int rows, int seq_len, int n_heads,
                             int n_kv_heads, hipStream_t st) {
-    hipLaunchKernelGGL(rope_rows_kernel, dim3(n_heads + n_kv_heads, rows), dim3(64), 0, st, (_Float16*)q, (_Float16*)k,
-                       (const h2*)rope_table, rope_rows, pos0, seq_len, n_heads, n_kv_heads);
+    const long units = (long)rows * (n_heads + n_kv_heads);
+    hipLaunchKernelGGL(rope_rows_kernel, dim3((unsigned)((units + 31) / 32)), dim3(256), 0, st, (_Float16*)q, (_Float16*)k,
+                       (const h2*)rope_table, rope_rows, pos0, seq_len, n_heads, n_kv_heads, units);
     return hipGetLastError();
 }
 

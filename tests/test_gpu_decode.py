@@ -76,6 +76,32 @@ def _rope_ref(t, pos):
     return t * cos + rot * sin
 
 
+@pytest.mark.parametrize("batch,seq,nh,nkv,pos0", [(1, 5, 4, 4, 0), (3, 37, 8, 2, 0), (2, 64, 5, 1, 11), (4, 300, 32, 8, 0)])
+def test_rope_rows_matches_hf_expression(batch, seq, nh, nkv, pos0):
+    """amq_rope_rows_f16 (in place on the q / k projections of a batched prompt pass) == HF apply_rotary_pos_emb in fp16,
+    bit for bit: t * cos + rotate_half(t) * sin with the table's fp16 cos / sin, position = pos0 + row % seq"""
+    from amq_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(batch * 100 + seq)
+    rows = batch * seq
+    q = torch.randn(rows, nh * 128, generator=g).half().to(dev)
+    k = torch.randn(rows, nkv * 128, generator=g).half().to(dev)
+    tab = ops.rope_table(pos0 + seq + 3, 10000.0, dev)
+    q2, k2 = q.clone(), k.clone()
+    ops.rope_rows(q2, k2, tab, seq, nh, nkv, pos0=pos0)
+    for r in sorted({0, 1, seq - 1, seq % rows, rows // 2, rows - 1}):
+        pos = pos0 + r % seq
+        assert torch.equal(q2[r].view(nh, 128), _rope_ref(q[r].view(nh, 128), pos)), (r, pos)
+        assert torch.equal(k2[r].view(nkv, 128), _rope_ref(k[r].view(nkv, 128), pos)), (r, pos)
+    # every row against the table-driven expression at once
+    cs = tab.view(-1, 64, 2)[pos0 + (torch.arange(rows, device=dev) % seq)]                 # [rows, 64, 2]
+    cos = torch.cat([cs[..., 0], cs[..., 0]], -1)[:, None, :]; sin = torch.cat([cs[..., 1], cs[..., 1]], -1)[:, None, :]
+    for t, t2, h in ((q, q2, nh), (k, k2, nkv)):
+        tv = t.view(rows, h, 128)
+        rot = torch.cat([-tv[..., 64:], tv[..., :64]], -1)
+        assert torch.equal(t2.view(rows, h, 128), tv * cos + rot * sin)
+
+
 @pytest.mark.parametrize("nh,nkv", [(4, 4), (8, 2)])
 def test_attn_decode_sequence(nh, nkv):
     """feed tokens one by one; compare each step with eager HF-style attention over the running cache"""
