@@ -269,7 +269,7 @@ int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void
     if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
     if (S < 1 || n_heads < 1 || n_kv_heads < 1 || rope_rows < 1) return fail(AMQ_ESHAPE, "bad sizes");
     if (pos0 < 0 || pos0 + S > max_seq) return fail(AMQ_ESHAPE, "rows %d..%d do not fit the cache (max_seq %d)", pos0, pos0 + S, max_seq);
-    if (S > 65535) return fail(AMQ_ESHAPE, "S=%d exceeds one launch (65535 rows)", S);
+
     return check_hip(amq::launch_rope_cache(q, k, v, kcache, vcache, rope_table, rope_rows, pos0, S, n_heads, n_kv_heads, max_seq,
                                             (hipStream_t)stream), "rope_cache");
 }

@@ -745,36 +745,47 @@ hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st
 // One 64-thread workgroup per (prompt row s, head): query heads are rotated in place, key heads are rotated INTO the
 // cache row pos0 + s, value heads are copied there.  Same fp16 expression and cos/sin table as the decode kernel's
 // rotate_and_append, so a prefilled cache row equals the row a decode step would have appended.
-__global__ __launch_bounds__(64) void rope_cache_kernel(_Float16* q, const _Float16* k, const _Float16* v, _Float16* kc,
-                                                        _Float16* vc, const h2* tab, int rope_rows, int pos0, int nh, int nkv,
-                                                        int max_seq) {
-    const int i = threadIdx.x, hx = blockIdx.x, s = blockIdx.y;
+// (eight threads per (row, head), 16-byte accesses: see rope_rows_kernel below)
+__global__ __launch_bounds__(256) void rope_cache_kernel(_Float16* q, const _Float16* k, const _Float16* v, _Float16* kc,
+                                                         _Float16* vc, const h2* tab, int rope_rows, int pos0, int nh, int nkv,
+                                                         int max_seq, long units) {
+    const long u = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (u >= units) return;
+    const int c = threadIdx.x & 7, nhk = nh + nkv;
+    const int s = (int)(u / nhk), hx = (int)(u - (long)s * nhk);
     const int pos = pos0 + s;
-    const h2 cs = tab[(size_t)(pos < rope_rows ? pos : rope_rows - 1) * 64 + i];
-    const _Float16 c16 = cs.x, s16 = cs.y;
+    const h2* cs = tab + (size_t)(pos < rope_rows ? pos : rope_rows - 1) * 64 + 8 * c;
+    const h8 cs0 = *(const h8*)cs, cs1 = *(const h8*)(cs + 4);
+    const _Float16* src = hx < nh ? q + ((size_t)s * nh + hx) * ATT_D : k + ((size_t)s * nkv + (hx - nh)) * ATT_D;
+    const h8 a0 = *(const h8*)(src + 8 * c), a1 = *(const h8*)(src + 64 + 8 * c);
+    h8 r0, r1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 c16 = e < 4 ? cs0[2 * e] : cs1[2 * (e - 4)], s16 = e < 4 ? cs0[2 * e + 1] : cs1[2 * (e - 4) + 1];
+        r0[e] = a0[e] * c16 + (-a1[e]) * s16;
+        r1[e] = a1[e] * c16 + a0[e] * s16;
+    }
     if (hx < nh) {
         _Float16* row = q + ((size_t)s * nh + hx) * ATT_D;
-        const _Float16 a0 = row[i], a1 = row[i + 64];
-        row[i] = a0 * c16 + (-a1) * s16;
-        row[i + 64] = a1 * c16 + a0 * s16;
+        *(h8*)(row + 8 * c) = r0;
+        *(h8*)(row + 64 + 8 * c) = r1;
     } else {
         const int h = hx - nh;
-        const _Float16* kr = k + ((size_t)s * nkv + h) * ATT_D;
         const _Float16* vr = v + ((size_t)s * nkv + h) * ATT_D;
-        const _Float16 a0 = kr[i], a1 = kr[i + 64];
         const size_t dst = ((size_t)h * max_seq + pos) * ATT_D;
-        kc[dst + i] = a0 * c16 + (-a1) * s16;
-        kc[dst + i + 64] = a1 * c16 + a0 * s16;
-        vc[dst + i] = vr[i];
-        vc[dst + i + 64] = vr[i + 64];
+        *(h8*)(kc + dst + 8 * c) = r0;
+        *(h8*)(kc + dst + 64 + 8 * c) = r1;
+        *(h8*)(vc + dst + 8 * c) = *(const h8*)(vr + 8 * c);
+        *(h8*)(vc + dst + 64 + 8 * c) = *(const h8*)(vr + 64 + 8 * c);
     }
 }
 
 hipError_t launch_rope_cache(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
                              int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int max_seq, hipStream_t st) {
-    hipLaunchKernelGGL(rope_cache_kernel, dim3(n_heads + n_kv_heads, S), dim3(64), 0, st, (_Float16*)q, (const _Float16*)k,
+    const long units = (long)S * (n_heads + n_kv_heads);
+    hipLaunchKernelGGL(rope_cache_kernel, dim3((unsigned)((units + 31) / 32)), dim3(256), 0, st, (_Float16*)q, (const _Float16*)k,
                        (const _Float16*)v, (_Float16*)kcache, (_Float16*)vcache, (const h2*)rope_table, rope_rows, pos0, n_heads,
-                       n_kv_heads, max_seq);
+                       n_kv_heads, max_seq, units);
     return hipGetLastError();
 }
 
