@@ -6,8 +6,9 @@ Same metric definitions and result keys:
   GeMV  1 / median(per-token forward latency) after one un-timed prefill; every token is
         timed individually with a device sync on both sides         (speed.py:50-127)
   GeMM  1 / median(prefill forward latency)                          (speed.py:61-71)
-  TTFT  median ms of prefill + argmax (the reference also counts tokenizer encode/decode;
-        no tokenizer files exist offline, so ids are used directly)  (speed.py:186-239)
+  TTFT  median ms of tokenizer encode + prefill + argmax + tokenizer decode of the first token (speed.py:186-239).
+        With no tokenizer (None) the ids are used directly; SyntheticTokenizer is the stand-in when no Llama tokenizer
+        files exist (offline): a `tokenizers` WordLevel model over one word per vocabulary id, same call surface.
 Returns ``{mode: {'B.S.G': value}}`` (+ ``'peak_memory'``) like the reference.
 The reference's static KV cache is batch-1 (ftllama_modeling.py:61-68); so is this runner.
 """
@@ -98,10 +99,47 @@ def _benchmark_gemm_batch(model, sizes, iteration, get_peak_memory):
     return data
 
 
+class _Encoding:
+    def __init__(self, ids):
+        self.input_ids = ids
+
+
+class SyntheticTokenizer:
+    """The slice of the HF tokenizer surface the reference's TTFT loop uses -- ``tok(text, return_tensors='pt',
+    truncation=True, max_length=n).input_ids`` and ``tok.decode(ids)`` (speed.py:193, 214-217) -- over a `tokenizers`
+    model.  ``SyntheticTokenizer(vocab)``: WordLevel, one word ("t<id>") per vocabulary id, whitespace pre-tokenizer -- what
+    stands in when no Llama tokenizer files are available; ``SyntheticTokenizer.from_file(path)``: a real tokenizer.json."""
+
+    def __init__(self, vocab_size=None, tokenizer=None):
+        import tokenizers
+        if tokenizer is None:
+            from tokenizers import models, pre_tokenizers
+            tokenizer = tokenizers.Tokenizer(models.WordLevel({f"t{i}": i for i in range(int(vocab_size))}, unk_token="t0"))
+            tokenizer.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+        self.tk = tokenizer
+
+    @classmethod
+    def from_file(cls, path):
+        import tokenizers
+        return cls(tokenizer=tokenizers.Tokenizer.from_file(path))
+
+    def __call__(self, text, return_tensors="pt", truncation=True, max_length=None):
+        ids = self.tk.encode(text).ids
+        if truncation and max_length is not None:
+            ids = ids[:max_length]
+        return _Encoding(torch.tensor([ids], dtype=torch.long))
+
+    def decode(self, ids):
+        if isinstance(ids, torch.Tensor):
+            ids = ids.reshape(-1).tolist()
+        return self.tk.decode(list(ids))
+
+
 @torch.inference_mode()
 def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 128, 128), mode="TPS", get_peak_memory=True):
     """speed.py:131-255.  ``model``: a runner with reset()/prefill()/decode_step()/generate()
-    (QuantLlama or DenseLlama).  ``tokenizer`` / ``use_ft`` are accepted for signature parity."""
+    (QuantLlama or DenseLlama).  ``tokenizer``: used by TTFT mode as in the reference (None: ids are used directly);
+    ``use_ft`` is accepted for signature parity."""
     assert mode.lower() in ["tps", "gemv", "gemm", "ttft"], \
         "speed benchmark mode should be one of ['TPS', 'GeMV', 'GeMM', 'TTFT']"
     batch_size, input_seq_len, gen_seq_len = sizes
@@ -134,13 +172,20 @@ def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 1
         speed = benchmark_gemv_gemm(model, input_ids, gen_seq_len, iteration, mode)
     else:
         times = []
+        text = tokenizer.decode(input_ids) if tokenizer is not None else None        # speed.py:193
         for _ in range(iteration):
             cleanup()
             model.reset()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            model.prefill(input_ids)
-            _ = int(model.token.item())           # argmax token back on the host (the decode of one token)
+            if tokenizer is not None:                                                  # speed.py:214-217
+                ids = tokenizer(text, return_tensors="pt", truncation=True, max_length=input_seq_len).input_ids[0].to(device)
+            else:
+                ids = input_ids
+            model.prefill(ids)
+            first = int(model.token.item())       # argmax token back on the host
+            if tokenizer is not None:
+                _ = tokenizer.decode([first])
             torch.cuda.synchronize()
             times.append((time.perf_counter() - t0) * 1000)
         speed = np.median(times)
@@ -153,4 +198,4 @@ def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 1
     return data
 
 
-__all__ = ["benchmark_speed"]
+__all__ = ["benchmark_speed", "SyntheticTokenizer"]

@@ -49,6 +49,9 @@ def main(argv=None):
     p.add_argument("--file_name", type=str, default=None)
     p.add_argument("--synthesize_arch", action="store_true", help="(extension) draw an arch at --target_bits")
     p.add_argument("--skip_fp16", action="store_true", help="(extension) do not run the fp16 baseline row")
+    p.add_argument("--tokenizer", type=str, default="auto",
+                   help="(extension) TTFT tokenizer: a tokenizer.json path, 'synthetic' (one word per vocabulary id), 'none' (ids "
+                        "used directly), or 'auto' = tokenizer.json of the checkpoint directory if present, else synthetic")
     args = p.parse_args(argv)
 
     def ckpt_dir(bits):
@@ -64,6 +67,14 @@ def main(argv=None):
         cfg = arch_mod.MODEL_CONFIGS[args.model_name]
     else:
         raise SystemExit(f"unknown model {args.model_name}; known: {sorted(arch_mod.MODEL_CONFIGS)} (or pass --save_path)")
+    tokenizer = None
+    if args.ttft and args.tokenizer != "none":
+        from .speed import SyntheticTokenizer
+        path = args.tokenizer if args.tokenizer not in ("auto", "synthetic") else None
+        if path is None and args.tokenizer == "auto" and args.save_path:
+            cand = os.path.join(ckpt_dir(have[0]), "tokenizer.json")
+            path = cand if os.path.exists(cand) else None
+        tokenizer = SyntheticTokenizer.from_file(path) if path else SyntheticTokenizer(cfg["vocab_size"])
     sizes = [args.batch_size, args.seq_length, args.gen_length]
     gemm_iteration = 20
     gemv_iteration = 5 if args.gen_length < 1024 else 2          # amq_speed_benchmark.py:168-169
@@ -83,7 +94,7 @@ def main(argv=None):
             r = benchmark_speed(model, None, use_ft=args.use_ft, iteration=gemv_iteration, sizes=sizes, mode="GeMV", get_peak_memory=False)
             result[row].update(r); print("GeMV : ", r)
         if args.ttft:
-            r = benchmark_speed(model, None, use_ft=args.use_ft, iteration=gemm_iteration, sizes=sizes, mode="TTFT", get_peak_memory=False)
+            r = benchmark_speed(model, tokenizer, use_ft=args.use_ft, iteration=gemm_iteration, sizes=sizes, mode="TTFT", get_peak_memory=False)
             result[row].update(r); print("TTFT : ", r)
         if args.memory:
             mem = get_memory_footprint(model) / 1024 ** 3

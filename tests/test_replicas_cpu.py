@@ -103,3 +103,17 @@ def test_single_process_needs_no_process_group():
     assert r.world == 1 and r.dist is None
     assert r.max_over_ranks(3.5) == 3.5
     assert r.timed(lambda: None, 3) >= 0.0
+
+
+def test_synthetic_tokenizer_round_trip():
+    """the TTFT stand-in tokenizer: ids -> text -> ids is the identity, truncation cuts, decode of one id gives one word
+    (the three calls of the reference's TTFT loop, amq/utils/speed.py:193, 214-217)"""
+    import torch
+    from amq_amd.speed import SyntheticTokenizer
+    tok = SyntheticTokenizer(32000)
+    ids = torch.randint(0, 31999, (64,), generator=torch.Generator().manual_seed(0))
+    text = tok.decode(ids)
+    back = tok(text, return_tensors="pt", truncation=True, max_length=64).input_ids
+    assert back.shape == (1, 64) and torch.equal(back[0], ids)
+    assert tok(text, max_length=10).input_ids.shape == (1, 10)
+    assert tok.decode([123]) == "t123"
