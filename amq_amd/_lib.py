@@ -69,6 +69,8 @@ SIGNATURES = {
     "amq_gemm_gated_f16": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "amq_attn_decode_split_workspace_bytes": (_sz, [_i, _i, _i]),
     "amq_attn_decode_split_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _sz, _vp, _vp]),
+    "amq_gemm_xfrag_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _i, _i, _i, _vp]),
+    "amq_attn_prefill_xfrag_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 5 + [_vp]),
     "amq_attn_prefill_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 10 + [_vp]),
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

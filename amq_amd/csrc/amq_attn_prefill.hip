@@ -264,15 +264,32 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         const float inv = 1.0f / l;
-        if (qrow[qi] < a.S) {
+        // (the fp16 values are formed once, ahead of the two store layouts: formed inside each branch the compiler picked a
+        //  fused multiply-convert for one and multiply + convert for the other -- results one fp16 ulp apart in ~1e-4 of the elements)
+        h4 ov[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ov[d][i] = (_Float16)(oacc[qi][d][i] * inv);
+        if (a.out_xfrag) {
+            // out in fragment order (amq_xfrag_f16's layout of the [S, heads * 128] matrix, K tile = head): element (s, h, dd) at
+            // ((((s >> 6) * heads + h) * 16 + ((s & 63) >> 4) * 4 + dd / 32) * 64 + 16 * ((dd & 31) >> 3) + (s & 15)) * 8 + (dd & 7);
+            // rows S .. 64 ceil(S / 64) - 1 of the last group are written as zeros (the few-row GEMM reads whole 64-row groups)
+            const int s = qrow[qi];
+            if (s < ((a.S + 63) & ~63)) {
+                _Float16* const xf = (_Float16*)a.out;
+                const size_t grp = ((size_t)(s >> 6) * a.n_heads + h) * 16 + ((s & 63) >> 4) * 4;
+                const h4 zero = {0, 0, 0, 0};
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const int ox = 2 * (d & 1) + (o >> 1);
+                    *(h4*)(xf + ((grp + (d >> 1)) * 64 + 16 * ox + (s & 15)) * 8 + 4 * (o & 1)) = s < a.S ? ov[d] : zero;
+                }
+            }
+        } else if (qrow[qi] < a.S) {
             _Float16* op = (_Float16*)a.out + (size_t)b * a.o_bstride + (size_t)qrow[qi] * a.o_rstride + (size_t)h * AP_D + 4 * o;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                h4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (_Float16)(oacc[qi][d][i] * inv);
-                *(h4*)(op + 16 * d) = v;
-            }
+            for (int d = 0; d < 8; ++d) *(h4*)(op + 16 * d) = ov[d];
         }
     }
 }

@@ -263,6 +263,25 @@ int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qn, const
     return check_hip(amq::launch_gemm_xfrag(a, (hipStream_t)stream), "gemm_xfrag");
 }
 
+int amq_gemm_xfrag_grouped_f16(const amq_segment* segs, int nseg, const void* xf, int M, int K, int group, void* stream) {
+    if (!segs || nseg < 1 || nseg > AMQ_MAX_SEGMENTS) return fail(AMQ_EINVAL, "nseg must be 1..%d (got %d)", AMQ_MAX_SEGMENTS, nseg);
+    if (!xf) return fail(AMQ_EINVAL, "null xf");
+    if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
+    if ((M + 63) / 64 > 65535) return fail(AMQ_ESHAPE, "M=%d exceeds one launch", M);
+    amq::GemvSeg gs[AMQ_MAX_SEGMENTS] = {};
+    for (int i = 0; i < nseg; ++i) {
+        const amq_segment& s = segs[i];
+        if (int rc = check_shape(s.bits, s.N, K, group)) return rc;
+        if (int rc = check_mode(s.mode)) return rc;
+        if (!s.qweight_native || !s.meta_native || !s.y) return fail(AMQ_EINVAL, "segment %d: null pointer", i);
+        amq::GemvSeg& d = gs[i];
+        d.qweight = s.qweight_native; d.meta = s.meta_native; d.bias = s.bias; d.residual = s.residual; d.y = s.y;
+        d.N = s.N; d.bits = s.bits; d.mode = s.mode;
+        d.y_stride = s.y_stride ? s.y_stride : s.N;
+    }
+    return check_hip(amq::launch_gemm_xfrag_grouped(xf, M, K, gs, nseg, (hipStream_t)stream), "gemm_xfrag_grouped");
+}
+
 int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
                        int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int head_dim, int max_seq, void* stream) {
     if (!q || !k || !v || !kcache || !vcache || !rope_table) return fail(AMQ_EINVAL, "null pointer");
@@ -429,10 +448,10 @@ int amq_attn_decode_split_f16(const void* q, const void* k, const void* v, void*
     return check_hip(amq::launch_attn_decode_split(a, batch, n_splits, workspace, tickets, (hipStream_t)stream), "attn_decode_split");
 }
 
-int amq_attn_prefill_f16(const void* q, const void* k, const void* v, void* out, int batch, int S, int pos0, int n_heads,
-                         int n_kv_heads, int head_dim, long long q_rstride, long long q_bstride, long long k_rstride,
-                         long long k_bstride, long long k_hstride, long long v_rstride, long long v_bstride, long long v_hstride,
-                         long long o_rstride, long long o_bstride, void* stream) {
+static int amq_attn_prefill_check(const void* q, const void* k, const void* v, const void* out, int batch, int S, int pos0, int n_heads,
+                                  int n_kv_heads, int head_dim, long long q_rstride, long long q_bstride, long long k_rstride,
+                                  long long k_bstride, long long k_hstride, long long v_rstride, long long v_bstride, long long v_hstride,
+                                  long long o_rstride, long long o_bstride) {
     if (!q || !k || !v || !out) return fail(AMQ_EINVAL, "null pointer");
     if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
     if (batch < 1 || batch > 65535 || S < 1 || pos0 < 0 || n_heads < 1 || n_heads > 65535 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0)
@@ -446,10 +465,29 @@ int amq_attn_prefill_f16(const void* q, const void* k, const void* v, void* out,
     const long long keys = (long long)pos0 + S;
     if (2 * k_rstride >= (1 << 24) || 2 * v_rstride >= (1 << 24) || keys >= (1 << 24) || 2 * keys * k_rstride >= (1ll << 32) || 2 * keys * v_rstride >= (1ll << 32))
         return fail(AMQ_ESHAPE, "k / v of one sequence must span fewer than 2^32 bytes (keys %lld, row strides %lld / %lld halves)", keys, k_rstride, v_rstride);
+    return AMQ_OK;
+}
+
+int amq_attn_prefill_f16(const void* q, const void* k, const void* v, void* out, int batch, int S, int pos0, int n_heads,
+                         int n_kv_heads, int head_dim, long long q_rstride, long long q_bstride, long long k_rstride,
+                         long long k_bstride, long long k_hstride, long long v_rstride, long long v_bstride, long long v_hstride,
+                         long long o_rstride, long long o_bstride, void* stream) {
+    if (int rc = amq_attn_prefill_check(q, k, v, out, batch, S, pos0, n_heads, n_kv_heads, head_dim, q_rstride, q_bstride, k_rstride, k_bstride,
+                                        k_hstride, v_rstride, v_bstride, v_hstride, o_rstride, o_bstride)) return rc;
     amq::AttnPrefillArgs a{q, k, v, out, S, pos0, n_heads, n_kv_heads, batch, (long)q_rstride, (long)q_bstride, (long)k_rstride,
                            (long)k_bstride, (long)k_hstride, (long)v_rstride, (long)v_bstride, (long)v_hstride, (long)o_rstride,
-                           (long)o_bstride};
+                           (long)o_bstride, 0};
     return check_hip(amq::launch_attn_prefill(a, (hipStream_t)stream), "attn_prefill");
+}
+
+int amq_attn_prefill_xfrag_f16(const void* q, const void* k, const void* v, void* out_xf, int S, int pos0, int n_heads,
+                               int n_kv_heads, int head_dim, long long q_rstride, long long k_rstride, long long k_hstride,
+                               long long v_rstride, long long v_hstride, void* stream) {
+    if (int rc = amq_attn_prefill_check(q, k, v, out_xf, 1, S, pos0, n_heads, n_kv_heads, head_dim, q_rstride, 0, k_rstride, 0, k_hstride,
+                                        v_rstride, 0, v_hstride, (long long)n_heads * 128, 0)) return rc;
+    amq::AttnPrefillArgs a{q, k, v, out_xf, S, pos0, n_heads, n_kv_heads, 1, (long)q_rstride, 0, (long)k_rstride, 0, (long)k_hstride,
+                           (long)v_rstride, 0, (long)v_hstride, 0, 0, 1};
+    return check_hip(amq::launch_attn_prefill(a, (hipStream_t)stream), "attn_prefill_xfrag");
 }
 
 int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,

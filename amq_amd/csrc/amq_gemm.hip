@@ -207,17 +207,16 @@ template <int BITS, int MB, int NSUB>
 struct SkinnyTile { h8 xr[MB * 4]; LanePayload<BITS> pay[NSUB]; h2 meta[NSUB]; };
 
 template <int BITS, int MODE, int MB, int NSUB, int D, int NWV, bool XF>
-__global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(GemmArgs a) {
+__device__ __forceinline__ void skinny_body(const GemmArgs& a, int bx, unsigned char* smem) {
     // per-wave transpose scratch (16*MB rows x 256 B, XOR-swizzled like the tiled kernel's x tiles); reused for the
     // cross-wave sum after the K loop
     constexpr int SCR = MB * 16 * 128;             // halves per wave
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* const scratch = (_Float16*)smem;              // NWV * SCR halves
     static_assert(SCR * 2 >= MB * NSUB * 64 * 16, "accumulator exchange must fit the scratch");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, o = lane >> 4;
     const int G = a.K >> 7;
-    const int nblk0 = (int)blockIdx.x * NSUB, nblk_last = (a.N >> 4) - 1;
+    const int nblk0 = bx * NSUB, nblk_last = (a.N >> 4) - 1;
     const int m_base = (int)blockIdx.y * (16 * MB);
     const uint32_t* qw = (const uint32_t*)a.qweight;
     const h2* mt = (const h2*)a.meta;
@@ -345,6 +344,76 @@ __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(GemmArgs a) {
             }
         }
     }
+}
+
+template <int BITS, int MODE, int MB, int NSUB, int D, int NWV, bool XF>
+__global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    skinny_body<BITS, MODE, MB, NSUB, D, NWV, XF>(a, (int)blockIdx.x, smem);
+}
+
+// Several linears that consume the same fragment-ordered x (q/k/v, gate/up of a prompt pass), each with its own bit-width, as
+// segments of ONE launch: a workgroup serves NSUB column blocks of one segment (three launches of ~11 us for the 7B q/k/v at
+// 64 rows are bound by their fixed cost and by every workgroup pulling x through its CU's L1 once per 16 columns; one launch of
+// 64-column workgroups pulls it once per 64).
+struct SkinnySegs {
+    int nseg;
+    int wg_begin[GEMV_MAX_SEG];            // first workgroup (blockIdx.x) of each segment
+    int N[GEMV_MAX_SEG], key[GEMV_MAX_SEG];    // key = bits * 2 + mode
+    const void* qweight[GEMV_MAX_SEG]; const void* meta[GEMV_MAX_SEG]; const void* bias[GEMV_MAX_SEG];
+    const void* residual[GEMV_MAX_SEG]; void* y[GEMV_MAX_SEG]; int y_stride[GEMV_MAX_SEG];
+};
+
+template <int NSUB>
+__global__ __launch_bounds__(512) void gemm_skinny_grouped_kernel(const void* xf, int M, int K, SkinnySegs sg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int seg = 0;
+#pragma unroll
+    for (int i = 1; i < GEMV_MAX_SEG; ++i)
+        if (i < sg.nseg && (int)blockIdx.x >= sg.wg_begin[i]) seg = i;
+    GemmArgs a{xf, sg.qweight[seg], sg.meta[seg], sg.bias[seg], sg.y[seg], M, sg.N[seg], K, sg.key[seg] >> 1, sg.key[seg] & 1, K,
+               sg.y_stride[seg], nullptr, 1, sg.residual[seg], nullptr};
+    const int bx = (int)blockIdx.x - sg.wg_begin[seg];
+    switch (sg.key[seg]) {
+        case 4 * 2 + MODE_HQQ: skinny_body<4, MODE_HQQ, 4, NSUB, 2, 8, true>(a, bx, smem); break;
+        case 3 * 2 + MODE_HQQ: skinny_body<3, MODE_HQQ, 4, NSUB, 2, 8, true>(a, bx, smem); break;
+        case 2 * 2 + MODE_HQQ: skinny_body<2, MODE_HQQ, 4, NSUB, 2, 8, true>(a, bx, smem); break;
+        case 4 * 2 + MODE_FMA: skinny_body<4, MODE_FMA, 4, NSUB, 2, 8, true>(a, bx, smem); break;
+        case 3 * 2 + MODE_FMA: skinny_body<3, MODE_FMA, 4, NSUB, 2, 8, true>(a, bx, smem); break;
+        default: skinny_body<2, MODE_FMA, 4, NSUB, 2, 8, true>(a, bx, smem); break;
+    }
+}
+
+template <int NSUB>
+static hipError_t skinny_grouped_launch(const void* xf, int M, int K, SkinnySegs& sg, int total_wg, hipStream_t st) {
+    auto k = gemm_skinny_grouped_kernel<NSUB>;
+    constexpr int LDS = 8 * NSUB * 4096;
+    if (LDS > 64 * 1024) {
+        static hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL(k, dim3(total_wg, (M + 63) / 64), dim3(512), LDS, st, xf, M, K, sg);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg* segs, int nseg, hipStream_t st) {
+    long blocks = 0;
+    for (int i = 0; i < nseg; ++i) blocks += segs[i].N >> 4;
+    blocks *= (M + 63) / 64;
+    const int nsub = blocks <= 320 ? 1 : blocks <= 640 ? 2 : 4;          // as skinny_launch_xf
+    SkinnySegs sg{};
+    sg.nseg = nseg;
+    int wg = 0;
+    for (int i = 0; i < nseg; ++i) {
+        sg.wg_begin[i] = wg;
+        wg += ((segs[i].N >> 4) + nsub - 1) / nsub;
+        sg.N[i] = segs[i].N; sg.key[i] = segs[i].bits * 2 + segs[i].mode;
+        sg.qweight[i] = segs[i].qweight; sg.meta[i] = segs[i].meta; sg.bias[i] = segs[i].bias;
+        sg.residual[i] = segs[i].residual; sg.y[i] = segs[i].y; sg.y_stride[i] = segs[i].y_stride;
+    }
+    if (nsub == 1) return skinny_grouped_launch<1>(xf, M, K, sg, wg, st);
+    if (nsub == 2) return skinny_grouped_launch<2>(xf, M, K, sg, wg, st);
+    return skinny_grouped_launch<4>(xf, M, K, sg, wg, st);
 }
 
 template <int BITS, int MODE, int MB>

@@ -66,6 +66,8 @@ int gemm_ring_rows(int M, int N);                                   // 256 / 128
 bool gemm_takes_ring(int M, int N, int K);                          // GEMM_ROUTE_AUTO's choice for the shape
 hipError_t launch_gemm_xfrag(const GemmArgs& a, hipStream_t st);     // a.x in fragment order (launch_xfrag)
 hipError_t launch_xfrag(const void* src, void* xf, int M, int K, long stride_m, long stride_kt, hipStream_t st);
+// several linears over the same fragment-ordered x as segments of one few-row launch (uses qweight / meta / bias / residual / y / N / bits / mode / y_stride)
+hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg* segs, int nseg, hipStream_t st);
 int gemm_pick_splits(int M, int N, int K, int route = GEMM_ROUTE_AUTO);
 
 // decode-step surroundings (amq_decode.hip)
@@ -103,6 +105,7 @@ struct AttnPrefillArgs {
     int pos0;               // keys already in k / v before this prompt chunk
     int n_heads, n_kv_heads, batch;
     long q_rstride, q_bstride, k_rstride, k_bstride, k_hstride, v_rstride, v_bstride, v_hstride, o_rstride, o_bstride;
+    int out_xfrag;          // 1: out is the fragment-ordered image of the [S, n_heads * 128] result (batch 1), o_* strides unused
 };
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
 // prefill glue (amq_decode.hip)

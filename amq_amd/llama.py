@@ -261,6 +261,11 @@ class QuantLlama:
         self.host_pos = S                       # (the replay sets the device-side position; the host mirror is not part of it)
         return self.logits
 
+    # prompt rows (exclusive, inclusive) served by the fragment-ordered few-row kernels with q/k/v and gate/up as grouped
+    # launches.  7B avg-3, ms per prompt pass, this path | the row-major / tiled kernels: 16 rows 2.91 | 2.55, 24 3.03 | 3.13,
+    # 32 3.06 | 3.28, 64 3.19 | 3.72, 256 6.74 | 7.32, 384 10.86 | 11.30, 512 12.58 | 11.26
+    FRAG_ROWS = (16, 384)
+
     def _prefill_eager(self, ids):
         """Many-row pass over the prompt: per block 2 RMSNorm + 7 GEMMs (residuals fused into the o_proj / down_proj
         epilogues) + one RoPE-and-cache-write launch + causal attention (library SDPA reading K/V straight from the
@@ -281,24 +286,29 @@ class QuantLlama:
             return ops.gemm_xfrag(xf, S, l.qn, l.mn, l.bits, l.mode, l.N, l.K, residual=residual, gate=gate,
                                   out=residual if residual is not None else gate)
 
+        def lin_xf_group(ls, xf):
+            ys = [torch.empty(S, l.N, dtype=torch.float16, device=self.dev) for l in ls]
+            ops.gemm_xfrag_grouped(xf, S, [dict(qn=l.qn, mn=l.mn, bits=l.bits, mode=l.mode, N=l.N, y=y) for l, y in zip(ls, ys)], ls[0].K)
+            return ys
+
         # up to 256 rows the projections that read a normed / attention activation take it in fragment order (written
         # that way by the producing launch): 1.2-1.6x faster few-row GEMMs; down_proj (K = 11008: the
         # per-workgroup x stream is what bounds that kernel) and longer prompts stay on the tiled kernel
-        frag = 32 < S <= 256                        # up to 32 rows the row-major skinny kernel (16 / 32-row variants) is as fast
+        frag = self.FRAG_ROWS[0] < S <= self.FRAG_ROWS[1]
         for blk in self.blocks:
             if frag:
                 h = ops.rmsnorm_xfrag(x, blk["ln1"], self.eps)
-                q, k, v = (lin_xf(blk["self_attn." + n], h) for n in ("q_proj", "k_proj", "v_proj"))
+                q, k, v = lin_xf_group([blk["self_attn." + n] for n in ("q_proj", "k_proj", "v_proj")], h)   # one launch
             else:
                 h = ops.rmsnorm(x, blk["ln1"], self.eps)
                 q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
             ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, 0, nh, nkv)
             if frag:
-                a = self._prefill_attention(q, blk, S)                             # [S, nh*128]
-                x = lin_xf(blk["self_attn.o_proj"], ops.xfrag(a, S, H), residual=x)
+                a_xf = ops.attn_prefill(q, blk["kc"], blk["vc"], None, S, nh, nkv, batch=1, kv_cache=True, out_xfrag=True)
+                x = lin_xf(blk["self_attn.o_proj"], a_xf, residual=x)              # attention output handed over in fragment order
                 h2 = ops.rmsnorm_xfrag(x, blk["ln2"], self.eps)
-                g = lin_xf(blk["mlp.gate_proj"], h2)
-                act = lin_xf(blk["mlp.up_proj"], h2, gate=g)                       # silu(gate) * up in up_proj's epilogue
+                g, u = lin_xf_group([blk["mlp.gate_proj"], blk["mlp.up_proj"]], h2)                            # one launch
+                act = ops.silu_mul(g, u, out=g)
             else:
                 x = lin(blk["self_attn.o_proj"], self._prefill_attention(q, blk, S), residual=x)
                 h2 = ops.rmsnorm(x, blk["ln2"], self.eps)

@@ -312,6 +312,28 @@ def gemm_xfrag(xf, M, qn, mn, bits, mode, N, K, bias=None, out=None, residual=No
     return y
 
 
+def gemm_xfrag_grouped(xf, M, segments, K):
+    """One few-row launch for several linears over the same fragment-ordered x (q/k/v, gate/up of a prompt pass).
+    segments: list of dicts {qn, mn, bits, mode, N, y, bias=None, residual=None} (y / residual: fp16 [M, N] contiguous).
+    Per segment the result is :func:`gemm_xfrag`'s, bit for bit."""
+    if not 1 <= len(segments) <= _lib.MAX_SEGMENTS:
+        raise ValueError(f"1..{_lib.MAX_SEGMENTS} segments")
+    lib = _lib.load()
+    _need(xf, torch.float16, "xf", lib.amq_xfrag_bytes(M, K) // 2)
+    arr = (Segment * len(segments))()
+    for i, s in enumerate(segments):
+        _check_shape(s["bits"], s["N"], K)
+        _check_native(s["qn"], s["mn"], s["bits"], s["N"], K)
+        _need(s["y"], torch.float16, "y", M * s["N"])
+        if s.get("bias") is not None:
+            _need(s["bias"], torch.float16, "bias", s["N"])
+        if s.get("residual") is not None:
+            _need(s["residual"], torch.float16, "residual", M * s["N"])
+        arr[i] = Segment(_lib.ptr(s["qn"]), _lib.ptr(s["mn"]), _lib.ptr(s.get("bias")), _lib.ptr(s.get("residual")),
+                         _lib.ptr(s["y"]), s["N"], s["bits"], s["mode"], 0)
+    _lib.check(lib.amq_gemm_xfrag_grouped_f16(arr, len(segments), _lib.ptr(xf), M, K, GROUP, _lib.current_stream()))
+
+
 def linear(x, qn, mn, bits, mode, N, K, bias=None):
     """Reference-style dispatch: few rows -> gemv family, otherwise gemm."""
     _check_shape(bits, N, K)
@@ -430,13 +452,22 @@ def rope_cache(q, k, v, kcache, vcache, table, pos0, n_heads, n_kv_heads):
                                               kcache.shape[1], _lib.current_stream()))
 
 
-def attn_prefill(q, k, v, out, S, n_heads, n_kv_heads, batch=1, pos0=0, kv_cache=False):
+def attn_prefill(q, k, v, out, S, n_heads, n_kv_heads, batch=1, pos0=0, kv_cache=False, out_xfrag=False):
     """Causal attention over a prompt (amq_attn_prefill_f16).  q / out: fp16 [batch*S, n_heads*128] (q rotated).
     kv_cache=False: k / v are projection outputs [batch*S, n_kv_heads*128] (rotated keys); kv_cache=True: k / v are cache
-    tensors [batch, n_kv_heads, max_seq, 128] whose rows 0 .. pos0+S-1 are valid."""
+    tensors [batch, n_kv_heads, max_seq, 128] whose rows 0 .. pos0+S-1 are valid.
+    out_xfrag (batch 1): ``out`` is an :func:`xfrag` buffer of the result (None: allocated) -- what :func:`gemm_xfrag` reads."""
     H = n_heads * 128
     _need(q, torch.float16, "q", batch * S * H)
-    _need(out, torch.float16, "out", batch * S * H)
+    if out_xfrag:
+        if batch != 1:
+            raise ValueError("out_xfrag needs batch == 1")
+        nb = _lib.load().amq_xfrag_bytes(S, H)
+        if out is None:
+            out = torch.empty(nb // 2, dtype=torch.float16, device=q.device)
+        _need(out, torch.float16, "out_xf", nb // 2)
+    else:
+        _need(out, torch.float16, "out", batch * S * H)
     if kv_cache:
         if k.dim() != 4 or k.shape[0] != batch or k.shape[1] != n_kv_heads or k.shape[3] != 128 or v.shape != k.shape:
             raise ValueError("caches must be [batch, n_kv_heads, max_seq, 128]")
@@ -452,6 +483,10 @@ def attn_prefill(q, k, v, out, S, n_heads, n_kv_heads, batch=1, pos0=0, kv_cache
         _need(k, torch.float16, "k", batch * S * n_kv_heads * 128)
         _need(v, torch.float16, "v", batch * S * n_kv_heads * 128)
         kr, kb, kh = n_kv_heads * 128, S * n_kv_heads * 128, 128
+    if out_xfrag:
+        _lib.check(_lib.load().amq_attn_prefill_xfrag_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(out), S, int(pos0), n_heads,
+                                                          n_kv_heads, 128, H, kr, kh, kr, kh, _lib.current_stream()))
+        return out
     _lib.check(_lib.load().amq_attn_prefill_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(out), batch, S, int(pos0), n_heads,
                                                 n_kv_heads, 128, H, S * H, kr, kb, kh, kr, kb, kh, H, S * H, _lib.current_stream()))
     return out

@@ -275,6 +275,11 @@ int amq_rmsnorm_xfrag_f16(const void* x, const void* gamma, void* xf, int M, int
 int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qweight_native, const void* meta_native,
                        const void* bias, const void* gate, const void* residual, void* y, int M, int N, int K, int group,
                        int y_stride, void* stream);
+/* Several linears over the SAME fragment-ordered x (q/k/v, gate/up of a prompt pass), each with its own bit-width, as
+ * segments of one few-row launch (amq_segment as for amq_gemv_grouped_f16; residual optional per segment):
+ * y_i = x . W_i^T (+ bias_i) (+ residual_i).  Results are those of amq_gemm_xfrag_f16 per segment, bit for bit. */
+int amq_gemm_xfrag_grouped_f16(const amq_segment* segments /* host */, int nseg, const void* xf, int M, int K, int group,
+                               void* stream);
 /* Causal self-attention over a prompt: for every sequence b < batch, query row s < S (position pos0 + s) and head h,
  *     out[b, s, h, :] = softmax(q[b, s, h, :] . K[b, 0 .. pos0 + s, g, :]^T / sqrt(128)) . V[b, 0 .. pos0 + s, g, :],   g = h / (n_heads / n_kv_heads)
  * as one flash-style MFMA kernel (fp32 scores and softmax, fp16 probabilities, like the eager HF path).  q must already be
@@ -288,6 +293,12 @@ int amq_attn_prefill_f16(const void* q, const void* k, const void* v, void* out,
                          int n_kv_heads, int head_dim, long long q_rstride, long long q_bstride, long long k_rstride,
                          long long k_bstride, long long k_hstride, long long v_rstride, long long v_bstride, long long v_hstride,
                          long long o_rstride, long long o_bstride, void* stream);
+/* The same for ONE sequence with the result written in fragment order (amq_xfrag_f16's layout of the [S, n_heads * 128]
+ * matrix; rows S .. 64 ceil(S / 64) - 1 zero): what o_proj's few-row GEMM (amq_gemm_xfrag_f16) reads, without the
+ * re-ordering launch in between.  out_xf: amq_xfrag_bytes(S, n_heads * 128) bytes. */
+int amq_attn_prefill_xfrag_f16(const void* q, const void* k, const void* v, void* out_xf, int S, int pos0, int n_heads,
+                               int n_kv_heads, int head_dim, long long q_rstride, long long k_rstride, long long k_hstride,
+                               long long v_rstride, long long v_hstride, void* stream);
 /* RoPE + KV-cache write for S new rows at positions pos0 .. pos0+S-1 of ONE sequence: q fp16 [S, n_heads*128] is
  * rotated in place; k [S, n_kv_heads*128] is rotated into kcache[h][pos0+s][:], v copied into vcache (both
  * [n_kv_heads, max_seq, 128]); rope_table from amq_rope_table_f16 (rows past rope_rows-1 clamp).  Same numerics as the

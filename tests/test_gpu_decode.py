@@ -585,6 +585,25 @@ def test_prefill_graph_survives_scratch_growth():
     del junk
 
 
+@pytest.mark.parametrize("S,nh,nkv,pos0", [(5, 4, 4, 0), (64, 4, 2, 0), (65, 8, 2, 0), (200, 32, 8, 0), (33, 4, 2, 70), (130, 4, 1, 0)])
+def test_attn_prefill_xfrag_output(S, nh, nkv, pos0):
+    """amq_attn_prefill_xfrag_f16: the attention result written straight in fragment order == amq_xfrag_f16 of the row-major
+    result, bit for bit, including the zero rows that pad the last 64-row group"""
+    from amq_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(S + nh)
+    H = nh * 128
+    q = torch.randn(S, H, generator=g).half().to(dev)
+    T = pos0 + S
+    kc = torch.zeros(1, nkv, T + 5, 128, dtype=torch.float16, device=dev); vc = torch.zeros_like(kc)
+    kc[:, :, :T] = torch.randn(1, nkv, T, 128, generator=g).half().to(dev)
+    vc[:, :, :T] = torch.randn(1, nkv, T, 128, generator=g).half().to(dev)
+    rows = ops.attn_prefill(q, kc, vc, torch.empty_like(q), S, nh, nkv, pos0=pos0, kv_cache=True)
+    want = ops.xfrag(rows, S, H)
+    got = ops.attn_prefill(q, kc, vc, torch.full_like(want, float("nan")), S, nh, nkv, pos0=pos0, kv_cache=True, out_xfrag=True)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("S,nh,nkv,batch,pos0", [(5, 4, 4, 1, 0), (64, 4, 2, 1, 0), (65, 8, 2, 2, 0), (200, 4, 4, 1, 0),
                                                   (130, 4, 1, 3, 0), (33, 4, 2, 1, 70), (257, 2, 2, 1, 0),
                                                   (300, 32, 8, 3, 0), (200, 32, 32, 4, 100),      # (many workgroups: several per CU)

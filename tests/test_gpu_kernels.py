@@ -522,6 +522,33 @@ def test_gemm_big_tiles(bits, m, n, k, route):
     assert torch.equal(inplace, res.to(dev) + y)
 
 
+@pytest.mark.parametrize("m,k,specs", [(64, 1024, [(4, 512), (2, 256), (3, 384)]),            # q/k/v-like, one column block per workgroup
+                                       (40, 512, [(3, 4096), (4, 4096)]),                       # 512 blocks: two per workgroup
+                                       (200, 768, [(2, 3072), (3, 1040), (4, 2064)]),           # four per workgroup, ragged last groups, 4 row groups
+                                       (33, 256, [(4, 16)])])
+def test_gemm_xfrag_grouped_equals_single_launches(m, k, specs):
+    """several linears over one fragment-ordered x as segments of ONE few-row launch == the same linears launched one by one
+    (amq_gemm_xfrag_f16), bit for bit, with bias and an in-place residual on one segment; and == the oracle linear."""
+    from amq_amd import ops
+    dev = _dev()
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(m + k)).to(torch.float16)
+    xf = ops.xfrag(x.to(dev), m, k)
+    segs, singles, refs = [], [], []
+    for i, (bits, n) in enumerate(specs):
+        h, qn, mn, w_ref = _random_case(bits, n, k, seed=100 * i + bits, bias=(i == 0))
+        bias = h.bias.to(dev) if i == 0 else None
+        res = torch.randn(m, n, generator=torch.Generator().manual_seed(i)).to(torch.float16).to(dev) if i == len(specs) - 1 else None
+        y = res.clone() if res is not None else torch.empty(m, n, dtype=torch.float16, device=dev)
+        segs.append(dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_HQQ, N=n, y=y, bias=bias, residual=y if res is not None else None))
+        singles.append(ops.gemm_xfrag(xf, m, qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias, residual=res.clone() if res is not None else None))
+        refs.append((w_ref, h.bias.numpy() if i == 0 else None, res))
+    ops.gemm_xfrag_grouped(xf, m, segs, k)
+    for s, one, (w_ref, b, res) in zip(segs, singles, refs):
+        assert torch.equal(s["y"], one)
+        if res is None:
+            _assert_close(s["y"].cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref, b), "grouped few-row segment")
+
+
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("m,n,k,route", [(20, 1024, 512, 0), (64, 2048, 256, 2), (300, 1040, 1152, 0), (300, 1040, 1152, 1),
                                          (200, 2048, 4096, 0),                       # tiled kernel + split-K, then the element-wise launch

@@ -1,8 +1,12 @@
 import sys, time, torch
 sys.path.insert(0, '/root/repo')
-import bench
+import bench, os
+from amq_amd.llama import QuantLlama
+if os.environ.get('FRAG_ROWS'):
+    QuantLlama.FRAG_ROWS = tuple(int(v) for v in os.environ['FRAG_ROWS'].split(','))
+SS = tuple(int(v) for v in os.environ.get('PREFILL_S', '16,64,128,256,512,1024,2048').split(','))
 m, a, usage = bench.build_model(torch.device('cuda:0'), seed=0, max_seq=2200)
-for S in (16, 64, 128, 256, 512, 1024, 2048):
+for S in SS:
     ids = torch.randint(0, m.vocab - 1, (S,), generator=torch.Generator().manual_seed(0)).to(m.dev)
     for _ in range(2):
         m.prefill(ids)
