@@ -550,6 +550,9 @@ static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
     // 64-row tiles while 128-row tiles would leave the chip under-filled (< 1.5 workgroups per CU)
     const long wg128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (a.splits > 1 && split_narrow(a.M)) return gemm_launch_cfg<BITS, MODE, 64, 1>(a, st);
+    // 64 x 64 tiles while 64 x 128 ones give at most 1.5 workgroups per CU: two waves per SIMD instead of one cover this kernel's
+    // per-K-step drain (4096^2 3-bit, TFLOP/s: M = 512 415 -> 431, 768 490 -> 530; at 1024 rows the wide tile wins, 629 vs 587)
+    if (a.splits <= 1 && (long)((a.M + 63) / 64) * ((a.N + 127) / 128) <= 384) return gemm_launch_cfg<BITS, MODE, 64, 1>(a, st);
     if (a.M <= 64 || wg128 < 384 || a.splits > 1) return gemm_launch_cfg<BITS, MODE, 64, 2>(a, st);
     // measured (5120x5120, M = 4096 / 16384): NSUB = 2 -> 0.81 / 0.89-0.92 PFLOP/s; NSUB = 4 needs ~390 VGPRs
     // (one wave per SIMD) and dropped to 0.68 / 0.76 (variant removed)
