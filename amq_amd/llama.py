@@ -231,34 +231,38 @@ class QuantLlama:
         rot = torch.cat([-t2, t1], dim=-1)
         return t * cos + rot * sin
 
-    def prefill(self, ids, use_graph=True):
-        """ids: int64 [S] prompt.  Fills the KV caches, leaves the next token in self.token and pos = S.
+    def prefill(self, ids, use_graph=True, start_pos=0):
+        """ids: int64 [S] prompt.  Fills the KV caches, leaves the next token in self.token and pos = start_pos + S.
         The ~25 framework launches per block make an eager prefill host-bound for short prompts (13 ms at S = 64,
         of which ~1 ms is GPU work); with ``use_graph`` the whole prefill of a given prompt LENGTH is captured once
-        into a hipGraph and replayed for later prompts of that length."""
+        into a hipGraph and replayed for later prompts of that length.
+        ``start_pos`` > 0 (the reference's patched forward takes the same argument, ftllama_modeling.py:76,98-104): the rows
+        are appended behind ``start_pos`` cached positions -- a prompt fed in chunks, or the next turn of a conversation --
+        and attend the whole cache; the graph cache is keyed by (length, start_pos)."""
         S = ids.numel()
-        if S > self.max_seq:
+        start_pos = int(start_pos)
+        if start_pos < 0 or start_pos + S > self.max_seq:
             raise ValueError("prompt longer than the KV cache")
         if not use_graph:
-            return self._prefill_eager(ids)
+            return self._prefill_eager(ids, start_pos)
         cache = self.__dict__.setdefault("_prefill_graphs", {})
-        ent = cache.get(S)
+        ent = cache.get((S, start_pos))
         if ent is None:
             static_ids = ids.to(self.dev).clone()
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
-                self._prefill_eager(static_ids)            # warm-up outside capture (allocator, lazy init)
+                self._prefill_eager(static_ids, start_pos)     # warm-up outside capture (allocator, lazy init)
                 side.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    self._prefill_eager(static_ids)
+                    self._prefill_eager(static_ids, start_pos)
             torch.cuda.current_stream(self.dev).wait_stream(side)
-            ent = cache[S] = (g, static_ids)
+            ent = cache[(S, start_pos)] = (g, static_ids)
         g, static_ids = ent
         static_ids.copy_(ids.to(self.dev))
         g.replay()
-        self.host_pos = S                       # (the replay sets the device-side position; the host mirror is not part of it)
+        self.host_pos = start_pos + S           # (the replay sets the device-side position; the host mirror is not part of it)
         return self.logits
 
     # prompt rows (exclusive, inclusive) served by the fragment-ordered few-row kernels with q/k/v and gate/up as grouped
@@ -266,12 +270,12 @@ class QuantLlama:
     # 32 3.06 | 3.28, 64 3.19 | 3.72, 256 6.74 | 7.32, 384 10.86 | 11.30, 512 12.58 | 11.26
     FRAG_ROWS = (16, 384)
 
-    def _prefill_eager(self, ids):
+    def _prefill_eager(self, ids, start_pos=0):
         """Many-row pass over the prompt: per block 2 RMSNorm + 7 GEMMs (residuals fused into the o_proj / down_proj
         epilogues) + one RoPE-and-cache-write launch + causal attention (library SDPA reading K/V straight from the
         cache) + one SiLU*up launch."""
         S = ids.numel()
-        if S > self.max_seq:
+        if start_pos + S > self.max_seq:
             raise ValueError("prompt longer than the KV cache")
         H, nh, nkv = self.H, self.nh, self.nkv
         x = self.embed.index_select(0, ids.to(self.dev))           # [S, H]; the residual stream, updated in place
@@ -302,15 +306,15 @@ class QuantLlama:
             else:
                 h = ops.rmsnorm(x, blk["ln1"], self.eps)
                 q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
-            ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, 0, nh, nkv)
+            ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, start_pos, nh, nkv)
             if frag:
-                a_xf = ops.attn_prefill(q, blk["kc"], blk["vc"], None, S, nh, nkv, batch=1, kv_cache=True, out_xfrag=True)
+                a_xf = ops.attn_prefill(q, blk["kc"], blk["vc"], None, S, nh, nkv, batch=1, pos0=start_pos, kv_cache=True, out_xfrag=True)
                 x = lin_xf(blk["self_attn.o_proj"], a_xf, residual=x)              # attention output handed over in fragment order
                 h2 = ops.rmsnorm_xfrag(x, blk["ln2"], self.eps)
                 g, u = lin_xf_group([blk["mlp.gate_proj"], blk["mlp.up_proj"]], h2)                            # one launch
                 act = ops.silu_mul(g, u, out=g)
             else:
-                x = lin(blk["self_attn.o_proj"], self._prefill_attention(q, blk, S), residual=x)
+                x = lin(blk["self_attn.o_proj"], self._prefill_attention(q, blk, S, start_pos), residual=x)
                 h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
                 g = lin(blk["mlp.gate_proj"], h2)
                 if S > 8:
@@ -319,7 +323,7 @@ class QuantLlama:
                 else:
                     act = ops.silu_mul(g, lin(blk["mlp.up_proj"], h2), out=g)
             x = lin(blk["mlp.down_proj"], act, residual=x)
-        return self._prefill_finish(x, S)
+        return self._prefill_finish(x, S, start_pos)
 
     def _rows_linear(self, l, inp, residual=None):
         # y = inp . W^T (+ residual, in place) for many rows
@@ -356,9 +360,9 @@ class QuantLlama:
             ops.gemv_f16w(last[b], self.lm_head, gamma=self.norm, eps=self.eps, out=logits[b])
         return logits
 
-    def _prefill_attention(self, q, blk, S):
-        """causal attention of the prompt rows: q [S, nh*128] rotated, K / V = the cache rows just written -> [S, nh*128]"""
-        return ops.attn_prefill(q, blk["kc"], blk["vc"], torch.empty_like(q), S, self.nh, self.nkv, batch=1, kv_cache=True)
+    def _prefill_attention(self, q, blk, S, start_pos=0):
+        """causal attention of the prompt rows: q [S, nh*128] rotated, K / V = cache rows 0 .. start_pos + S - 1 -> [S, nh*128]"""
+        return ops.attn_prefill(q, blk["kc"], blk["vc"], torch.empty_like(q), S, self.nh, self.nkv, batch=1, pos0=start_pos, kv_cache=True)
 
     def _prefill_attention_sdpa(self, q, blk, S):
         """the same through the framework's SDPA (comparison point for tests / tools; not on the product path)"""
@@ -371,10 +375,10 @@ class QuantLlama:
         a = torch.nn.functional.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
         return a.transpose(0, 1).reshape(S, self.H).contiguous()
 
-    def _prefill_finish(self, x, S):
+    def _prefill_finish(self, x, S, start_pos=0):
         last = x[S - 1].contiguous()
         ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        self.set_pos(S)
+        self.set_pos(start_pos + S)
         self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
         return self.logits
 
@@ -500,22 +504,22 @@ class DenseLlama(QuantLlama):
     def _rows_up_gated(self, w, inp, gate):
         return ops.silu_mul(gate, torch.nn.functional.linear(inp, w), out=gate)
 
-    def _prefill_eager(self, ids):
+    def _prefill_eager(self, ids, start_pos=0):
         F = torch.nn.functional
         S = ids.numel()
-        if S > self.max_seq:
+        if start_pos + S > self.max_seq:
             raise ValueError("prompt longer than the KV cache")
         nh, nkv = self.nh, self.nkv
         x = self.embed.index_select(0, ids.to(self.dev))
         for blk in self.blocks:
             h = ops.rmsnorm(x, blk["ln1"], self.eps)
             q, k, v = F.linear(h, blk["self_attn.q_proj"]), F.linear(h, blk["self_attn.k_proj"]), F.linear(h, blk["self_attn.v_proj"])
-            ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, 0, nh, nkv)
-            x = torch.addmm(x, self._prefill_attention(q, blk, S), blk["self_attn.o_proj"].t())
+            ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, start_pos, nh, nkv)
+            x = torch.addmm(x, self._prefill_attention(q, blk, S, start_pos), blk["self_attn.o_proj"].t())
             h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             g, u = F.linear(h2, blk["mlp.gate_proj"]), F.linear(h2, blk["mlp.up_proj"])
             x = torch.addmm(x, ops.silu_mul(g, u, out=g), blk["mlp.down_proj"].t())
-        return self._prefill_finish(x, S)
+        return self._prefill_finish(x, S, start_pos)
 
 
 def get_memory_footprint(model):

@@ -502,6 +502,45 @@ def test_prefill_batch_matches_single_sequence_passes(gqa):
     assert (gd[1].float() - rd).abs().max() <= 1e-2 * rd.abs().max()
 
 
+@pytest.mark.parametrize("gqa,split", [(False, (40, 24)), (True, (7, 90)), (False, (70, 3))])
+def test_prefill_in_chunks_matches_one_pass(gqa, split):
+    """prefill(ids[a:], start_pos=a) behind prefill(ids[:a]) (the reference's patched forward takes the same start_pos,
+    ftllama_modeling.py:76-104): same cache rows and last-token logits as one pass over the whole prompt (different row counts
+    pick different GEMM kernels: fp16-rounding distance), the decode steps that follow agree, graph and eager forms agree."""
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama, DenseLlama
+    a, b = split
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 2 if gqa else 4, 1, vocab=1024))
+    ids = torch.randint(0, 1024, (a + b,), generator=torch.Generator().manual_seed(a)).to(_dev())
+    for cls in (QuantLlama, DenseLlama):
+        m = cls(cfg, None, device="cuda:0", max_seq=a + b + 8, seed=4) if cls is QuantLlama else cls(cfg, device="cuda:0", max_seq=a + b + 8, seed=4)
+        whole = m.prefill(ids, use_graph=False).float().clone()
+        kc_whole = [blk["kc"].clone() for blk in m.blocks]
+        m.decode_step(use_graph=False)
+        next_whole = m.logits.float().clone()
+        m.reset()
+        m.prefill(ids[:a], use_graph=False)
+        got = m.prefill(ids[a:], use_graph=False, start_pos=a).float().clone()
+        assert m.host_pos == a + b and int(m.pos.item()) == a + b
+        scale = whole.abs().max()
+        assert (got - whole).abs().max() <= 1e-2 * scale
+        for blk, ref in zip(m.blocks, kc_whole):
+            d = (blk["kc"][:, :, :a + b].float() - ref[:, :, :a + b].float()).abs().max()
+            assert d <= 2e-2 * ref.float().abs().max()
+        m.decode_step(use_graph=False)
+        assert (m.logits.float() - next_whole).abs().max() <= 1e-2 * scale
+        # the graph form of the second chunk (keyed by length and start position) gives the eager form's bits
+        m.reset()
+        m.prefill(ids[:a], use_graph=False)
+        eager = m.prefill(ids[a:], use_graph=False, start_pos=a).clone()
+        m.reset()
+        m.prefill(ids[:a])
+        graph = m.prefill(ids[a:], start_pos=a).clone()
+        assert torch.equal(graph, eager) and m.host_pos == a + b
+    with pytest.raises(ValueError):
+        m.prefill(ids, start_pos=20)                       # does not fit the cache
+
+
 def test_speed_harness_gemm_mode_batched():
     from amq_amd import arch
     from amq_amd.llama import QuantLlama
