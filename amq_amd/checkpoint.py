@@ -62,7 +62,7 @@ def runner_config(hf):
     return c
 
 
-def load_mixed(dirs, arch_linear, device="cuda:0", max_seq=256):
+def load_mixed(dirs, arch_linear, device="cuda:0", max_seq=256, batch=1):
     """dirs: {bits: checkpoint dir}; arch_linear: {'self_attn.q_proj': [bits]*n_block, ...}.
     Returns a QuantLlama holding real weights."""
     from .llama import QuantLlama
@@ -82,4 +82,4 @@ def load_mixed(dirs, arch_linear, device="cuda:0", max_seq=256):
              "norm": any_w["model.norm"]["weight"].to(torch.float16),
              "ln1": [any_w[f"model.layers.{i}.input_layernorm"]["weight"].to(torch.float16) for i in range(cfg["n_block"])],
              "ln2": [any_w[f"model.layers.{i}.post_attention_layernorm"]["weight"].to(torch.float16) for i in range(cfg["n_block"])]}
-    return QuantLlama(cfg, arch_linear, device=device, max_seq=max_seq, hqq_layers=layers, dense=dense)
+    return QuantLlama(cfg, arch_linear, device=device, max_seq=max_seq, hqq_layers=layers, dense=dense, batch=batch)

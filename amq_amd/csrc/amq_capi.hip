@@ -394,6 +394,15 @@ int amq_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const
     return check_hip(amq::launch_gemv_f16w(x, W, bias, y, gamma, eps, N, K, (hipStream_t)stream), "gemv_f16w");
 }
 
+int amq_gemv_f16w_rows(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps, int M,
+                       int N, int K, void* stream) {
+    if (!x || !W || !y) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1 || M > 8) return fail(AMQ_ESHAPE, "M must be 1..8 (got %d)", M);
+    if (N < 1 || K < 8 || (K % 8) != 0) return fail(AMQ_ESHAPE, "need N >= 1 and K %% 8 == 0 (got %d, %d)", N, K);
+    if ((size_t)M * K * 2 + 64 > LDS_LIMIT) return fail(AMQ_ESHAPE, "%d rows of K=%d do not fit LDS", M, K);
+    return check_hip(amq::launch_gemv_f16w(x, W, bias, y, gamma, eps, N, K, (hipStream_t)stream, M), "gemv_f16w_rows");
+}
+
 int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcache, void* vcache, void* out,
                         const int* pos_dev, int pos, int batch, int n_heads, int n_kv_heads, int head_dim,
                         int max_seq, float rope_theta, const void* rope_table, void* stream) {
@@ -497,6 +506,17 @@ int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hi
     if (rope_cur && rope_rows < 1) return fail(AMQ_EINVAL, "rope_rows must be the number of rows of rope_table");
     if (vocab < 1 || hidden < 8 || (hidden % 8) != 0) return fail(AMQ_ESHAPE, "need vocab >= 1 and hidden %% 8 == 0 (got %d, %d)", vocab, hidden);
     return check_hip(amq::launch_decode_tail(logits, vocab, embed, hidden, token, pos, x, rope_table, rope_cur, rope_rows, (hipStream_t)stream), "decode_tail");
+}
+
+int amq_decode_tail_batch_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
+                              const void* rope_table, void* rope_cur, int rope_rows, int batch, void* stream) {
+    if (!logits || !embed || !token || !pos || !x) return fail(AMQ_EINVAL, "null pointer");
+    if ((rope_table == nullptr) != (rope_cur == nullptr)) return fail(AMQ_EINVAL, "rope_table and rope_cur go together");
+    if (rope_cur && rope_rows < 1) return fail(AMQ_EINVAL, "rope_rows must be the number of rows of rope_table");
+    if (vocab < 1 || hidden < 8 || (hidden % 8) != 0) return fail(AMQ_ESHAPE, "need vocab >= 1 and hidden %% 8 == 0 (got %d, %d)", vocab, hidden);
+    if (batch < 1 || batch > 65535) return fail(AMQ_ESHAPE, "bad batch %d", batch);
+    if (batch > 1 && (vocab % 8) != 0) return fail(AMQ_ESHAPE, "batched rows need vocab %% 8 == 0 (16-byte aligned logits rows)");
+    return check_hip(amq::launch_decode_tail(logits, vocab, embed, hidden, token, pos, x, rope_table, rope_cur, rope_rows, (hipStream_t)stream, batch), "decode_tail_batch");
 }
 
 int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream) {

@@ -76,44 +76,51 @@ hipError_t launch_rmsnorm_xfrag(const void* x, const void* gamma, void* xf, int 
 }
 
 // ------------------------------------------------------- fp16-weight GEMV
-// M == 1.  x (optionally RMSNorm'ed) staged in LDS; each wave owns rows
-// r = first + i * stride and streams them 16 B per lane (512 k per wave-load),
-// two rows in flight; 6-step wavefront reduction per row.
+// M = 1 .. 8 rows of x (batched decode: the lm_head is streamed ONCE for all sequences).  x (optionally RMSNorm'ed) staged in
+// LDS; each wave owns rows r = first + i * stride of W and streams them 16 B per lane (512 k per wave-load), four loads
+// in flight; 6-step wavefront reduction per (row of W, row of x).  M is a template parameter: the M = 1 instantiation
+// is the decode step's lm_head kernel unchanged.
 constexpr int F16W_WAVES = 4;
 
-template <bool NORM>
+template <bool NORM, int M>
 __global__ __launch_bounds__(F16W_WAVES * 64) void gemv_f16w_kernel(const _Float16* x, const _Float16* W, const _Float16* bias,
                                                                      _Float16* y, const _Float16* gamma, float eps, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    _Float16* xl = (_Float16*)smem;
-    float* red = (float*)(smem + (size_t)K * 2);
+    _Float16* xl = (_Float16*)smem;                 // [M][K]
+    float* red = (float*)(smem + (size_t)M * K * 2);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunks = K >> 3;
-    if (!NORM) {
-        for (int c = tid; c < chunks; c += F16W_WAVES * 64) *(h8*)(xl + 8 * c) = *(const h8*)(x + 8 * c);
-    } else {
-        float ss = 0.f;
-        for (int c = tid; c < chunks; c += F16W_WAVES * 64) {
-            h8 v = *(const h8*)(x + 8 * c);
-            *(h8*)(xl + 8 * c) = v;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { float f = (float)v[i]; ss += f * f; }
-        }
-        ss = wave_sum_f(ss);
-        if (lane == 0) red[wave] = ss;
-        __syncthreads();
-        float tot = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const _Float16* xm = x + (size_t)m * K;
+        _Float16* xlm = xl + (size_t)m * K;
+        if (!NORM) {
+            for (int c = tid; c < chunks; c += F16W_WAVES * 64) *(h8*)(xlm + 8 * c) = *(const h8*)(xm + 8 * c);
+        } else {
+            float ss = 0.f;
+            for (int c = tid; c < chunks; c += F16W_WAVES * 64) {
+                h8 v = *(const h8*)(xm + 8 * c);
+                *(h8*)(xlm + 8 * c) = v;
 #pragma unroll
-        for (int w = 0; w < F16W_WAVES; ++w) tot += red[w];
-        const float rstd = rsqrtf(tot / (float)K + eps);
-        for (int c = tid; c < chunks; c += F16W_WAVES * 64) {
-            h8 v = *(h8*)(xl + 8 * c);
-            h8 g = *(const h8*)(gamma + 8 * c);
-            h8 r;
+                for (int i = 0; i < 8; ++i) { float f = (float)v[i]; ss += f * f; }
+            }
+            ss = wave_sum_f(ss);
+            if (M > 1) __syncthreads();             // the previous row's readers of red[] are done
+            if (lane == 0) red[wave] = ss;
+            __syncthreads();
+            float tot = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { _Float16 n = (_Float16)((float)v[i] * rstd); r[i] = g[i] * n; }
-            *(h8*)(xl + 8 * c) = r;
+            for (int w = 0; w < F16W_WAVES; ++w) tot += red[w];
+            const float rstd = rsqrtf(tot / (float)K + eps);
+            for (int c = tid; c < chunks; c += F16W_WAVES * 64) {
+                h8 v = *(h8*)(xlm + 8 * c);
+                h8 g = *(const h8*)(gamma + 8 * c);
+                h8 r;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { _Float16 n = (_Float16)((float)v[i] * rstd); r[i] = g[i] * n; }
+                *(h8*)(xlm + 8 * c) = r;
+            }
         }
     }
     __syncthreads();
@@ -121,7 +128,9 @@ __global__ __launch_bounds__(F16W_WAVES * 64) void gemv_f16w_kernel(const _Float
     const int steps = (K + 511) >> 9;               // 512 k per wave-load; lanes past K are masked (K % 8 == 0)
     for (int row = gw; row < N; row += nw) {
         const _Float16* wr = W + (size_t)row * K + 8 * lane;
-        float acc = 0.f;
+        float acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = 0.f;
         for (int s = 0; s < steps; s += 4) {
             u4 buf[4];
 #pragma unroll
@@ -130,42 +139,73 @@ __global__ __launch_bounds__(F16W_WAVES * 64) void gemv_f16w_kernel(const _Float
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (s + j < steps && (s + j) * 512 + 8 * lane < K) {
-                    const h8 xv = *(const h8*)(xl + (s + j) * 512 + 8 * lane);
                     const uint32_t wv[4] = {buf[j].x, buf[j].y, buf[j].z, buf[j].w};
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        h2 xp = {xv[2 * p], xv[2 * p + 1]};
-                        acc = __builtin_amdgcn_fdot2(as_h2(wv[p]), xp, acc, false);
+                    for (int m = 0; m < M; ++m) {
+                        const h8 xv = *(const h8*)(xl + (size_t)m * K + (s + j) * 512 + 8 * lane);
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            h2 xp = {xv[2 * p], xv[2 * p + 1]};
+                            acc[m] = __builtin_amdgcn_fdot2(as_h2(wv[p]), xp, acc[m], false);
+                        }
                     }
                 }
             }
         }
-        acc = wave_sum_f(acc);
-        if (lane == 0) {
-            _Float16 o = (_Float16)acc;
-            if (bias) o = o + bias[row];
-            y[row] = o;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float t = wave_sum_f(acc[m]);
+            if (lane == 0) {
+                _Float16 o = (_Float16)t;
+                if (bias) o = o + bias[row];
+                y[(size_t)m * N + row] = o;
+            }
         }
     }
 }
 
-hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
-                            int N, int K, hipStream_t st) {
-    const size_t lds = (size_t)K * 2 + 64;
-    const int grid = 1024;
-    if (gamma)
-        hipLaunchKernelGGL((gemv_f16w_kernel<true>), dim3(grid), dim3(F16W_WAVES * 64), lds, st, (const _Float16*)x, (const _Float16*)W,
-                           (const _Float16*)bias, (_Float16*)y, (const _Float16*)gamma, eps, N, K);
-    else
-        hipLaunchKernelGGL((gemv_f16w_kernel<false>), dim3(grid), dim3(F16W_WAVES * 64), lds, st, (const _Float16*)x, (const _Float16*)W,
-                           (const _Float16*)bias, (_Float16*)y, (const _Float16*)nullptr, eps, N, K);
+template <bool NORM, int M>
+static hipError_t launch_gemv_f16w_m(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
+                                     int N, int K, hipStream_t st) {
+    const size_t lds = (size_t)M * K * 2 + 64;
+    auto k = gemv_f16w_kernel<NORM, M>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(1024), dim3(F16W_WAVES * 64), lds, st, (const _Float16*)x, (const _Float16*)W, (const _Float16*)bias,
+                       (_Float16*)y, (const _Float16*)gamma, eps, N, K);
     return hipGetLastError();
+}
+
+template <bool NORM>
+static hipError_t launch_gemv_f16w_n(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
+                                     int M, int N, int K, hipStream_t st) {
+    switch (M) {
+        case 1: return launch_gemv_f16w_m<NORM, 1>(x, W, bias, y, gamma, eps, N, K, st);
+        case 2: return launch_gemv_f16w_m<NORM, 2>(x, W, bias, y, gamma, eps, N, K, st);
+        case 3: return launch_gemv_f16w_m<NORM, 3>(x, W, bias, y, gamma, eps, N, K, st);
+        case 4: return launch_gemv_f16w_m<NORM, 4>(x, W, bias, y, gamma, eps, N, K, st);
+        case 5: return launch_gemv_f16w_m<NORM, 5>(x, W, bias, y, gamma, eps, N, K, st);
+        case 6: return launch_gemv_f16w_m<NORM, 6>(x, W, bias, y, gamma, eps, N, K, st);
+        case 7: return launch_gemv_f16w_m<NORM, 7>(x, W, bias, y, gamma, eps, N, K, st);
+        default: return launch_gemv_f16w_m<NORM, 8>(x, W, bias, y, gamma, eps, N, K, st);
+    }
+}
+
+// x: fp16 [M, K] contiguous, y: fp16 [M, N] contiguous, 1 <= M <= 8
+hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
+                            int N, int K, hipStream_t st, int M) {
+    if (gamma) return launch_gemv_f16w_n<true>(x, W, bias, y, gamma, eps, M, N, K, st);
+    return launch_gemv_f16w_n<false>(x, W, bias, y, nullptr, eps, M, N, K, st);
 }
 
 // ------------------------------------------------ end of a token step
 // greedy next token + what the next step needs, in ONE single-workgroup launch (replaces argmax, position increment and
 // embedding gather = three framework kernels and their boundaries): token = argmax(logits) (first maximum, like
 // torch.argmax), pos += 1, x = embed[token].
+// Batched decode: one workgroup per sequence (logits / token / x rows of blockIdx.x); the shared position and the cos/sin row are
+// advanced by workgroup 0 only (nobody else reads them here).
 __global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logits, int vocab, const _Float16* embed, int hidden,
                                                             long long* token, int* pos, _Float16* x, const _Float16* rope_table,
                                                             _Float16* rope_cur, int rope_rows) {
@@ -173,6 +213,10 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logit
     __shared__ int sidx[16];
     __shared__ int stok, spos;
     const int tid = threadIdx.x;
+    logits += (size_t)blockIdx.x * vocab;
+    token += blockIdx.x;
+    x += (size_t)blockIdx.x * hidden;
+    if (blockIdx.x != 0) rope_cur = nullptr;
     float best = -INFINITY;
     int bi = 0x7fffffff;
     const int chunks = vocab >> 3;
@@ -204,9 +248,11 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logit
         if (ix == 0x7fffffff) ix = 0;                            // all NaN / empty: torch returns 0-ish; keep it in range
         stok = ix;
         token[0] = (long long)ix;
-        spos = pos[0] + 1;
-        if (rope_cur && spos > rope_rows) spos = rope_rows;      // saturate at the end of the cache: the attention kernel
-        pos[0] = spos;                                           // treats pos == max_seq as "out of range" (no-op + error word)
+        if (blockIdx.x == 0) {
+            spos = pos[0] + 1;
+            if (rope_table && spos > rope_rows) spos = rope_rows;    // saturate at the end of the cache: the attention kernel
+            pos[0] = spos;                                           // treats pos == max_seq as "out of range" (no-op + error word)
+        }
     }
     __syncthreads();
     if (rope_cur && tid < 128) {                                      // cos/sin row of the new position (last row once the cache is full)
@@ -218,8 +264,8 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logit
 }
 
 hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, int hidden, void* token, void* pos, void* x,
-                              const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st) {
-    hipLaunchKernelGGL(decode_tail_kernel, dim3(1), dim3(1024), 0, st, (const _Float16*)logits, vocab, (const _Float16*)embed, hidden,
+                              const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st, int batch) {
+    hipLaunchKernelGGL(decode_tail_kernel, dim3(batch), dim3(1024), 0, st, (const _Float16*)logits, vocab, (const _Float16*)embed, hidden,
                        (long long*)token, (int*)pos, (_Float16*)x, (const _Float16*)rope_table, (_Float16*)rope_cur, rope_rows);
     return hipGetLastError();
 }

@@ -60,13 +60,18 @@ def _synthetic_linear(n, k, bits, gen, device):
 
 class QuantLlama:
     def __init__(self, config, arch_linear=None, device="cuda:0", max_seq=256, seed=0, synthetic=True,
-                 hqq_layers=None, dense=None):
+                 hqq_layers=None, dense=None, batch=1):
         """config: an entry of arch.MODEL_CONFIGS (or its name).
         arch_linear: {'self_attn.q_proj': [bits]*n_block, ...}; default uniform 4.
         hqq_layers: {(block, name): HQQWeights} real quantized layers (else synthetic).
-        dense: {'embed','lm_head','norm','ln1'[n_block],'ln2'[n_block]} fp16 tensors (else synthetic)."""
+        dense: {'embed','lm_head','norm','ln1'[n_block],'ln2'[n_block]} fp16 tensors (else synthetic).
+        batch: sequences decoded together, 1 .. 8 (same prompt length; one step = the same launches with ``batch`` rows: the
+        weights are streamed once per step for all of them).  batch = 1 is the reference's FT configuration."""
         if isinstance(config, str):
             config = MODEL_CONFIGS[config]
+        if not 1 <= int(batch) <= 8:
+            raise ValueError("batch must be 1..8")
+        self.B = int(batch)
         self.cfg = config
         self.dev = torch.device(device)
         self.H = config["hidden_size"]
@@ -106,8 +111,8 @@ class QuantLlama:
             else:
                 blk["ln1"] = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
                 blk["ln2"] = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
-            blk["kc"] = torch.zeros(1, self.nkv, max_seq, 128, dtype=torch.float16, device=dev)
-            blk["vc"] = torch.zeros(1, self.nkv, max_seq, 128, dtype=torch.float16, device=dev)
+            blk["kc"] = torch.zeros(self.B, self.nkv, max_seq, 128, dtype=torch.float16, device=dev)
+            blk["vc"] = torch.zeros(self.B, self.nkv, max_seq, 128, dtype=torch.float16, device=dev)
             self.blocks.append(blk)
         if dense is not None:
             self.embed, self.lm_head, self.norm = dense["embed"].to(dev), dense["lm_head"].to(dev), dense["norm"].to(dev)
@@ -117,15 +122,16 @@ class QuantLlama:
             self.norm = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
 
         f16 = dict(dtype=torch.float16, device=dev)
-        self.x = torch.zeros(1, self.H, **f16)
-        self.q = torch.zeros(1, self.H, **f16)
-        self.k = torch.zeros(1, self.kvd, **f16)
-        self.v = torch.zeros(1, self.kvd, **f16)
-        self.att = torch.zeros(1, self.H, **f16)
-        self.gate = torch.zeros(1, self.I, **f16)
-        self.up = torch.zeros(1, self.I, **f16)
-        self.logits = torch.zeros(self.vocab, **f16)
-        self.token = torch.zeros(1, dtype=torch.int64, device=dev)
+        B = self.B
+        self.x = torch.zeros(B, self.H, **f16)
+        self.q = torch.zeros(B, self.H, **f16)
+        self.k = torch.zeros(B, self.kvd, **f16)
+        self.v = torch.zeros(B, self.kvd, **f16)
+        self.att = torch.zeros(B, self.H, **f16)
+        self.gate = torch.zeros(B, self.I, **f16)
+        self.up = torch.zeros(B, self.I, **f16)
+        self.logits = torch.zeros(self.vocab, **f16) if B == 1 else torch.zeros(B, self.vocab, **f16)    # [vocab] | [B, vocab]
+        self.token = torch.zeros(B, dtype=torch.int64, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.rope_tab = ops.rope_table(max_seq, self.theta, dev)
         # step state: cos/sin row of self.pos + the position itself in one block (set_token / the step's tail keep it)
@@ -133,6 +139,7 @@ class QuantLlama:
         self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
         self.host_pos = 0          # host mirror of self.pos (decode_step refuses to run past the cache without a device sync)
+        self._down_rows_fit = self.B <= ops.gemv_max_rows(self.I)
 
     # ----------------------------------------------------------------- sizes
     def linear_bytes_per_token(self):
@@ -157,10 +164,14 @@ class QuantLlama:
             ops.gemv_grouped(self.att, [blk["self_attn.o_proj"].seg(self.x, residual=self.x)], H)
             ops.gemv_grouped(self.x, [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H,
                              prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=self.eps)
-            ops.gemv_grouped(self.gate, [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I,
-                             prologue=ops.PRO_SILU_MUL, x2=self.up)
-        ops.gemv_f16w(self.x.reshape(-1), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-        # argmax, pos += 1, x = embed[token], rope_cur = cos/sin row of the new position
+            if self._down_rows_fit:
+                ops.gemv_grouped(self.gate, [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I,
+                                 prologue=ops.PRO_SILU_MUL, x2=self.up)
+            else:       # batch x intermediate size past the GEMV kernel's LDS stage (7B: 8 rows of 11008): few-row MFMA kernel
+                d = blk["mlp.down_proj"]
+                ops.gemm(ops.silu_mul(self.gate, self.up, out=self.gate), d.qn, d.mn, d.bits, d.mode, d.N, d.K, residual=self.x, out=self.x)
+        ops.gemv_f16w(self.x.reshape(-1) if self.B == 1 else self.x, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
+        # argmax, pos += 1, x = embed[token], rope_cur = cos/sin row of the new position (per sequence; the position is shared)
         ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
 
     def set_pos(self, pos):
@@ -179,7 +190,7 @@ class QuantLlama:
         """make ``token`` (int or 1-element tensor) the input of the next decode step; also re-derives what the step
         reads besides the token (embedding row, cos/sin row of the current position) -- set_pos() first"""
         if isinstance(token, torch.Tensor):
-            self.token.copy_(token.reshape(1))
+            self.token.copy_(token.reshape(-1).expand(self.B) if token.numel() == 1 else token.reshape(self.B))
         else:
             self.token.fill_(int(token))
         torch.index_select(self.embed, 0, self.token, out=self.x)
@@ -239,12 +250,13 @@ class QuantLlama:
         ``start_pos`` > 0 (the reference's patched forward takes the same argument, ftllama_modeling.py:76,98-104): the rows
         are appended behind ``start_pos`` cached positions -- a prompt fed in chunks, or the next turn of a conversation --
         and attend the whole cache; the graph cache is keyed by (length, start_pos)."""
-        S = ids.numel()
+        ids = self._ids_rows(ids)
+        S = ids.shape[1]
         start_pos = int(start_pos)
         if start_pos < 0 or start_pos + S > self.max_seq:
             raise ValueError("prompt longer than the KV cache")
         if not use_graph:
-            return self._prefill_eager(ids, start_pos)
+            return self._prefill_rows(ids, start_pos)
         cache = self.__dict__.setdefault("_prefill_graphs", {})
         ent = cache.get((S, start_pos))
         if ent is None:
@@ -252,17 +264,55 @@ class QuantLlama:
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
-                self._prefill_eager(static_ids, start_pos)     # warm-up outside capture (allocator, lazy init)
+                self._prefill_rows(static_ids, start_pos)      # warm-up outside capture (allocator, lazy init)
                 side.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    self._prefill_eager(static_ids, start_pos)
+                    self._prefill_rows(static_ids, start_pos)
             torch.cuda.current_stream(self.dev).wait_stream(side)
             ent = cache[(S, start_pos)] = (g, static_ids)
         g, static_ids = ent
-        static_ids.copy_(ids.to(self.dev))
+        static_ids.copy_(ids)
         g.replay()
         self.host_pos = start_pos + S           # (the replay sets the device-side position; the host mirror is not part of it)
+        return self.logits
+
+    def _ids_rows(self, ids):
+        """prompt ids as [batch, S] on the device (a 1-D prompt is the batch-1 form)"""
+        ids = ids.to(self.dev)
+        if ids.dim() == 1:
+            ids = ids[None, :]
+        if ids.dim() != 2 or ids.shape[0] != self.B:
+            raise ValueError(f"expected {self.B} prompt(s) of equal length, got ids of shape {tuple(ids.shape)}")
+        return ids
+
+    def _prefill_rows(self, ids, start_pos):
+        """the prompt pass of every sequence (each into its own slice of the caches), then the shared position / next tokens"""
+        if self.B == 1:
+            return self._prefill_eager(ids[0], start_pos)
+        # several sequences: the linears see all B * S rows at once (one pass over the weights), RoPE / cache write and the
+        # causal attention run per sequence on its own slice of the caches
+        B, S = ids.shape
+        H, nh, nkv = self.H, self.nh, self.nkv
+        x = self.embed.index_select(0, ids.reshape(-1))
+        lin = self._rows_linear
+        for blk in self.blocks:
+            h = ops.rmsnorm(x, blk["ln1"], self.eps)
+            q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
+            a = torch.empty_like(q)
+            for b in range(B):
+                rows = slice(b * S, (b + 1) * S)
+                kc, vc = self._cache_rows(blk, b)
+                ops.rope_cache(q[rows], k[rows], v[rows], kc[0], vc[0], self.rope_tab, start_pos, nh, nkv)
+                ops.attn_prefill(q[rows], kc, vc, a[rows], S, nh, nkv, batch=1, pos0=start_pos, kv_cache=True)
+            x = lin(blk["self_attn.o_proj"], a, residual=x)
+            h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
+            act = self._rows_up_gated(blk["mlp.up_proj"], h2, lin(blk["mlp.gate_proj"], h2))
+            x = lin(blk["mlp.down_proj"], act, residual=x)
+        last = x.view(B, S, H)[:, S - 1].contiguous()
+        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
+        self.set_pos(start_pos + S)
+        self.set_token(torch.argmax(self.logits, dim=1))
         return self.logits
 
     # prompt rows (exclusive, inclusive) served by the fragment-ordered few-row kernels with q/k/v and gate/up as grouped
@@ -270,8 +320,9 @@ class QuantLlama:
     # 32 3.06 | 3.28, 64 3.19 | 3.72, 256 6.74 | 7.32, 384 10.86 | 11.30, 512 12.58 | 11.26
     FRAG_ROWS = (16, 384)
 
-    def _prefill_eager(self, ids, start_pos=0):
-        """Many-row pass over the prompt: per block 2 RMSNorm + 7 GEMMs (residuals fused into the o_proj / down_proj
+    def _prefill_eager(self, ids, start_pos=0, b=None):
+        """(b: sequence of a batched runner -- its slice of the caches and its logits row, position / token left to the caller)
+        Many-row pass over the prompt: per block 2 RMSNorm + 7 GEMMs (residuals fused into the o_proj / down_proj
         epilogues) + one RoPE-and-cache-write launch + causal attention (library SDPA reading K/V straight from the
         cache) + one SiLU*up launch."""
         S = ids.numel()
@@ -306,15 +357,16 @@ class QuantLlama:
             else:
                 h = ops.rmsnorm(x, blk["ln1"], self.eps)
                 q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
-            ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, start_pos, nh, nkv)
+            kc, vc = self._cache_rows(blk, b)
+            ops.rope_cache(q, k, v, kc[0], vc[0], self.rope_tab, start_pos, nh, nkv)
             if frag:
-                a_xf = ops.attn_prefill(q, blk["kc"], blk["vc"], None, S, nh, nkv, batch=1, pos0=start_pos, kv_cache=True, out_xfrag=True)
+                a_xf = ops.attn_prefill(q, kc, vc, None, S, nh, nkv, batch=1, pos0=start_pos, kv_cache=True, out_xfrag=True)
                 x = lin_xf(blk["self_attn.o_proj"], a_xf, residual=x)              # attention output handed over in fragment order
                 h2 = ops.rmsnorm_xfrag(x, blk["ln2"], self.eps)
                 g, u = lin_xf_group([blk["mlp.gate_proj"], blk["mlp.up_proj"]], h2)                            # one launch
                 act = ops.silu_mul(g, u, out=g)
             else:
-                x = lin(blk["self_attn.o_proj"], self._prefill_attention(q, blk, S, start_pos), residual=x)
+                x = lin(blk["self_attn.o_proj"], self._prefill_attention(q, blk, S, start_pos, b), residual=x)
                 h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
                 g = lin(blk["mlp.gate_proj"], h2)
                 if S > 8:
@@ -323,7 +375,7 @@ class QuantLlama:
                 else:
                     act = ops.silu_mul(g, lin(blk["mlp.up_proj"], h2), out=g)
             x = lin(blk["mlp.down_proj"], act, residual=x)
-        return self._prefill_finish(x, S, start_pos)
+        return self._prefill_finish(x, S, start_pos, b)
 
     def _rows_linear(self, l, inp, residual=None):
         # y = inp . W^T (+ residual, in place) for many rows
@@ -360,9 +412,16 @@ class QuantLlama:
             ops.gemv_f16w(last[b], self.lm_head, gamma=self.norm, eps=self.eps, out=logits[b])
         return logits
 
-    def _prefill_attention(self, q, blk, S, start_pos=0):
+    def _cache_rows(self, blk, b=None):
+        """the [1, n_kv_heads, max_seq, 128] cache views of sequence b (None: the batch-1 runner's whole caches)"""
+        if b is None:
+            return blk["kc"], blk["vc"]
+        return blk["kc"][b:b + 1], blk["vc"][b:b + 1]
+
+    def _prefill_attention(self, q, blk, S, start_pos=0, b=None):
         """causal attention of the prompt rows: q [S, nh*128] rotated, K / V = cache rows 0 .. start_pos + S - 1 -> [S, nh*128]"""
-        return ops.attn_prefill(q, blk["kc"], blk["vc"], torch.empty_like(q), S, self.nh, self.nkv, batch=1, pos0=start_pos, kv_cache=True)
+        kc, vc = self._cache_rows(blk, b)
+        return ops.attn_prefill(q, kc, vc, torch.empty_like(q), S, self.nh, self.nkv, batch=1, pos0=start_pos, kv_cache=True)
 
     def _prefill_attention_sdpa(self, q, blk, S):
         """the same through the framework's SDPA (comparison point for tests / tools; not on the product path)"""
@@ -375,8 +434,11 @@ class QuantLlama:
         a = torch.nn.functional.scaled_dot_product_attention(qh[None], kh[None], vh[None], is_causal=True)[0]
         return a.transpose(0, 1).reshape(S, self.H).contiguous()
 
-    def _prefill_finish(self, x, S, start_pos=0):
+    def _prefill_finish(self, x, S, start_pos=0, b=None):
         last = x[S - 1].contiguous()
+        if b is not None:                       # one sequence of a batch: its logits row; the caller sets position and tokens
+            ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits[b])
+            return self.logits[b]
         ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         self.set_pos(start_pos + S)
         self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
@@ -417,15 +479,16 @@ class QuantLlama:
     def generate(self, ids, gen_len, use_graph=True):
         """greedy: prefill + gen_len tokens (min_new_tokens = max_new_tokens = gen_len,
         amq/utils/speed.py:34-39).  Returns the generated ids (device tensor)."""
-        if ids.numel() + gen_len > self.max_seq:
+        S = ids.shape[-1]
+        if S + gen_len > self.max_seq:
             raise ValueError("sequence does not fit the KV cache")
-        out = torch.empty(gen_len, dtype=torch.int64, device=self.dev)
+        out = torch.empty(self.B, gen_len, dtype=torch.int64, device=self.dev)
         self.prefill(ids)
-        out[0:1] = self.token
+        out[:, 0] = self.token
         for i in range(1, gen_len):
             self.decode_step(use_graph)
-            out[i:i + 1] = self.token
-        return out
+            out[:, i] = self.token
+        return out[0] if self.B == 1 else out
 
 
 class DenseLlama(QuantLlama):
@@ -433,10 +496,12 @@ class DenseLlama(QuantLlama):
     amq_speed_benchmark.py:171-197): plain library GEMMs (torch / hipBLASLt) for the seven
     linears, the same RMSNorm / attention / lm_head kernels around them."""
 
-    def __init__(self, config, device="cuda:0", max_seq=256, seed=0):
+    def __init__(self, config, device="cuda:0", max_seq=256, seed=0, batch=1):
         if isinstance(config, str):
             config = MODEL_CONFIGS[config]
-        # build the shared parts through the parent with a minimal (2-bit) arch, then drop the quantized linears
+        if not 1 <= int(batch) <= 8:
+            raise ValueError("batch must be 1..8")
+        self.B = int(batch)
         self._dense_init(config, device, max_seq, seed)
 
     def _dense_init(self, config, device, max_seq, seed):
@@ -459,16 +524,16 @@ class DenseLlama(QuantLlama):
                 blk[name] = (torch.randn(n, k, device=dev, generator=gen) * (0.5 / math.sqrt(k))).to(torch.float16)
             blk["ln1"] = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
             blk["ln2"] = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
-            blk["kc"] = torch.zeros(1, self.nkv, max_seq, 128, **f16)
-            blk["vc"] = torch.zeros(1, self.nkv, max_seq, 128, **f16)
+            blk["kc"] = torch.zeros(self.B, self.nkv, max_seq, 128, **f16)
+            blk["vc"] = torch.zeros(self.B, self.nkv, max_seq, 128, **f16)
             self.blocks.append(blk)
         self.embed = torch.randn(self.vocab, self.H, device=dev, generator=gen).to(torch.float16)
         self.lm_head = (torch.randn(self.vocab, self.H, device=dev, generator=gen) / math.sqrt(self.H)).to(torch.float16)
         self.norm = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
-        self.x = torch.zeros(1, self.H, **f16)
-        self.att = torch.zeros(1, self.H, **f16)
-        self.logits = torch.zeros(self.vocab, **f16)
-        self.token = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.x = torch.zeros(self.B, self.H, **f16)
+        self.att = torch.zeros(self.B, self.H, **f16)
+        self.logits = torch.zeros(self.vocab, **f16) if self.B == 1 else torch.zeros(self.B, self.vocab, **f16)
+        self.token = torch.zeros(self.B, dtype=torch.int64, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.rope_tab = ops.rope_table(max_seq, self.theta, dev)
         # step state: cos/sin row of self.pos + the position itself in one block (set_token / the step's tail keep it)
@@ -493,7 +558,8 @@ class DenseLlama(QuantLlama):
             h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             x = x + F.linear(F.silu(F.linear(h2, blk["mlp.gate_proj"])) * F.linear(h2, blk["mlp.up_proj"]),
                              blk["mlp.down_proj"])
-        ops.gemv_f16w(x.reshape(-1).contiguous(), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
+        ops.gemv_f16w(x.reshape(-1).contiguous() if self.B == 1 else x.contiguous(), self.lm_head, gamma=self.norm, eps=self.eps,
+                      out=self.logits)
         ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
 
     def _rows_linear(self, w, inp, residual=None):
@@ -504,7 +570,7 @@ class DenseLlama(QuantLlama):
     def _rows_up_gated(self, w, inp, gate):
         return ops.silu_mul(gate, torch.nn.functional.linear(inp, w), out=gate)
 
-    def _prefill_eager(self, ids, start_pos=0):
+    def _prefill_eager(self, ids, start_pos=0, b=None):
         F = torch.nn.functional
         S = ids.numel()
         if start_pos + S > self.max_seq:
@@ -514,12 +580,13 @@ class DenseLlama(QuantLlama):
         for blk in self.blocks:
             h = ops.rmsnorm(x, blk["ln1"], self.eps)
             q, k, v = F.linear(h, blk["self_attn.q_proj"]), F.linear(h, blk["self_attn.k_proj"]), F.linear(h, blk["self_attn.v_proj"])
-            ops.rope_cache(q, k, v, blk["kc"][0], blk["vc"][0], self.rope_tab, start_pos, nh, nkv)
-            x = torch.addmm(x, self._prefill_attention(q, blk, S, start_pos), blk["self_attn.o_proj"].t())
+            kc, vc = self._cache_rows(blk, b)
+            ops.rope_cache(q, k, v, kc[0], vc[0], self.rope_tab, start_pos, nh, nkv)
+            x = torch.addmm(x, self._prefill_attention(q, blk, S, start_pos, b), blk["self_attn.o_proj"].t())
             h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             g, u = F.linear(h2, blk["mlp.gate_proj"]), F.linear(h2, blk["mlp.up_proj"])
             x = torch.addmm(x, ops.silu_mul(g, u, out=g), blk["mlp.down_proj"].t())
-        return self._prefill_finish(x, S, start_pos)
+        return self._prefill_finish(x, S, start_pos, b)
 
 
 def get_memory_footprint(model):

@@ -75,6 +75,8 @@ class ModuleWalkLlama(nn.Module):
 
     def __init__(self, runner):
         super().__init__()
+        if getattr(runner, "B", 1) != 1:
+            raise ValueError("the module walk mirrors the reference's batch-1 step")
         self.r = runner
         self.layers = nn.ModuleList(_Block(blk, runner) for blk in runner.blocks)
         self.graph = None

@@ -357,6 +357,13 @@ def linear(x, qn, mn, bits, mode, N, K, bias=None):
 DEFAULT_GEMV_OPTS = None
 
 
+def gemv_max_rows(K):
+    """largest number of x rows the weight-streaming GEMV stages in LDS for this K (amq_query)"""
+    out = (ctypes.c_int * 4)()
+    _lib.load().amq_query(int(K), out, 4)
+    return int(out[0])
+
+
 def gemv_grouped(x, segments, K, prologue=PRO_NONE, x2=None, gamma=None, eps=0.0, opts=None):
     """One launch for several linears sharing x.
 
@@ -403,36 +410,52 @@ def rmsnorm(x, gamma, eps, out=None):
 
 
 def gemv_f16w(x, W, bias=None, gamma=None, eps=0.0, out=None):
-    """y[N] = (RMSNorm'ed if gamma) x[K] . W[N,K]^T, fp16 weights (lm_head)."""
+    """y[N] = (RMSNorm'ed if gamma) x[K] . W[N,K]^T, fp16 weights (lm_head).  x [M, K] with 2 <= M <= 8 (batched decode):
+    y [M, N], W streamed once for all rows."""
     N, K = W.shape
     _need(W, torch.float16, "W", N * K)
-    _need(x, torch.float16, "x", K)
+    M = x.shape[0] if x.dim() == 2 else 1
+    _need(x, torch.float16, "x", M * K)
     if gamma is not None:
         _need(gamma, torch.float16, "gamma", K)
     if bias is not None:
         _need(bias, torch.float16, "bias", N)
-    y = out if out is not None else torch.empty(N, dtype=torch.float16, device=x.device)
-    _need(y, torch.float16, "y", N)
-    _lib.check(_lib.load().amq_gemv_f16w(_lib.ptr(x), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(gamma),
-                                         ctypes.c_float(eps), N, K, _lib.current_stream()))
+    shape = (M, N) if x.dim() == 2 else (N,)
+    y = out if out is not None else torch.empty(shape, dtype=torch.float16, device=x.device)
+    _need(y, torch.float16, "y", M * N)
+    if M == 1:
+        _lib.check(_lib.load().amq_gemv_f16w(_lib.ptr(x), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(gamma),
+                                             ctypes.c_float(eps), N, K, _lib.current_stream()))
+    else:
+        if M > 8:
+            raise ValueError("at most 8 rows")
+        _lib.check(_lib.load().amq_gemv_f16w_rows(_lib.ptr(x), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(gamma),
+                                                  ctypes.c_float(eps), M, N, K, _lib.current_stream()))
     return y
 
 
 def decode_tail(logits, embed, token, pos, x, table=None, cur=None):
     """token = argmax(logits), pos += 1, x = embed[token] (and cur = table[pos], the next step's cos/sin row) -- one
-    launch (graph-capturable)"""
+    launch (graph-capturable).  Batched decode: logits [B, vocab], token [B], x [B, hidden]; pos / cur advance once."""
     vocab, hidden = embed.shape
-    _need(logits, torch.float16, "logits", vocab)
+    B = token.numel()
+    _need(logits, torch.float16, "logits", B * vocab)
     _need(embed, torch.float16, "embed", vocab * hidden)
-    _need(token, torch.int64, "token", 1)
+    _need(token, torch.int64, "token", B)
     _need(pos, torch.int32, "pos", 1)
-    _need(x, torch.float16, "x", hidden)
+    _need(x, torch.float16, "x", B * hidden)
     if cur is not None:
         _need(cur, torch.float16, "rope_cur", 128)
         _need(table, torch.float16, "rope table")
-    _lib.check(_lib.load().amq_decode_tail_f16(_lib.ptr(logits), vocab, _lib.ptr(embed), hidden, _lib.ptr(token), _lib.ptr(pos),
-                                               _lib.ptr(x), _lib.ptr(table) if cur is not None else None, _lib.ptr(cur),
-                                               table.numel() // 128 if cur is not None else 0, _lib.current_stream()))
+    tab = _lib.ptr(table) if cur is not None else None
+    rows = table.numel() // 128 if cur is not None else 0
+    if B == 1:
+        _lib.check(_lib.load().amq_decode_tail_f16(_lib.ptr(logits), vocab, _lib.ptr(embed), hidden, _lib.ptr(token), _lib.ptr(pos),
+                                                   _lib.ptr(x), tab, _lib.ptr(cur), rows, _lib.current_stream()))
+    else:
+        _lib.check(_lib.load().amq_decode_tail_batch_f16(_lib.ptr(logits), vocab, _lib.ptr(embed), hidden, _lib.ptr(token),
+                                                         _lib.ptr(pos), _lib.ptr(x), tab, _lib.ptr(cur), rows, B,
+                                                         _lib.current_stream()))
 
 
 def rope_cache(q, k, v, kcache, vcache, table, pos0, n_heads, n_kv_heads):

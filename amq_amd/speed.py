@@ -143,11 +143,11 @@ def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 1
     assert mode.lower() in ["tps", "gemv", "gemm", "ttft"], \
         "speed benchmark mode should be one of ['TPS', 'GeMV', 'GeMM', 'TTFT']"
     batch_size, input_seq_len, gen_seq_len = sizes
-    if batch_size != 1:
-        # the static KV cache is batch 1 (as in the reference's FT path, ftllama_modeling.py:61-68): batches are served
-        # for the prompt pass only (GeMM mode), which needs no cache
+    if batch_size != getattr(model, "B", 1):
+        # a runner built for another batch (the reference's FT path has a batch-1 cache, ftllama_modeling.py:61-68): the
+        # batched prompt pass (GeMM mode) needs no cache and is served anyway; token modes need QuantLlama(batch=batch_size)
         if mode.lower() != "gemm":
-            raise NotImplementedError("batch_size > 1 is supported in GeMM mode only (the static KV cache is batch 1)")
+            raise NotImplementedError(f"batch_size {batch_size} needs a runner built with batch={batch_size} (this one: {getattr(model, 'B', 1)})")
         if input_seq_len > model.max_seq:
             raise ValueError("sizes do not fit the model's RoPE table")
         return _benchmark_gemm_batch(model, sizes, iteration, get_peak_memory)
@@ -159,7 +159,9 @@ def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 1
         cleanup()
         torch.cuda.reset_peak_memory_stats(device=device)
         data["peak_memory"] = {}
-    input_ids = torch.randint(0, model.vocab - 1, (input_seq_len,), dtype=torch.long).to(device)   # speed.py:162
+    input_ids = torch.randint(0, model.vocab - 1, (batch_size, input_seq_len), dtype=torch.long).to(device)   # speed.py:162
+    if batch_size == 1:
+        input_ids = input_ids[0]
     device_warmup(device)
     cleanup()
     if get_peak_memory:
@@ -172,6 +174,8 @@ def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 1
         speed = benchmark_gemv_gemm(model, input_ids, gen_seq_len, iteration, mode)
     else:
         times = []
+        if batch_size != 1:
+            raise NotImplementedError("TTFT is a batch-1 measurement (as in the reference: one decoded text)")
         text = tokenizer.decode(input_ids) if tokenizer is not None else None        # speed.py:193
         for _ in range(iteration):
             cleanup()

@@ -79,6 +79,9 @@ def main(argv=None):
     gemm_iteration = 20
     gemv_iteration = 5 if args.gen_length < 1024 else 2          # amq_speed_benchmark.py:168-169
     max_seq = args.seq_length + args.gen_length + 8
+    # token modes at batch_size 2 .. 8 run a runner built for that batch (one step = the same launches with batch_size rows); larger
+    # batches are served in GeMM mode only, which needs no cache
+    run_batch = args.batch_size if 1 <= args.batch_size <= 8 and (args.tps or args.gemv) else 1
     result = {}
 
     def run(model, row):
@@ -93,7 +96,9 @@ def main(argv=None):
         if args.gemv:
             r = benchmark_speed(model, None, use_ft=args.use_ft, iteration=gemv_iteration, sizes=sizes, mode="GeMV", get_peak_memory=False)
             result[row].update(r); print("GeMV : ", r)
-        if args.ttft:
+        if args.ttft and args.batch_size != 1:
+            print("TTFT : skipped (a batch-1 measurement)")
+        elif args.ttft:
             r = benchmark_speed(model, tokenizer, use_ft=args.use_ft, iteration=gemm_iteration, sizes=sizes, mode="TTFT", get_peak_memory=False)
             result[row].update(r); print("TTFT : ", r)
         if args.memory:
@@ -102,7 +107,7 @@ def main(argv=None):
 
     if not args.skip_fp16:
         print("Get Speed of original model...")
-        base = DenseLlama(cfg, max_seq=max_seq)
+        base = DenseLlama(cfg, max_seq=max_seq, batch=run_batch)
         run(base, "fp16")
         del base
         cleanup()
@@ -124,9 +129,9 @@ def main(argv=None):
         missing = [ckpt_dir(b) for b in used if not os.path.isdir(ckpt_dir(b))]
         if missing:
             raise FileNotFoundError(f"the arch needs HQQ checkpoints that are not there: {missing}")
-        model = checkpoint.load_mixed({b: ckpt_dir(b) for b in used}, linear, max_seq=max_seq)
+        model = checkpoint.load_mixed({b: ckpt_dir(b) for b in used}, linear, max_seq=max_seq, batch=run_batch)
     else:
-        model = QuantLlama(cfg, linear, max_seq=max_seq)
+        model = QuantLlama(cfg, linear, max_seq=max_seq, batch=run_batch)
     run(model, f"{args.target_bits}bit")
     del model
     cleanup()

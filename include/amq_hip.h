@@ -187,6 +187,9 @@ int amq_rmsnorm_f16(const void* x, const void* gamma, void* y, int M, int K, flo
 /* y[N] = (optionally RMSNorm'ed) x[K] . W^T for fp16 W[N,K] (lm_head), K % 8 == 0; gamma NULL = no norm */
 int amq_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                   int N, int K, void* stream);
+/* the same for M = 1 .. 8 rows (batched decode): x fp16 [M, K], y fp16 [M, N], both contiguous; W is streamed once */
+int amq_gemv_f16w_rows(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps, int M,
+                       int N, int K, void* stream);
 /* one new token per sequence: RoPE(q, k) at position *pos_dev (or pos if pos_dev is NULL), append k/v to the
  * cache [B, n_kv_heads, max_seq, 128], out = softmax(q K^T / sqrt(128)) V.  head_dim must be 128.
  * Replaces FT single_query_attention (ft/attention/decoder_masked_multihead_attention.cu:30-61) with HF-Llama numerics. */
@@ -233,6 +236,10 @@ int amq_attn_decode_split_f16(const void* q, const void* k, const void* v, void*
  * a hipGraph.  logits, embed, x: fp16; token: int64; pos: int32; all device pointers. */
 int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
                         const void* rope_table, void* rope_cur, int rope_rows, void* stream);
+/* Batched decode (several sequences at the SAME position, one step state): logits fp16 [batch, vocab], token int64 [batch],
+ * x fp16 [batch, hidden]; pos / rope_cur are advanced once. */
+int amq_decode_tail_batch_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
+                              const void* rope_table, void* rope_cur, int rope_rows, int batch, void* stream);
 
 /* ---- many-row (prefill) glue --------------------------------------------------------------------------
  * The reference runs these steps as framework ops between the linears of a HF Llama block

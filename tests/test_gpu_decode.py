@@ -541,6 +541,70 @@ def test_prefill_in_chunks_matches_one_pass(gqa, split):
         m.prefill(ids, start_pos=20)                       # does not fit the cache
 
 
+@pytest.mark.parametrize("B,gqa", [(2, False), (4, True), (8, False)])
+def test_batched_decode_matches_single_sequence_runs(B, gqa):
+    """QuantLlama(batch=B): B sequences decoded together (one step = the same launches with B rows, weights streamed once) give
+    each sequence what a batch-1 runner gives it alone: same greedy tokens, logits to fp16 rounding (M = B rows go through the
+    general x staging of the GEMV kernel instead of the one-row register path); graph replay == eager; dense runner too."""
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama, DenseLlama
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 2 if gqa else 4, 1, vocab=1024))
+    ids = torch.randint(0, 1024, (B, 24), generator=torch.Generator().manual_seed(B)).to(_dev())
+    steps = 6
+    for dense in (False, True):
+        mk = (lambda b: DenseLlama(cfg, device="cuda:0", max_seq=48, seed=4, batch=b)) if dense else \
+             (lambda b: QuantLlama(cfg, None, device="cuda:0", max_seq=48, seed=4, batch=b))
+        mb = mk(B)
+        out_b = mb.generate(ids, steps, use_graph=False).clone()                 # [B, steps]
+        logits_b = mb.logits.float().clone()
+        assert out_b.shape == (B, steps) and int(mb.pos.item()) == 24 + steps - 1
+        m1 = mk(1)
+        for b in range(B):
+            m1.reset()
+            out_1 = m1.generate(ids[b], steps, use_graph=False)
+            ref = m1.logits.float()
+            assert (logits_b[b] - ref).abs().max() <= 1e-2 * ref.abs().max()
+            agree = (out_1 == out_b[b]).float().mean().item()
+            assert agree >= 0.8, (b, out_1.tolist(), out_b[b].tolist())         # (a near-tie may flip a greedy choice)
+        mb.reset()
+        out_g = mb.generate(ids, steps, use_graph=True)
+        assert torch.equal(out_g, out_b) and torch.equal(mb.logits.float(), logits_b)
+        mb.check()
+    with pytest.raises(ValueError):
+        mb.prefill(ids[:1])                                # wrong number of prompts
+
+
+def test_batched_lm_head_and_tail_kernels():
+    """amq_gemv_f16w_rows (lm_head for 2 .. 8 rows, W streamed once) row by row == the one-row kernel; amq_decode_tail_batch_f16:
+    per-row first-maximum argmax + embedding gather, the shared position advanced once"""
+    from amq_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    n, k = 1000, 1024
+    w = (torch.randn(n, k, generator=g) * 0.03).half().to(dev)
+    gamma = (1 + 0.1 * torch.randn(k, generator=g)).half().to(dev)
+    for M in (2, 3, 8):
+        x = torch.randn(M, k, generator=g).half().to(dev)
+        for gm in (None, gamma):
+            y = ops.gemv_f16w(x, w, gamma=gm, eps=1e-5)
+            assert y.shape == (M, n)
+            for m in range(M):
+                assert torch.equal(y[m], ops.gemv_f16w(x[m].contiguous(), w, gamma=gm, eps=1e-5))
+    vocab, hidden, B = 1024, 256, 5
+    embed = torch.randn(vocab, hidden, generator=g).half().to(dev)
+    logits = torch.randn(B, vocab, generator=g).half().to(dev)
+    logits[2, 100] = 9.0; logits[2, 700] = 9.0                      # tie: the first one wins
+    token = torch.zeros(B, dtype=torch.int64, device=dev)
+    tab = ops.rope_table(50, 10000.0, dev)
+    cur, pos, _err = ops.new_step_state(dev)
+    pos.fill_(41)
+    x = torch.zeros(B, hidden, dtype=torch.float16, device=dev)
+    ops.decode_tail(logits, embed, token, pos, x, table=tab, cur=cur)
+    assert torch.equal(token.cpu(), torch.argmax(logits.float().cpu(), dim=1)) and int(token[2]) == 100
+    assert int(pos.item()) == 42 and torch.equal(cur, tab.view(50, 128)[42])
+    assert torch.equal(x, embed[token])
+
+
 def test_speed_harness_gemm_mode_batched():
     from amq_amd import arch
     from amq_amd.llama import QuantLlama
