@@ -721,10 +721,11 @@ unsigned long long* g_stamp_ptr = nullptr;
 extern "C" int amq_debug_set_stamps(void* p) { g_stamp_ptr = (unsigned long long*)p; return 0; }
 #endif
 
-size_t gemv_lds_bytes(int M, int K, int /*copies: one staged x for every math mode*/) {
+// nw: waves per workgroup the launch will use (sizes the double-buffered cross-wave sum); <= 1: the largest (16), a safe bound
+size_t gemv_lds_bytes(int M, int K, int nw) {
     const size_t xbytes = (((size_t)M * (K + XPAD) * 2) + 15) & ~(size_t)15;
     const size_t xg = (size_t)(K >> 7) * 64;
-    const size_t red = (size_t)2 * 16 /*max NW*/ * 16 * 16 * 4;
+    const size_t red = (size_t)2 * (nw > 1 ? nw : 16) * 16 * 16 * 4;
     return xbytes + xg + red;
 }
 
@@ -786,7 +787,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_rt, a.K);
     // several rows (batched decode): the staged x grows with M, and once fewer than three 8-wave workgroups fit a CU's LDS one
     // 16-wave workgroup keeps more waves on the weight stream (7B, 8 sequences: 2.76 -> 2.15 ms a step; 4 sequences still fit three)
-    if (!a.force_waves && a.M > 1 && nw == 8 && 3 * gemv_lds_bytes(a.M, a.K, 1) > 160 * 1024) nw = 16;
+    if (!a.force_waves && a.M > 1 && nw == 8 && 3 * gemv_lds_bytes(a.M, a.K, 8) > 160 * 1024) nw = 16;
     // 4096 < K <= 8192 at one row (13B / 70B hidden sizes): 8-wave workgroups staging two x chunks per thread, two per CU
     // (~90 VGPRs), instead of one 16-wave workgroup -- 13B 464 -> 485 tokens/s, 70B 126.5 -> 133.  The same trade for
     // 8192 < K <= 16384 (four chunks per thread) loses (13B 484 -> 467; 7B's K = 11008 with three chunks 808 -> 773), as do
@@ -812,7 +813,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     }
     const bool lin = (a.flags & GEMV_FLAG_LINEAR) && !((a.flags & GEMV_FLAG_DOT) && a.M == 1);
     (void)lin; (void)mask;
-    const size_t lds = gemv_lds_bytes(a.M, a.K, 1);
+    const size_t lds = gemv_lds_bytes(a.M, a.K, a.M > 1 ? nw : 16);     // (one-row launches keep the allocation they were tuned with)
     GemvKArgs k{};
     k.x = a.x; k.x2 = a.x2; k.gamma = a.gamma;
     k.M = a.M; k.K = a.K; k.x_stride = a.x_stride; k.nseg = a.nseg;
