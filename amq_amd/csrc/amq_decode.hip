@@ -82,8 +82,10 @@ hipError_t launch_rmsnorm_xfrag(const void* x, const void* gamma, void* xf, int 
 // is the decode step's lm_head kernel unchanged.
 constexpr int F16W_WAVES = 4;
 
-template <bool NORM, int M>
-__global__ __launch_bounds__(F16W_WAVES * 64) void gemv_f16w_kernel(const _Float16* x, const _Float16* W, const _Float16* bias,
+// WV: waves per workgroup.  One row: 4 (many small workgroups per CU).  Several rows: the staged x (M * K halves) is what limits the
+// workgroups per CU, so 16 waves share one stage (8 rows of K = 4096: 2 x 16 waves per CU instead of 2 x 4: 96 -> us per launch below).
+template <bool NORM, int M, int WV>
+__global__ __launch_bounds__(WV * 64) void gemv_f16w_kernel(const _Float16* x, const _Float16* W, const _Float16* bias,
                                                                      _Float16* y, const _Float16* gamma, float eps, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* xl = (_Float16*)smem;                 // [M][K]
@@ -96,10 +98,10 @@ __global__ __launch_bounds__(F16W_WAVES * 64) void gemv_f16w_kernel(const _Float
         const _Float16* xm = x + (size_t)m * K;
         _Float16* xlm = xl + (size_t)m * K;
         if (!NORM) {
-            for (int c = tid; c < chunks; c += F16W_WAVES * 64) *(h8*)(xlm + 8 * c) = *(const h8*)(xm + 8 * c);
+            for (int c = tid; c < chunks; c += WV * 64) *(h8*)(xlm + 8 * c) = *(const h8*)(xm + 8 * c);
         } else {
             float ss = 0.f;
-            for (int c = tid; c < chunks; c += F16W_WAVES * 64) {
+            for (int c = tid; c < chunks; c += WV * 64) {
                 h8 v = *(const h8*)(xm + 8 * c);
                 *(h8*)(xlm + 8 * c) = v;
 #pragma unroll
@@ -111,9 +113,9 @@ __global__ __launch_bounds__(F16W_WAVES * 64) void gemv_f16w_kernel(const _Float
             __syncthreads();
             float tot = 0.f;
 #pragma unroll
-            for (int w = 0; w < F16W_WAVES; ++w) tot += red[w];
+            for (int w = 0; w < WV; ++w) tot += red[w];
             const float rstd = rsqrtf(tot / (float)K + eps);
-            for (int c = tid; c < chunks; c += F16W_WAVES * 64) {
+            for (int c = tid; c < chunks; c += WV * 64) {
                 h8 v = *(h8*)(xlm + 8 * c);
                 h8 g = *(const h8*)(gamma + 8 * c);
                 h8 r;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(F16W_WAVES * 64) void gemv_f16w_kernel(const _Float
         }
     }
     __syncthreads();
-    const int gw = blockIdx.x * F16W_WAVES + wave, nw = gridDim.x * F16W_WAVES;
+    const int gw = blockIdx.x * WV + wave, nw = gridDim.x * WV;
     const int steps = (K + 511) >> 9;               // 512 k per wave-load; lanes past K are masked (K % 8 == 0)
     for (int row = gw; row < N; row += nw) {
         const _Float16* wr = W + (size_t)row * K + 8 * lane;
@@ -168,12 +170,13 @@ template <bool NORM, int M>
 static hipError_t launch_gemv_f16w_m(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                                      int N, int K, hipStream_t st) {
     const size_t lds = (size_t)M * K * 2 + 64;
-    auto k = gemv_f16w_kernel<NORM, M>;
+    constexpr int WV = M == 1 ? F16W_WAVES : 16;
+    auto k = gemv_f16w_kernel<NORM, M, WV>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(1024), dim3(F16W_WAVES * 64), lds, st, (const _Float16*)x, (const _Float16*)W, (const _Float16*)bias,
+    hipLaunchKernelGGL(k, dim3(M == 1 ? 1024 : 512), dim3(WV * 64), lds, st, (const _Float16*)x, (const _Float16*)W, (const _Float16*)bias,
                        (_Float16*)y, (const _Float16*)gamma, eps, N, K);
     return hipGetLastError();
 }
