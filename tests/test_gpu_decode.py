@@ -574,6 +574,34 @@ def test_batched_decode_matches_single_sequence_runs(B, gqa):
         mb.prefill(ids[:1])                                # wrong number of prompts
 
 
+def test_batched_decode_long_cache_and_chunked_prompt():
+    """batch 3 over a cache long enough for the split attention kernel (several workgroups per head and sequence), the prompt fed in
+    two chunks: every sequence agrees with its own batch-1 run (whole prompt, single-workgroup attention forced)"""
+    from amq_amd import arch, ops
+    from amq_amd.llama import QuantLlama
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 2, 1, vocab=1024))
+    B, S, max_seq, steps = 3, 300, 640, 5
+    assert ops.attn_decode_splits(max_seq) > 1
+    ids = torch.randint(0, 1024, (B, S), generator=torch.Generator().manual_seed(5)).to(_dev())
+    mb = QuantLlama(cfg, None, device="cuda:0", max_seq=max_seq, seed=4, batch=B)
+    mb.prefill(ids[:, :200], use_graph=False)
+    mb.prefill(ids[:, 200:], use_graph=False, start_pos=200)
+    toks = [mb.token.clone()]
+    for _ in range(steps):
+        mb.decode_step()
+        toks.append(mb.token.clone())
+    got = torch.stack(toks, 1)                                   # [B, steps + 1]
+    logits_b = mb.logits.float().clone()
+    mb.check()
+    m1 = QuantLlama(cfg, None, device="cuda:0", max_seq=max_seq, seed=4)
+    for b in range(B):
+        m1.reset()
+        ref_t = m1.generate(ids[b], steps + 1, use_graph=False)
+        ref = m1.logits.float()
+        assert (logits_b[b] - ref).abs().max() <= 1e-2 * ref.abs().max()
+        assert (ref_t == got[b]).float().mean().item() >= 0.8
+
+
 def test_batched_lm_head_and_tail_kernels():
     """amq_gemv_f16w_rows (lm_head for 2 .. 8 rows, W streamed once) row by row == the one-row kernel; amq_decode_tail_batch_f16:
     per-row first-maximum argmax + embedding gather, the shared position advanced once"""
