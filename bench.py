@@ -53,13 +53,58 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 measured
 MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16
 
 
-def build_model(device, seed=0, max_seq=1024, model=MODEL, pinned=None):
+def build_model(device, seed=0, max_seq=1024, model=MODEL, pinned=None, batch=1):
     from amq_amd import arch
     from amq_amd.llama import QuantLlama
     cfg = arch.MODEL_CONFIGS[model]
     a, usage = arch.synthesize_arch(cfg, TARGET_BITS, seed=0, pinned=arch.PINNED_7B if pinned is None else pinned)
-    m = QuantLlama(cfg, a["linear"], device=device, max_seq=max_seq, seed=seed)
+    m = QuantLlama(cfg, a["linear"], device=device, max_seq=max_seq, seed=seed, batch=batch)
     return m, a, usage
+
+
+def beyond_the_metric(dev):
+    """Two figures next to the headline (NOT part of `value`; same workload and weights, rank 0 at N = 1 only): decode over a long
+    cache (2048 cached keys: the attention step split over several workgroups per head) and 8 sequences decoded together (one
+    pass over the weights per step).  Each is a short graph-replayed run; a failure is reported as a string, never raised."""
+    out = {}
+    try:
+        m, _, _ = build_model(dev, seed=0, max_seq=2048 + 64 + 16)
+        ids = torch.randint(0, m.vocab - 1, (2048,), generator=torch.Generator().manual_seed(0)).to(dev)
+        m.prefill(ids, use_graph=False)
+        m.capture()
+        for _ in range(8):
+            m.decode_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(48):
+            m.decode_step()
+        torch.cuda.synchronize(dev)
+        out["decode_tokens_per_s_at_2048_cached_keys"] = round(48 / (time.perf_counter() - t0), 1)
+        m.check()
+        del m
+        torch.cuda.empty_cache()
+    except Exception as e:      # noqa: BLE001
+        out["decode_tokens_per_s_at_2048_cached_keys"] = "failed: %r" % (e,)
+    try:
+        B = 8
+        m, _, _ = build_model(dev, seed=0, max_seq=PROMPT + 96, batch=B)
+        ids = torch.randint(0, m.vocab - 1, (B, PROMPT), generator=torch.Generator().manual_seed(0)).to(dev)
+        m.prefill(ids, use_graph=False)
+        m.capture()
+        for _ in range(8):
+            m.decode_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(64):
+            m.decode_step()
+        torch.cuda.synchronize(dev)
+        out["decode_tokens_per_s_8_sequences"] = round(B * 64 / (time.perf_counter() - t0), 1)
+        m.check()
+        del m
+        torch.cuda.empty_cache()
+    except Exception as e:      # noqa: BLE001
+        out["decode_tokens_per_s_8_sequences"] = "failed: %r" % (e,)
+    return out
 
 
 def _graph_time(dev, launches, reps):
@@ -217,6 +262,7 @@ def run_decode(args, rep, dev):
         del m
         torch.cuda.empty_cache()
         out["gemv_layers"] = gemv_layer_table(dev)
+        out["beyond_the_metric"] = beyond_the_metric(dev)
     if n_gpus == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline()
         out["cpu_baseline"] = {"value": cb["tokens_per_s_predequantized"], "unit": "tokens/s", "cores": cb["cores"],
