@@ -346,7 +346,9 @@ __device__ __forceinline__ void unpack_lane_sub(const uint32_t* w, h2* out) {
 }
 
 // ---------------------------------------------------------------- body
-template <int BITS, int MODE, int PRO, int NW, int U, int MATH, int XCH>
+// RS: floats per wave in the cross-wave sum buffer red[2][NW][RS]: 256 = 16 x-rows x 16 columns; 128 for launches of at most 8 rows
+// (several sequences decoded together), whose staged x is what limits the workgroups per CU
+template <int BITS, int MODE, int PRO, int NW, int U, int MATH, int XCH, int RS = 256>
 __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk, int sidx, const void* qweight, const void* meta_base,
                                           int seg_n_rt, int local, _Float16* lds_x, const _Float16* xl, float* xg,
                                           float* red, int xs, bool fastx, const XRegs& xr) {
@@ -449,23 +451,23 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     // end of a row-tile for this wave: publish partials, one barrier, fixed-order sum by the first M*16 threads
 #define AMQ_FINISH()                                                                             \
     do {                                                                                         \
-        float* rp_ = red + par * (NW * 16 * 16);                                                 \
+        float* rp_ = red + par * (NW * RS);                                                      \
         if (MATH == MATH_DOT) {                                                                  \
             float v_ = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);                                \
             v_ += __shfl_xor(v_, 16);                                                            \
             v_ += __shfl_xor(v_, 32);                                                            \
-            if (lane < 16) rp_[wave * 256 + lane] = v_;                                          \
+            if (lane < 16) rp_[wave * RS + lane] = v_;                                           \
             acc1[0] = acc1[1] = acc1[2] = acc1[3] = 0.f;                                         \
         } else {                                                                                 \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                     \
-                if (4 * o + i_ < a.M) rp_[wave * 256 + (4 * o + i_) * 16 + r] = accm[i_];        \
+                if (4 * o + i_ < a.M) rp_[wave * RS + (4 * o + i_) * 16 + r] = accm[i_];         \
             accm = (f4){0.f, 0.f, 0.f, 0.f};                                                     \
         }                                                                                        \
         __syncthreads();                                                                         \
         const int rt_ = rt0 + cj;                                                                \
         if (e_on) {                                           /* M * 16 <= 256 <= threads */     \
             float tot_ = 0.f;                                                                    \
-            _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) tot_ += rp_[w_ * 256 + threadIdx.x]; \
+            _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) tot_ += rp_[w_ * RS + threadIdx.x];  \
             _Float16 y_ = (_Float16)tot_;                     /* fp16(matmul) */                 \
             if (so.bias) y_ = y_ + pf_bias;                   /* out + bias      (fp16 add) */   \
             if (so.residual) y_ = pf_res + y_;                /* residual + out */               \
@@ -641,7 +643,7 @@ struct GemvPre {            // not a kernel parameter type: just names the 14 dw
     int K, m_nseg, rpt, n_rt0, key0; float eps;
 };
 
-template <int PRO, int NW, int U, int MATH, int XCH>
+template <int PRO, int NW, int U, int MATH, int XCH, int RS = 256>
 __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const void* p_x, const void* p_xw, const void* p_qw0,
                                                                      const void* p_mt0, int p_K, int p_m_nseg, int p_rpt,
                                                                      int p_n_rt0, int p_key0, float p_eps, GemvKArgs blk) {
@@ -703,12 +705,12 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const v
 
     const _Float16* xuse = xl;
     switch (key) {
-        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
     }
     if (threadIdx.x < 64) AMQ_STAMP_AT(blk, 4);
 #ifdef AMQ_STAMP
@@ -744,9 +746,9 @@ int gemv_pick_waves(int total_rt, int K) {
     return 8;
 }
 
-template <int PRO, int NW, int U, int MATH, int XCH = XCfg<NW>::XC>
+template <int PRO, int NW, int U, int MATH, int XCH = XCfg<NW>::XC, int RS = 256>
 static hipError_t launch_one(const GemvKArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    auto kern = gemv_kernel<PRO, NW, U, MATH, XCH>;
+    auto kern = gemv_kernel<PRO, NW, U, MATH, XCH, RS>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -766,6 +768,7 @@ static hipError_t launch_nw(const GemvKArgs& a, int flags, int depth, int total_
         return launch_one<PRO, NW, 2, MATH_LINEAR>(a, total_wg, lds, st);
     }
     if (u == 4) return launch_one<PRO, NW, 4, MATH_EXACT>(a, total_wg, lds, st);
+    if (NW == 8 && (flags & GEMV_FLAG_RS128)) return launch_one<PRO, 8, 2, MATH_EXACT, XCfg<8>::XC, 128>(a, total_wg, lds, st);
     if (NW == 16 && a.M == 1 && (a.K >> 3) > XCfg<16>::XC * 1024 && (a.K >> 3) <= 4 * 1024)
         return launch_one<PRO, 16, 2, MATH_EXACT, 4>(a, total_wg, lds, st);        // 16384 < K <= 32768 (70B down_proj)
     if (NW == 8 && a.M == 1 && (a.K >> 3) > 512 && (a.K >> 3) <= 1024)
@@ -787,7 +790,16 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_rt, a.K);
     // several rows (batched decode): the staged x grows with M, and once fewer than three 8-wave workgroups fit a CU's LDS one
     // 16-wave workgroup keeps more waves on the weight stream (7B, 8 sequences: 2.76 -> 2.15 ms a step; 4 sequences still fit three)
-    if (!a.force_waves && a.M > 1 && nw == 8 && 3 * gemv_lds_bytes(a.M, a.K, 8) > 160 * 1024) nw = 16;
+    // with at most 8 rows the cross-wave sum needs half its buffer (RS = 128): at 5 rows three 8-wave workgroups fit a CU again
+    // (7B: 2.20 -> 2.01 ms a step); TWO 8-wave workgroups (6 - 8 rows) measured slower than one 16-wave workgroup (2.28 / 2.34 vs
+    // 2.10 / 2.19 ms), so those keep the 16-wave form (profiles/r02_decode_batch.txt)
+    bool rs128 = false;
+    if (!a.force_waves && a.M > 1 && nw == 8) {
+        const bool plain = !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4;
+        const size_t lds128 = gemv_lds_bytes(a.M, a.K, 8) - 2 * 8 * 128 * 4;
+        if (plain && a.M <= 8 && 3 * lds128 <= 160 * 1024) rs128 = true;
+        else if (3 * gemv_lds_bytes(a.M, a.K, 8) > 160 * 1024) nw = 16;
+    }
     // 4096 < K <= 8192 at one row (13B / 70B hidden sizes): 8-wave workgroups staging two x chunks per thread, two per CU
     // (~90 VGPRs), instead of one 16-wave workgroup -- 13B 464 -> 485 tokens/s, 70B 126.5 -> 133.  The same trade for
     // 8192 < K <= 16384 (four chunks per thread) loses (13B 484 -> 467; 7B's K = 11008 with three chunks 808 -> 773), as do
@@ -813,7 +825,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     }
     const bool lin = (a.flags & GEMV_FLAG_LINEAR) && !((a.flags & GEMV_FLAG_DOT) && a.M == 1);
     (void)lin; (void)mask;
-    const size_t lds = gemv_lds_bytes(a.M, a.K, a.M > 1 ? nw : 16);     // (one-row launches keep the allocation they were tuned with)
+    const size_t lds = gemv_lds_bytes(a.M, a.K, a.M > 1 ? nw : 16) - (rs128 ? 2 * 8 * 128 * 4 : 0);     // (one-row launches keep the allocation they were tuned with)
     GemvKArgs k{};
     k.x = a.x; k.x2 = a.x2; k.gamma = a.gamma;
     k.M = a.M; k.K = a.K; k.x_stride = a.x_stride; k.nseg = a.nseg;
@@ -828,9 +840,9 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     k.stamps = g_stamp_ptr;
 #endif
     switch (a.prologue) {
-        case PRO_NONE: return launch_pro<PRO_NONE>(k, a.flags, a.force_depth, nw, wg, lds, st);
-        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(k, a.flags, a.force_depth, nw, wg, lds, st);
-        default: return launch_pro<PRO_SILU_MUL>(k, a.flags, a.force_depth, nw, wg, lds, st);
+        case PRO_NONE: return launch_pro<PRO_NONE>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0), a.force_depth, nw, wg, lds, st);
+        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0), a.force_depth, nw, wg, lds, st);
+        default: return launch_pro<PRO_SILU_MUL>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0), a.force_depth, nw, wg, lds, st);
     }
 }
 

@@ -41,7 +41,7 @@ struct GemvArgs {
     int force_depth;       // 0 = auto, else 2 / 4 tile loads in flight per wave
     int force_rpt;         // 0 = auto, else row-tiles per workgroup
 };
-enum { GEMV_FLAG_DOT = 1, GEMV_FLAG_LINEAR = 2 };
+enum { GEMV_FLAG_DOT = 1, GEMV_FLAG_LINEAR = 2, GEMV_FLAG_RS128 = 4 /* internal: half-size cross-wave sum buffer (<= 8 rows) */ };
 constexpr int GEMV_MAX_M = 16;
 
 size_t gemv_lds_bytes(int M, int K, int copies);
