@@ -26,9 +26,12 @@ int check_hip(hipError_t e, const char* what) {
 
 int check_shape(int bits, int N, int K, int group) {
     if (bits != 2 && bits != 3 && bits != 4) return fail(AMQ_EINVAL, "bits must be 2, 3 or 4 (got %d)", bits);
-    if (group != 128) return fail(AMQ_ESHAPE, "group size must be 128 (got %d)", group);
+    // 128, or a multiple of it that divides K: the repack entry points read such a source format and replicate each group's
+    // (scale, zero) into the native layout's per-128 pairs; the compute entry points work on the native layout either way
+    if (group < 128 || (group % 128) != 0) return fail(AMQ_ESHAPE, "group size must be a multiple of 128 (got %d)", group);
     if (N <= 0 || K <= 0 || (N % 16) != 0 || (K % 128) != 0)
         return fail(AMQ_ESHAPE, "need N %% 16 == 0 and K %% 128 == 0 (got N=%d K=%d)", N, K);
+    if ((K % group) != 0) return fail(AMQ_ESHAPE, "group size %d does not divide K=%d", group, K);
     return AMQ_OK;
 }
 
@@ -67,21 +70,21 @@ int amq_repack_from_hqq(int bits, const void* W_q, const void* scale, const void
                         void* qn, void* mn, void* stream) {
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (!W_q || !scale || !zero || !qn || !mn) return fail(AMQ_EINVAL, "null pointer");
-    return check_hip(amq::launch_repack(amq::FMT_HQQ, bits, W_q, scale, zero, N, K, qn, mn, (hipStream_t)stream), "repack_from_hqq");
+    return check_hip(amq::launch_repack(amq::FMT_HQQ, bits, W_q, scale, zero, N, K, qn, mn, (hipStream_t)stream, group), "repack_from_hqq");
 }
 
 int amq_repack_from_gptq(int bits, const void* qweight, const void* scales, const void* zeros, int N, int K, int group,
                          void* qn, void* mn, void* stream) {
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (!qweight || !scales || !zeros || !qn || !mn) return fail(AMQ_EINVAL, "null pointer");
-    return check_hip(amq::launch_repack(amq::FMT_GPTQ, bits, qweight, scales, zeros, N, K, qn, mn, (hipStream_t)stream), "repack_from_gptq");
+    return check_hip(amq::launch_repack(amq::FMT_GPTQ, bits, qweight, scales, zeros, N, K, qn, mn, (hipStream_t)stream, group), "repack_from_gptq");
 }
 
 int amq_repack_from_awq(const void* qweight, const void* scales, const void* scaled_zeros, int N, int K, int group,
                         void* qn, void* mn, void* stream) {
     if (int rc = check_shape(4, N, K, group)) return rc;
     if (!qweight || !scales || !scaled_zeros || !qn || !mn) return fail(AMQ_EINVAL, "null pointer");
-    return check_hip(amq::launch_repack(amq::FMT_AWQ, 4, qweight, scales, scaled_zeros, N, K, qn, mn, (hipStream_t)stream), "repack_from_awq");
+    return check_hip(amq::launch_repack(amq::FMT_AWQ, 4, qweight, scales, scaled_zeros, N, K, qn, mn, (hipStream_t)stream, group), "repack_from_awq");
 }
 
 int amq_dequantize_f16(int bits, int mode, const void* qn, const void* mn, int N, int K, int group, void* W, void* stream) {
@@ -95,7 +98,7 @@ int amq_dequantize_hqq_f16(int bits, const void* W_q, const void* scale, const v
                            void* W, void* stream) {
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (!W_q || !scale || !zero || !W) return fail(AMQ_EINVAL, "null pointer");
-    return check_hip(amq::launch_dequantize_hqq(bits, W_q, scale, zero, N, K, W, (hipStream_t)stream), "dequantize_hqq");
+    return check_hip(amq::launch_dequantize_hqq(bits, W_q, scale, zero, N, K, W, (hipStream_t)stream, group), "dequantize_hqq");
 }
 
 int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const void* x2, const void* gamma,

@@ -121,13 +121,13 @@ hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void
 
 // reference formats -> native
 hipError_t launch_repack(int fmt, int bits, const void* qsrc, const void* s_src, const void* z_src,
-                         int N, int K, void* q_native, void* meta_native, hipStream_t st);
+                         int N, int K, void* q_native, void* meta_native, hipStream_t st, int group = 128);   // group: the SOURCE format's
 hipError_t launch_accumulate_f32(void* mul, const void* y, size_t n, hipStream_t st);
 // native -> fp16 W[N,K]
 hipError_t launch_dequantize(int bits, int mode, const void* q_native, const void* meta_native,
                              int N, int K, void* w_out, hipStream_t st);
 // HQQ Format A -> fp16 W[N,K] directly (ATEN-style standalone dequant, f-4)
 hipError_t launch_dequantize_hqq(int bits, const void* wq, const void* scale, const void* zero,
-                                 int N, int K, void* w_out, hipStream_t st);
+                                 int N, int K, void* w_out, hipStream_t st, int group = 128);
 
 }  // namespace amq

@@ -17,24 +17,25 @@ namespace amq {
 // FMT_HQQ  (Format A, hqq/core/bitpack.py:24-110; axis=1 grouping quantize.py:106-111)
 // FMT_GPTQ (Format B, autogptq.py:121-156)
 // FMT_AWQ  (Format C, ft.py:15-55)
+// gs: the SOURCE format's group size (a multiple of 128 dividing K); the native layout always keeps one (scale, zero) per 128 k
 template <int FMT, int BITS>
-__device__ __forceinline__ uint32_t fetch_q(const void* src, int n, int k, int N, int K) {
+__device__ __forceinline__ uint32_t fetch_q(const void* src, int n, int k, int N, int K, int gs) {
     if (FMT == FMT_HQQ) {
-        const int G = K >> 7;
-        const int R = N * G;                 // rows of the [R,128] grouped view
-        const int row = n * G + (k >> 7);
-        const int col = k & 127;
+        const int G = K / gs;
+        const int R = N * G;                 // rows of the [R, gs] grouped view
+        const int row = n * G + k / gs;
+        const int col = k % gs;
         if (BITS == 4) {
             const int step = R >> 1;
-            const uint8_t b = ((const uint8_t*)src)[(size_t)(row % step) * 128 + col];
+            const uint8_t b = ((const uint8_t*)src)[(size_t)(row % step) * gs + col];
             return row < step ? (b >> 4) : (b & 15);
         } else if (BITS == 2) {
             const int step = R >> 2;
-            const uint8_t b = ((const uint8_t*)src)[(size_t)(row % step) * 128 + col];
+            const uint8_t b = ((const uint8_t*)src)[(size_t)(row % step) * gs + col];
             return (b >> (6 - 2 * (row / step))) & 3;
         } else {
             const int step = (R + 9) / 10;   // rows zero-padded to a multiple of 10
-            const uint32_t w = ((const uint32_t*)src)[(size_t)(row % step) * 128 + col];
+            const uint32_t w = ((const uint32_t*)src)[(size_t)(row % step) * gs + col];
             return (w >> (27 - 3 * (row / step))) & 7;
         }
     } else if (FMT == FMT_GPTQ) {
@@ -63,7 +64,7 @@ __device__ __forceinline__ uint32_t fetch_q(const void* src, int n, int k, int N
 
 template <int FMT, int BITS>
 __global__ __launch_bounds__(256) void repack_kernel(const void* qsrc, const void* s_src, const void* z_src,
-                                                     int N, int K, uint32_t* qn, h2* mn) {
+                                                     int N, int K, uint32_t* qn, h2* mn, int gs) {
     const int G = K >> 7;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t ntiles = (size_t)(N >> 4) * G;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void repack_kernel(const void* qsrc, const voi
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = g * 128 + 32 * t + 8 * o + j;
-            const uint32_t q = fetch_q<FMT, BITS>(qsrc, n, k, N, K);
+            const uint32_t q = fetch_q<FMT, BITS>(qsrc, n, k, N, K, gs);
             if (BITS == 3 && t == 3 && j >= 6) {
                 const int pos = (j & 1) ? 31 : 15;
                 w[0] |= (q & 1u) << pos;
@@ -98,16 +99,17 @@ __global__ __launch_bounds__(256) void repack_kernel(const void* qsrc, const voi
 
     if (o == 0) {   // one lane group also writes the (row, group) meta pair
         h2 m;
-        if (FMT == FMT_HQQ) {            // meta['scale'], meta['zero']: fp16 [N*K/G, 1]
-            const size_t row = (size_t)n * G + g;
+        const int gsrc = (g * 128) / gs;  // the source group this 128-k tile belongs to (its pair is replicated per tile)
+        if (FMT == FMT_HQQ) {            // meta['scale'], meta['zero']: fp16 [N*K/gs, 1]
+            const size_t row = (size_t)n * (K / gs) + gsrc;
             m.x = ((const _Float16*)s_src)[row];
             m.y = ((const _Float16*)z_src)[row];
-        } else if (FMT == FMT_GPTQ) {    // scales fp32 [K/G,N] = s ; zeros fp32 = fp16(z*s)
-            m.x = (_Float16)((const float*)s_src)[(size_t)g * N + n];
-            m.y = -(_Float16)((const float*)z_src)[(size_t)g * N + n];   // c = -zeros (auto_gptq_kernel.cu:200)
-        } else {                          // scales fp16 [K/G,N] ; scaled_zeros = -(z*s)
-            m.x = ((const _Float16*)s_src)[(size_t)g * N + n];
-            m.y = ((const _Float16*)z_src)[(size_t)g * N + n];
+        } else if (FMT == FMT_GPTQ) {    // scales fp32 [K/gs,N] = s ; zeros fp32 = fp16(z*s)
+            m.x = (_Float16)((const float*)s_src)[(size_t)gsrc * N + n];
+            m.y = -(_Float16)((const float*)z_src)[(size_t)gsrc * N + n];   // c = -zeros (auto_gptq_kernel.cu:200)
+        } else {                          // scales fp16 [K/gs,N] ; scaled_zeros = -(z*s)
+            m.x = ((const _Float16*)s_src)[(size_t)gsrc * N + n];
+            m.y = ((const _Float16*)z_src)[(size_t)gsrc * N + n];
         }
         mn[tile * 16 + r] = m;
     }
@@ -146,19 +148,20 @@ __global__ __launch_bounds__(256) void dequant_native_kernel(const uint32_t* qn,
 // instruction reads whole 128-byte lines and every store instruction writes 256 contiguous bytes per output row.
 template <int BITS>
 __global__ __launch_bounds__(256) void dequant_hqq_kernel(const void* wq, const _Float16* scale, const _Float16* zero,
-                                                          int R, _Float16* out) {
+                                                          int R, _Float16* out, int gs) {
     constexpr int C = BITS == 4 ? 2 : BITS == 2 ? 4 : 10;
     const int step = BITS == 3 ? (R + 9) / 10 : R / C;     // packed rows (3 bit: rows zero-padded to a multiple of 10)
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int i = (int)(gid >> 4), c8 = (int)(gid & 15) * 8;
+    const int tpr = gs >> 3;                               // threads per packed row of gs elements (gs = 128: 16)
+    const int i = (int)(gid / tpr), c8 = (int)(gid % tpr) * 8;
     if (i >= step) return;
     uint32_t q[8];                                         // the 8 packed elements, widened
     if (BITS == 3) {
-        const u4 a = *(const u4*)((const uint32_t*)wq + (size_t)i * 128 + c8);
-        const u4 b = *(const u4*)((const uint32_t*)wq + (size_t)i * 128 + c8 + 4);
+        const u4 a = *(const u4*)((const uint32_t*)wq + (size_t)i * gs + c8);
+        const u4 b = *(const u4*)((const uint32_t*)wq + (size_t)i * gs + c8 + 4);
         q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
     } else {
-        const u2 p = *(const u2*)((const uint8_t*)wq + (size_t)i * 128 + c8);
+        const u2 p = *(const u2*)((const uint8_t*)wq + (size_t)i * gs + c8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { q[e] = (p.x >> (8 * e)) & 0xFFu; q[4 + e] = (p.y >> (8 * e)) & 0xFFu; }
     }
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void dequant_hqq_kernel(const void* wq, const 
             const _Float16 d = f - z;                      // fp16 rounding #1
             v[e] = d * s;                                  // fp16 rounding #2
         }
-        *(h8*)(out + (size_t)row * 128 + c8) = v;
+        *(h8*)(out + (size_t)row * gs + c8) = v;
     }
 }
 
@@ -193,22 +196,22 @@ hipError_t launch_accumulate_f32(void* mul, const void* y, size_t n, hipStream_t
 
 template <int FMT>
 static hipError_t repack_bits(int bits, const void* q, const void* s, const void* z, int N, int K,
-                              void* qn, void* mn, hipStream_t st) {
+                              void* qn, void* mn, hipStream_t st, int gs) {
     const size_t threads = (size_t)(N >> 4) * (K >> 7) * 64;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
-    if (bits == 4) hipLaunchKernelGGL((repack_kernel<FMT, 4>), dim3(blocks), dim3(256), 0, st, q, s, z, N, K, (uint32_t*)qn, (h2*)mn);
-    else if (bits == 3) hipLaunchKernelGGL((repack_kernel<FMT, 3>), dim3(blocks), dim3(256), 0, st, q, s, z, N, K, (uint32_t*)qn, (h2*)mn);
-    else hipLaunchKernelGGL((repack_kernel<FMT, 2>), dim3(blocks), dim3(256), 0, st, q, s, z, N, K, (uint32_t*)qn, (h2*)mn);
+    if (bits == 4) hipLaunchKernelGGL((repack_kernel<FMT, 4>), dim3(blocks), dim3(256), 0, st, q, s, z, N, K, (uint32_t*)qn, (h2*)mn, gs);
+    else if (bits == 3) hipLaunchKernelGGL((repack_kernel<FMT, 3>), dim3(blocks), dim3(256), 0, st, q, s, z, N, K, (uint32_t*)qn, (h2*)mn, gs);
+    else hipLaunchKernelGGL((repack_kernel<FMT, 2>), dim3(blocks), dim3(256), 0, st, q, s, z, N, K, (uint32_t*)qn, (h2*)mn, gs);
     return hipGetLastError();
 }
 
 hipError_t launch_repack(int fmt, int bits, const void* q, const void* s, const void* z, int N, int K,
-                         void* qn, void* mn, hipStream_t st) {
-    if (fmt == FMT_HQQ) return repack_bits<FMT_HQQ>(bits, q, s, z, N, K, qn, mn, st);
-    if (fmt == FMT_GPTQ) return repack_bits<FMT_GPTQ>(bits, q, s, z, N, K, qn, mn, st);
+                         void* qn, void* mn, hipStream_t st, int gs) {
+    if (fmt == FMT_HQQ) return repack_bits<FMT_HQQ>(bits, q, s, z, N, K, qn, mn, st, gs);
+    if (fmt == FMT_GPTQ) return repack_bits<FMT_GPTQ>(bits, q, s, z, N, K, qn, mn, st, gs);
     const size_t threads = (size_t)(N >> 4) * (K >> 7) * 64;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
-    hipLaunchKernelGGL((repack_kernel<FMT_AWQ, 4>), dim3(blocks), dim3(256), 0, st, q, s, z, N, K, (uint32_t*)qn, (h2*)mn);
+    hipLaunchKernelGGL((repack_kernel<FMT_AWQ, 4>), dim3(blocks), dim3(256), 0, st, q, s, z, N, K, (uint32_t*)qn, (h2*)mn, gs);
     return hipGetLastError();
 }
 
@@ -224,13 +227,13 @@ hipError_t launch_dequantize(int bits, int mode, const void* qn, const void* mn,
 }
 
 hipError_t launch_dequantize_hqq(int bits, const void* wq, const void* scale, const void* zero, int N, int K,
-                                 void* w, hipStream_t st) {
-    const int R = (int)((size_t)N * K / 128);
+                                 void* w, hipStream_t st, int gs) {
+    const int R = (int)((size_t)N * K / gs);
     const int step = bits == 3 ? (R + 9) / 10 : bits == 4 ? R / 2 : R / 4;
-    const unsigned blocks = (unsigned)(((size_t)step * 16 + 255) / 256);
-    if (bits == 4) hipLaunchKernelGGL((dequant_hqq_kernel<4>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w);
-    else if (bits == 3) hipLaunchKernelGGL((dequant_hqq_kernel<3>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w);
-    else hipLaunchKernelGGL((dequant_hqq_kernel<2>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w);
+    const unsigned blocks = (unsigned)(((size_t)step * (gs >> 3) + 255) / 256);
+    if (bits == 4) hipLaunchKernelGGL((dequant_hqq_kernel<4>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w, gs);
+    else if (bits == 3) hipLaunchKernelGGL((dequant_hqq_kernel<3>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w, gs);
+    else hipLaunchKernelGGL((dequant_hqq_kernel<2>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w, gs);
     return hipGetLastError();
 }
 

@@ -71,8 +71,8 @@ def quantize_rtn(W: torch.Tensor, nbits: int, group_size: int = GROUP, bias=None
     (axis=1 grouping, inverted scale stored, fractional fp16 zero:
     quantize.py:106-155).  Not the HQQ optimizer -- accuracy is irrelevant to
     the speed path, only the format and value ranges matter."""
-    if group_size != GROUP:
-        raise ValueError("group size must be 128")
+    if group_size < GROUP or group_size % GROUP:
+        raise ValueError("group size must be a multiple of 128")
     n, k = W.shape
     wg = W.float().reshape(-1, group_size)
     mn = wg.min(dim=1, keepdim=True)[0]
@@ -87,16 +87,16 @@ def quantize_rtn(W: torch.Tensor, nbits: int, group_size: int = GROUP, bias=None
                       nbits, (n, k), group_size, bias, name)
 
 
-def random_hqq(n, k, nbits, seed=0, device="cpu", bias=False) -> HQQWeights:
+def random_hqq(n, k, nbits, seed=0, device="cpu", bias=False, group=GROUP) -> HQQWeights:
     """Synthetic layer of a given shape: random integers, scales ~2.7e-3*U(0.5,1.5),
     fractional zeros U(0, 2^b - 1) (values do not affect speed)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    r = n * k // GROUP
-    q = torch.randint(0, 2 ** nbits, (r, GROUP), generator=g, dtype=torch.int32)
+    r = n * k // group
+    q = torch.randint(0, 2 ** nbits, (r, group), generator=g, dtype=torch.int32)
     scale = ((torch.rand(r, 1, generator=g) + 0.5) * 2.7e-3 * (16.0 / 2 ** nbits)).to(torch.float16)
     zero = (torch.rand(r, 1, generator=g) * (2 ** nbits - 1)).to(torch.float16)
     b = (torch.randn(n, generator=g) * 0.1).to(torch.float16) if bias else None
-    return HQQWeights(pack_rows(q, nbits), scale, zero, nbits, (n, k), GROUP, b).to(device)
+    return HQQWeights(pack_rows(q, nbits), scale, zero, nbits, (n, k), group, b).to(device)
 
 
 def from_hqq_layer(layer) -> HQQWeights:
@@ -107,11 +107,11 @@ def from_hqq_layer(layer) -> HQQWeights:
         raise ValueError("only axis=1 HQQ layers are supported (AMQ uses axis=1)")
     if meta.get("view_as_float", False):
         raise ValueError("view_as_float HQQ payloads are not supported")
-    if meta["group_size"] != GROUP:
-        raise ValueError(f"group size must be 128 (got {meta['group_size']})")
+    if meta["group_size"] < GROUP or meta["group_size"] % GROUP:
+        raise ValueError(f"group size must be a multiple of 128 (got {meta['group_size']})")
     nbits = int(meta["nbits"])
     if nbits not in (2, 3, 4):
         raise NotImplementedError("Only 2,3,4 bits are supported.")
     W_q = layer.W_q.data if hasattr(layer.W_q, "data") else layer.W_q
     return HQQWeights(W_q, meta["scale"].to(torch.float16).reshape(-1, 1), meta["zero"].to(torch.float16).reshape(-1, 1),
-                      nbits, tuple(meta["shape"]), GROUP, getattr(layer, "bias", None), getattr(layer, "name", None))
+                      nbits, tuple(meta["shape"]), int(meta["group_size"]), getattr(layer, "bias", None), getattr(layer, "name", None))

@@ -97,7 +97,7 @@ class QuantLlama:
                 h: HQQWeights = hqq_layers[(block, name)].to(dev)
                 assert h.nbits == bits and tuple(h.shape) == (n, k)
                 qn, mn = ops.repack_from_hqq(h.W_q.contiguous(), h.scale.reshape(-1).contiguous(),
-                                             h.zero.reshape(-1).contiguous(), bits, n, k)
+                                             h.zero.reshape(-1).contiguous(), bits, n, k, group=h.group_size)
                 return _Lin(qn, mn, bits, ops.MODE_HQQ, n, k)
             if not synthetic:
                 raise ValueError("no weights given")

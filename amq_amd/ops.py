@@ -45,47 +45,59 @@ def _check_shape(bits, N, K):
         raise ValueError(f"need N % 16 == 0 and K % 128 == 0 (got N={N}, K={K})")
 
 
-def repack_from_hqq(W_q, scale, zero, bits, N, K):
+def _check_group(group, K):
+    """source-format group sizes the repack kernels read: 128 or a multiple of it that divides K (each group's (scale, zero) is
+    replicated into the native layout's per-128 pairs)"""
+    group = int(group)
+    if group < GROUP or group % GROUP or K % group:
+        raise ValueError(f"group size must be a multiple of {GROUP} that divides K={K} (got {group})")
+    return group
+
+
+def repack_from_hqq(W_q, scale, zero, bits, N, K, group=GROUP):
     """HQQLinear.W_q + meta['scale'|'zero'] -> (qweight_native, meta_native), MODE_HQQ."""
     _check_shape(bits, N, K)
+    group = _check_group(group, K)
     lib = _lib.load()
-    R = N * K // GROUP
+    R = N * K // group
     if bits == 3:
-        _need(W_q, torch.int32, "W_q", ((R + 9) // 10) * GROUP)
+        _need(W_q, torch.int32, "W_q", ((R + 9) // 10) * group)
     else:
-        _need(W_q, torch.uint8, "W_q", R * GROUP * bits // 8)
+        _need(W_q, torch.uint8, "W_q", R * group * bits // 8)
     _need(scale, torch.float16, "scale", R)
     _need(zero, torch.float16, "zero", R)
     qn, mn = alloc_native(bits, N, K, W_q.device)
-    _lib.check(lib.amq_repack_from_hqq(bits, _lib.ptr(W_q), _lib.ptr(scale), _lib.ptr(zero), N, K, GROUP,
+    _lib.check(lib.amq_repack_from_hqq(bits, _lib.ptr(W_q), _lib.ptr(scale), _lib.ptr(zero), N, K, group,
                                        _lib.ptr(qn), _lib.ptr(mn), _lib.current_stream()))
     return qn, mn
 
 
-def repack_from_gptq(qweight, scales, zeros, bits, N, K):
+def repack_from_gptq(qweight, scales, zeros, bits, N, K, group=GROUP):
     """GPTQLinear buffers -> native, MODE_FMA."""
     _check_shape(bits, N, K)
+    group = _check_group(group, K)
     lib = _lib.load()
     _need(qweight, torch.int32, "qweight", K // 32 * bits * N)
-    _need(scales, torch.float32, "scales", K // GROUP * N)
-    _need(zeros, torch.float32, "zeros", K // GROUP * N)
+    _need(scales, torch.float32, "scales", K // group * N)
+    _need(zeros, torch.float32, "zeros", K // group * N)
     qn, mn = alloc_native(bits, N, K, qweight.device)
-    _lib.check(lib.amq_repack_from_gptq(bits, _lib.ptr(qweight), _lib.ptr(scales), _lib.ptr(zeros), N, K, GROUP,
+    _lib.check(lib.amq_repack_from_gptq(bits, _lib.ptr(qweight), _lib.ptr(scales), _lib.ptr(zeros), N, K, group,
                                         _lib.ptr(qn), _lib.ptr(mn), _lib.current_stream()))
     return qn, mn
 
 
-def repack_from_awq(qweight, scales, scaled_zeros, N, K):
+def repack_from_awq(qweight, scales, scaled_zeros, N, K, group=GROUP):
     """FT_QuantLinear buffers (4 bit) -> native, MODE_FMA."""
     _check_shape(4, N, K)
+    group = _check_group(group, K)
     if N % 4 or K % 64:
         raise ValueError("AWQ pack needs N % 4 == 0 and K % 64 == 0")
     lib = _lib.load()
     _need(qweight, torch.int16, "qweight", N // 4 * K)
-    _need(scales, torch.float16, "scales", K // GROUP * N)
-    _need(scaled_zeros, torch.float16, "scaled_zeros", K // GROUP * N)
+    _need(scales, torch.float16, "scales", K // group * N)
+    _need(scaled_zeros, torch.float16, "scaled_zeros", K // group * N)
     qn, mn = alloc_native(4, N, K, qweight.device)
-    _lib.check(lib.amq_repack_from_awq(_lib.ptr(qweight), _lib.ptr(scales), _lib.ptr(scaled_zeros), N, K, GROUP,
+    _lib.check(lib.amq_repack_from_awq(_lib.ptr(qweight), _lib.ptr(scales), _lib.ptr(scaled_zeros), N, K, group,
                                        _lib.ptr(qn), _lib.ptr(mn), _lib.current_stream()))
     return qn, mn
 
@@ -107,17 +119,18 @@ def dequantize(qn, mn, bits, mode, N, K, out=None):
     return out
 
 
-def dequantize_hqq(W_q, scale, zero, bits, N, K):
+def dequantize_hqq(W_q, scale, zero, bits, N, K, group=GROUP):
     _check_shape(bits, N, K)
-    R = N * K // GROUP
+    group = _check_group(group, K)
+    R = N * K // group
     if bits == 3:
-        _need(W_q, torch.int32, "W_q", ((R + 9) // 10) * GROUP)
+        _need(W_q, torch.int32, "W_q", ((R + 9) // 10) * group)
     else:
-        _need(W_q, torch.uint8, "W_q", R * GROUP * bits // 8)
+        _need(W_q, torch.uint8, "W_q", R * group * bits // 8)
     _need(scale, torch.float16, "scale", R)
     _need(zero, torch.float16, "zero", R)
     out = torch.empty(N, K, dtype=torch.float16, device=W_q.device)
-    _lib.check(_lib.load().amq_dequantize_hqq_f16(bits, _lib.ptr(W_q), _lib.ptr(scale), _lib.ptr(zero), N, K, GROUP,
+    _lib.check(_lib.load().amq_dequantize_hqq_f16(bits, _lib.ptr(W_q), _lib.ptr(scale), _lib.ptr(zero), N, K, group,
                                                   _lib.ptr(out), _lib.current_stream()))
     return out
 

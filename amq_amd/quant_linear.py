@@ -30,8 +30,9 @@ class HIPQuantLinear(nn.Module):
         if bits not in [2, 3, 4]:
             raise NotImplementedError("Only 2,3,4 bits are supported.")     # autogptq.py:44-45
         group_size = group_size if group_size != -1 else infeatures
-        if group_size != GROUP:
-            raise NotImplementedError("Only group_size 128 is supported.")   # the only size AMQ produces
+        if group_size < GROUP or group_size % GROUP or infeatures % group_size:
+            # 128 is what AMQ produces; coarser groups are read and their (scale, zero) replicated per 128 (native layout)
+            raise NotImplementedError("group_size must be a multiple of 128 that divides infeatures.")
         if infeatures % 128 or outfeatures % 16:
             raise ValueError(f"need infeatures % 128 == 0 and outfeatures % 16 == 0 (got {infeatures}, {outfeatures})")
         assert weight_dtype == torch.float16, "Only fp16 is supported."      # ft.py:62
@@ -72,7 +73,7 @@ class HIPQuantLinear(nn.Module):
             raise RuntimeError("HIPQuantLinear.from_hqq needs a GPU device (repack runs as a HIP kernel)")
         mod = cls(h.nbits, h.group_size, k, n, bias=h.bias, name=h.name)
         qn, mn = ops.repack_from_hqq(h.W_q.to(dev).contiguous(), h.scale.to(dev).reshape(-1).contiguous(),
-                                     h.zero.to(dev).reshape(-1).contiguous(), h.nbits, n, k)
+                                     h.zero.to(dev).reshape(-1).contiguous(), h.nbits, n, k, group=h.group_size)
         mod._set_native(qn, mn, ops.MODE_HQQ)
         return mod
 
@@ -83,8 +84,9 @@ class HIPQuantLinear(nn.Module):
         w = fma(q, s, -zeros) (auto_gptq_kernel.cu:206)."""
         n = qweight.shape[1]
         k = qweight.shape[0] * 32 // bits
-        mod = cls(bits, GROUP, k, n, bias=bias, name=name, mode=ops.MODE_FMA)
-        qn, mn = ops.repack_from_gptq(qweight.contiguous(), scales.contiguous(), zeros.contiguous(), bits, n, k)
+        group = k // scales.shape[0]                       # scales [K / group, N]
+        mod = cls(bits, group, k, n, bias=bias, name=name, mode=ops.MODE_FMA)
+        qn, mn = ops.repack_from_gptq(qweight.contiguous(), scales.contiguous(), zeros.contiguous(), bits, n, k, group=group)
         mod._set_native(qn, mn, ops.MODE_FMA)
         return mod
 
@@ -94,8 +96,9 @@ class HIPQuantLinear(nn.Module):
         scales / scaled_zeros fp16 [K/G, N].  w = fma(q, s, scaled_zeros) (gemv_cuda.cu:151)."""
         k = qweight.shape[1]
         n = qweight.shape[0] * 4
-        mod = cls(4, GROUP, k, n, bias=bias, name=name, mode=ops.MODE_FMA)
-        qn, mn = ops.repack_from_awq(qweight.contiguous(), scales.contiguous(), scaled_zeros.contiguous(), n, k)
+        group = k // scales.shape[0]
+        mod = cls(4, group, k, n, bias=bias, name=name, mode=ops.MODE_FMA)
+        qn, mn = ops.repack_from_awq(qweight.contiguous(), scales.contiguous(), scaled_zeros.contiguous(), n, k, group=group)
         mod._set_native(qn, mn, ops.MODE_FMA)
         return mod
 
@@ -115,7 +118,7 @@ class HIPQuantLinear(nn.Module):
         intweight = torch.round((W + sz_rep) / s_rep).to(torch.int32).clamp_(0, self.maxq)
         W_q = pack_rows(intweight.reshape(-1, self.group_size), self.bits)
         qn, mn = ops.repack_from_hqq(W_q.contiguous(), scales.to(torch.float16).reshape(-1).contiguous(),
-                                     zeros.to(torch.float16).reshape(-1).contiguous(), self.bits, n, k)
+                                     zeros.to(torch.float16).reshape(-1).contiguous(), self.bits, n, k, group=self.group_size)
         self._set_native(qn, mn, ops.MODE_HQQ)
 
     def post_init(self):

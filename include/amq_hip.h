@@ -20,8 +20,11 @@
  *   - return value: AMQ_OK (0) or a negative AMQ_E* code; amq_last_error()
  *     returns a thread-local message for the most recent failure.
  *   - fp16 activations / outputs, fp32 accumulation; weights 2, 3 or 4 bit,
- *     group size 128 along K (the only configuration AMQ produces:
- *     amq/amq_quantization_proxy.py:22,36), N % 16 == 0, K % 128 == 0.
+ *     group size 128 along K (what AMQ produces: amq/amq_quantization_proxy.py:22,36) or a multiple of 128 that divides K: the
+ *     `group` argument of the amq_repack_from_* / amq_dequantize_hqq_f16 calls is the SOURCE format's group size (HQQ's packing
+ *     geometry depends on it); each group's (scale, zero) is replicated into the native layout's per-128 pairs, so the compute
+ *     entry points are the same kernels for every group size (their `group` argument is validated, not used).  Groups finer than
+ *     128 (64, 32) are not supported.  N % 16 == 0, K % 128 == 0.
  *   - "native" buffers are in the AMQ-T16 layout (amq_common.cuh);
  *     sizes from amq_native_*_bytes(); produced by the amq_repack_from_* calls.
  */
@@ -39,7 +42,7 @@ extern "C" {
 
 #define AMQ_OK            0
 #define AMQ_EINVAL       -1        /* bad argument (null pointer, bits, mode ...) */
-#define AMQ_ESHAPE       -2        /* unsupported shape (N % 16, K % 128, group != 128, M out of range) */
+#define AMQ_ESHAPE       -2        /* unsupported shape (N % 16, K % 128, group not a multiple of 128 dividing K, M out of range) */
 #define AMQ_ELAUNCH      -3        /* HIP launch failed (message carries hipGetErrorString) */
 #define AMQ_EUNSUPPORTED -4        /* valid request this build does not implement */
 

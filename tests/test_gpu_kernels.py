@@ -125,6 +125,72 @@ def _random_case(bits, n, k, seed, bias=False):
     return h, qn, mn, w_ref
 
 
+GCASES = sorted(glob.glob(os.path.join(GOLDEN, "hqq_g*_b*.npz")))
+
+
+@pytest.mark.parametrize("path", GCASES, ids=[os.path.basename(c) for c in GCASES])
+def test_group256_reference_golden(path):
+    """the reference's own group-256 layer (HQQ Format A payload and GPTQLinear buffers): native dequant == its W_deq bit for bit,
+    outputs vs its captured CPU results, GPTQ import == the reference kernels' fma dequant"""
+    from amq_amd import ops
+    g = _load(path)
+    bits, (n, k), G = int(g["nbits"]), tuple(int(v) for v in g["shape"]), int(g["group_size"])
+    qn, mn = ops.repack_from_hqq(_t(g["W_q"]), _t(g["scale"].reshape(-1)), _t(g["zero"].reshape(-1)), bits, n, k, group=G)
+    w = ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy()
+    assert np.array_equal(w.view(np.uint16), g["W_deq"].view(np.uint16))
+    w2 = ops.dequantize_hqq(_t(g["W_q"]), _t(g["scale"].reshape(-1)), _t(g["zero"].reshape(-1)), bits, n, k, group=G).cpu().numpy()
+    assert np.array_equal(w2.view(np.uint16), g["W_deq"].view(np.uint16))
+    _assert_close(ops.gemv(_t(g["x"]), qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy(), g["y_ref"], "gemv M=3, group 256")
+    _assert_close(ops.gemm(_t(g["gptq_x"]), qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy(),
+                  linear_ref.linear_f16(g["gptq_x"], g["W_deq"]), "gemm M=128, group 256")
+    qg, mg = ops.repack_from_gptq(_t(g["gptq_qweight"]), _t(g["gptq_scales"]), _t(g["gptq_zeros"]), bits, n, k, group=G)
+    wg = ops.dequantize(qg, mg, bits, ops.MODE_FMA, n, k).cpu().numpy()
+    assert np.array_equal(wg.view(np.uint16), gptq_ref.dequant_kernel(g["gptq_qweight"], g["gptq_scales"], g["gptq_zeros"], bits, G).view(np.uint16))
+    assert torch.equal(qg, qn)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k,group", [(64, 512, 256), (48, 1536, 512), (256, 1024, 1024), (32, 768, 384)])
+def test_coarser_groups_are_read_bit_exact(bits, n, k, group):
+    """source formats with a group size that is a multiple of 128 (HQQ Format A, whose packing geometry depends on it; GPTQ int32
+    and AWQ int16 with [K / group, N] metadata): repack -> native -> dequantize == the oracle's dequant of the same buffers, bit for
+    bit; the standalone HQQ dequant too; GEMV on them within the output tolerance; group 64 is refused."""
+    from amq_amd import ops
+    from amq_amd.hqq_format import random_hqq
+    from amq_amd.quant_linear import HIPQuantLinear
+    dev = _dev()
+    h = random_hqq(n, k, bits, seed=7 * bits + group, group=group)
+    w_ref = hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (n, k), group_size=group)
+    hd = h.to(dev)
+    qn, mn = ops.repack_from_hqq(hd.W_q, hd.scale.reshape(-1), hd.zero.reshape(-1), bits, n, k, group=group)
+    w = ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy()
+    assert np.array_equal(w.view(np.uint16), np.asarray(w_ref, np.float16).view(np.uint16))
+    w2 = ops.dequantize_hqq(hd.W_q, hd.scale.reshape(-1), hd.zero.reshape(-1), bits, n, k, group=group).cpu().numpy()
+    assert np.array_equal(w2.view(np.uint16), np.asarray(w_ref, np.float16).view(np.uint16))
+    x = torch.randn(2, k, generator=torch.Generator().manual_seed(1)).to(torch.float16)
+    mod = HIPQuantLinear.from_hqq(h, device=dev)
+    assert mod.group_size == group
+    _assert_close(mod(x.to(dev)).cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref), f"group {group}")
+    # GPTQ int32 buffers of the same layer (the reference's own pack from W_deq + meta), then through the module
+    s_ng = h.scale.numpy().reshape(n, k // group)
+    z_ng = h.zero.numpy().reshape(n, k // group)
+    qweight, scales, zeros = gptq_ref.pack(np.asarray(w_ref, np.float16), s_ng, z_ng, bits, group_size=group)
+    want = gptq_ref.dequant_kernel(qweight, scales, zeros, bits, group_size=group)        # [N, K] fp16, the kernels' fma arithmetic
+    m2 = HIPQuantLinear.from_gptq_buffers(torch.from_numpy(qweight).to(dev), torch.from_numpy(scales).to(dev),
+                                          torch.from_numpy(zeros).to(dev), bits)
+    assert m2.group_size == group
+    got = ops.dequantize(m2.qweight, m2.meta, bits, ops.MODE_FMA, n, k).cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), np.asarray(want, np.float16).view(np.uint16))
+    if bits == 4 and n % 4 == 0 and k % 64 == 0:
+        qw, sc, szr = awq_ref.pack(np.asarray(w_ref, np.float16), s_ng, z_ng, group_size=group)
+        want = awq_ref.dequant_kernel(qw, sc, szr, group_size=group)
+        m3 = HIPQuantLinear.from_ft_buffers(torch.from_numpy(qw).to(dev), torch.from_numpy(sc).to(dev), torch.from_numpy(szr).to(dev))
+        got = ops.dequantize(m3.qweight, m3.meta, 4, ops.MODE_FMA, n, k).cpu().numpy()
+        assert np.array_equal(got.view(np.uint16), np.asarray(want, np.float16).view(np.uint16))
+    with pytest.raises(ValueError):
+        ops.repack_from_hqq(hd.W_q, hd.scale.reshape(-1), hd.zero.reshape(-1), bits, n, k, group=64)
+
+
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("n,k", [(16, 128), (48, 384), (256, 1024), (1024, 4096), (4096, 11008)])
 def test_random_dequant_bit_exact(bits, n, k):

@@ -126,3 +126,32 @@ def test_awq_pack_bit_exact(path):
     wk = awq_ref.dequant_kernel(qweight, scales, szeros, 128).astype(np.float32)
     wd = g["W_deq"].astype(np.float32)
     assert np.max(np.abs(wk - wd)) <= 2.0 ** -9 * np.max(np.abs(wd))
+
+
+# ---- a group size other than 128 (256), captured from the real reference by tests/golden/gen_golden_groups.py
+GCASES = sorted(glob.glob(os.path.join(GOLDEN, "hqq_g*_b*.npz")))
+
+
+def test_group_fixture_inventory():
+    assert len(GCASES) == 3
+
+
+@pytest.mark.parametrize("path", GCASES, ids=[os.path.basename(c) for c in GCASES])
+def test_coarser_group_oracle_matches_reference(path):
+    """the oracle's group_size parameter against the reference at group 256: Format A dequant and pack / unpack bit-exact (the
+    packing geometry depends on the group), forward within one fp16 ulp, GPTQ pack bit-exact and its fallback forward"""
+    g = _load(path)
+    bits, (n, k), G = int(g["nbits"]), tuple(int(v) for v in g["shape"]), int(g["group_size"])
+    assert G == 256
+    w = hqq_ref.dequantize(g["W_q"], g["scale"], g["zero"], bits, (n, k), G)
+    assert np.array_equal(w.view(np.uint16), g["W_deq"].view(np.uint16))
+    q = hqq_ref.unpack(g["W_q"], bits, (n, k), G)
+    assert np.array_equal(hqq_ref.pack(q, bits, G), g["W_q"])
+    y = linear_ref.hqq_forward(g["x"], g["W_q"], g["scale"], g["zero"], bits, (n, k), G, None)
+    ref = g["y_ref"].astype(np.float32)
+    assert np.all(np.abs(y.astype(np.float32) - ref) <= 1e-3 * np.abs(ref) + 1e-4)
+    qweight, scales, zeros = gptq_ref.pack(g["W_deq"], g["scale"].reshape(n, -1), g["zero"].reshape(n, -1), bits, G)
+    assert np.array_equal(qweight, g["gptq_qweight"]) and np.array_equal(scales, g["gptq_scales"]) and np.array_equal(zeros, g["gptq_zeros"])
+    yf = gptq_ref.forward_fallback(g["gptq_x"], g["gptq_qweight"], g["gptq_scales"], g["gptq_zeros"], bits, G)
+    rf = g["gptq_y"].astype(np.float32)
+    assert np.all(np.abs(yf.astype(np.float32) - rf) <= 1e-3 * np.abs(rf) + 2e-4)
