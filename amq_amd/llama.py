@@ -408,8 +408,12 @@ class QuantLlama:
             x = lin(blk["mlp.down_proj"], act, residual=x)
         last = x.view(B, S, H)[:, S - 1].contiguous()
         logits = torch.empty(B, self.vocab, dtype=torch.float16, device=self.dev)
-        for b in range(B):
-            ops.gemv_f16w(last[b], self.lm_head, gamma=self.norm, eps=self.eps, out=logits[b])
+        for b0 in range(0, B, 8):                   # the lm_head is streamed once per 8 sequences
+            rows = slice(b0, min(B, b0 + 8))
+            if rows.stop - rows.start == 1:
+                ops.gemv_f16w(last[b0], self.lm_head, gamma=self.norm, eps=self.eps, out=logits[b0])
+            else:
+                ops.gemv_f16w(last[rows], self.lm_head, gamma=self.norm, eps=self.eps, out=logits[rows])
         return logits
 
     def _cache_rows(self, blk, b=None):
