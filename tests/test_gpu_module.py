@@ -192,3 +192,26 @@ def test_module_walk_decode_matches_runner():
     lin2 = copy.deepcopy(lin)                                    # amq_speed_benchmark.py:231 deep-copies the patched model
     assert lin2.qweight.data_ptr() != lin.qweight.data_ptr() and torch.equal(lin2(x), y)
     assert torch.equal(lin(x.reshape(1, 1, 512)).reshape(1, -1), y) and lin(x.float()).dtype == torch.float32
+
+
+@pytest.mark.parametrize("rows", [1, 5, 40])
+def test_module_accepts_bf16_and_fp32_inputs(rows):
+    """HIPQuantLinear.forward on non-fp16 inputs: cast to fp16, computed by the fp16 kernels, returned in the caller's dtype -- what
+    the reference modules do (autogptq.py:166-169 casts with a warning); there is no bf16 arithmetic path"""
+    import numpy as np
+    from amq_amd.hqq_format import random_hqq
+    from amq_amd.quant_linear import HIPQuantLinear
+    dev = torch.device("cuda:0")
+    h = random_hqq(256, 512, 3, seed=2, bias=True)
+    mod = HIPQuantLinear.from_hqq(h, device=dev)
+    x = torch.randn(rows, 512, generator=torch.Generator().manual_seed(rows))
+    y16 = mod(x.half().to(dev))
+    for dt in (torch.bfloat16, torch.float32):
+        xin = x.to(dt).to(dev)
+        y = mod(xin)
+        assert y.dtype == dt and y.shape == (rows, 256)
+        want = mod(xin.to(torch.float16)).to(dt)            # the documented semantics
+        assert torch.equal(y, want)
+    # bf16 rounding of the INPUT is the only difference from the fp16 call
+    yb = mod(x.to(torch.bfloat16).to(dev)).float()
+    assert (yb - y16.float()).abs().max() <= 2e-2 * y16.float().abs().max() + 1e-2
