@@ -47,17 +47,15 @@ constexpr int rg_lds(int bm) { return RG_NA * bm * 128 + 2 * RG_WSLOT + 2 * RG_M
 // LDS-DMA as inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in a kernel hipcc (ROCm 7.2) turns EVERY
 // ds_read wait into `s_waitcnt lgkmcnt(0)` (it books the DMA as a flat access that may return out of order with LDS
 // reads), which drains the operand look-ahead at every step; an asm DMA is invisible to that pass, the ds_read waits
-// stay counted, and the DMA's own completion is hand-counted anyway (vmcnt).  M0 (the LDS destination base) is
-// compiler-reserved: saved and restored inside the statement.  dst_ = wave-uniform LDS byte address.
-__device__ __forceinline__ void rg_glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+// stay counted, and the DMA's own completion is hand-counted anyway (vmcnt).  Source = 64-bit scalar base + 32-bit lane
+// offset (no 64-bit vector add per piece); M0 (the LDS destination, wave-uniform byte address) is set and LEFT: it is
+// compiler-reserved, but nothing the compiler emits for these kernels reads it (gfx9+ LDS instructions do not), and saving /
+// restoring it cost 2 scalar instructions per piece (hipcc warns about the clobber: -Wno-inline-asm for this file).
+__device__ __forceinline__ void rg_glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
-__device__ __forceinline__ void rg_glds4(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+__device__ __forceinline__ void rg_glds4(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 #ifdef AMQ_RING_ABL_NOBAR          /* timing-only ablation: results are wrong */
 #define RG_BARRIER() do { } while (0)
@@ -70,12 +68,6 @@ __device__ __forceinline__ void rg_glds4(const void* gsrc, unsigned lds_dst) {
         if constexpr (NXI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                    \
     } while (0)
-#define RG_GLDS(src_, dst_, size_)                                                                                   \
-    do {                                                                                                             \
-        const unsigned d_ = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(dst_) - (unsigned)(size_t)smem + lds0); \
-        if ((size_) == 16) rg_glds16((src_), d_); else rg_glds4((src_), d_);                                         \
-    } while (0)
-
 template <int BITS, int MODE, int BM>
 __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int ntm, int ntn) {
     constexpr int RG_BM = BM;
@@ -119,20 +111,25 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
     // ---- DMA sources
     // x: instruction i (0..31) of a half-tile fills rows 8i .. 8i+7 (128 B each); wave w issues i = w + 8j.
     // lane l -> row 8i + (l >> 3), LDS chunk position l & 7  <-  global chunk (l & 7) ^ ((row >> 1) & 7)
-    const _Float16* asrc[NXI];
+    // (every DMA source = wave-uniform 64-bit base in SGPRs + a 32-bit byte offset per lane: no 64-bit vector adds in the loop;
+    // gemm_ring_ok checks that x, the packed weights and the meta each span < 4 GiB)
+    unsigned aoff[NXI];
 #pragma unroll
     for (int j = 0; j < NXI; ++j) {
         const int row = 8 * (wave + 8 * j) + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         int m = m0 + row;
         m = m < a.M ? m : a.M - 1;                         // rows past M: computed, never stored
-        asrc[j] = (const _Float16*)a.x + (size_t)m * a.x_stride + chunk * 8;
+        aoff[j] = ((unsigned)m * (unsigned)a.x_stride + chunk * 8) * 2u;
     }
+    const unsigned char* const xbase = (const unsigned char*)a.x;
+    const unsigned char* const qbase = (const unsigned char*)a.qweight;
+    const unsigned char* const mbase = (const unsigned char*)a.meta;
     // packed W + meta of the wave's own column blocks (blocks past N are clamped: computed, never stored)
-    const unsigned char* wsrc[NWI];
+    unsigned woff[NWI];
     if (BITS == 2) {                                       // one instruction: lanes 0-31 tile cb0, lanes 32-63 tile cb0 + 1
         const int cb = min(cb0 + (lane >> 5), nblk_last);
-        wsrc[0] = (const unsigned char*)a.qweight + (size_t)cb * G * TB + (lane & 31) * 16;
+        woff[0] = (unsigned)cb * (unsigned)G * TB + (lane & 31) * 16;
     } else if (BITS == 3) {
         // two 768-byte tiles = 1536 contiguous LDS bytes, moved as raw bytes by two 16-byte-per-lane instructions (the
         // 12-byte form of the DMA does not lay lanes out 12 bytes apart): byte b = 1024 j + 16 lane of the image comes from
@@ -142,37 +139,33 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
             int b = 1024 * j + 16 * lane;
             b = b < 2 * TB ? b : b - 512;
             const int cb = min(cb0 + b / TB, nblk_last);
-            wsrc[j] = (const unsigned char*)a.qweight + (size_t)cb * G * TB + b % TB;
+            woff[j] = (unsigned)cb * (unsigned)G * TB + b % TB;
         }
     } else {
 #pragma unroll
         for (int nb = 0; nb < NWI; ++nb) {
             const int cb = min(cb0 + nb, nblk_last);
-            wsrc[nb] = (const unsigned char*)a.qweight + (size_t)cb * G * TB + lane * (4 * BITS);
+            woff[nb] = (unsigned)cb * (unsigned)G * TB + lane * (4 * BITS);
         }
     }
-    const unsigned char* msrc;
+    unsigned moff;
     {
         const int cb = min(cb0 + ((lane >> 4) & 1), nblk_last);
-        msrc = (const unsigned char*)a.meta + ((size_t)cb * G * 16 + r) * 4;
+        moff = ((unsigned)cb * (unsigned)G * 16 + r) * 4;
     }
+    const unsigned lds_a = lds0 + wave * 1024, lds_w = lds0 + RG_NA * RG_ABYTES + wave * WREG,
+                   lds_m = lds0 + RG_NA * RG_ABYTES + 2 * RG_WSLOT + wave * 256;
 
     auto issue_a = [&](int h, int slot) {                  // 4 DMA instructions
         const int hc = h < NH ? h : NH - 1;                // past the end: harmless re-read into a consumed slot (keeps the counts uniform)
-        unsigned char* dst = a_ring + slot * RG_ABYTES + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < NXI; ++j) RG_GLDS(asrc[j] + hc * 64, dst + j * 8192, 16);
+        for (int j = 0; j < NXI; ++j) rg_glds16(xbase + hc * 128, aoff[j], lds_a + slot * RG_ABYTES + j * 8192);
     };
     auto issue_w = [&](int g, int slot) {                  // NWI + 1 DMA instructions
         const int gc = g < G ? g : G - 1;
-        unsigned char* dst = w_ring + slot * RG_WSLOT + wave * WREG;
-        if (BITS == 2) {
-            RG_GLDS(wsrc[0] + (size_t)gc * TB, dst, 16);
-        } else {
 #pragma unroll
-            for (int nb = 0; nb < NWI; ++nb) RG_GLDS(wsrc[nb] + (size_t)gc * TB, dst + nb * 1024, 16);
-        }
-        RG_GLDS(msrc + (size_t)gc * 64, m_ring + slot * RG_MSLOT + wave * 256, 4);
+        for (int nb = 0; nb < NWI; ++nb) rg_glds16(qbase + (size_t)gc * TB, woff[nb], lds_w + slot * RG_WSLOT + nb * 1024);
+        rg_glds4(mbase + (size_t)gc * 64, moff, lds_m + slot * RG_MSLOT);
     };
 
     f4 acc[NRB][2];
@@ -233,8 +226,9 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
         const unsigned char* ab = a_ring + slot * RG_ABYTES;
         const int hc = dma_h < NH ? dma_h : NH - 1;         // past the end: harmless re-read into a consumed slot (keeps the counts uniform)
         const int gc = dma_g < G ? dma_g : G - 1;
-        unsigned char* const adst = a_ring + dma_slot * RG_ABYTES + wave * 1024;
-        unsigned char* const wdst = w_ring + dma_wslot * RG_WSLOT + wave * WREG;
+        const unsigned char* const xsrc = xbase + hc * 128;
+        const unsigned char* const qsrc = qbase + (size_t)gc * TB;
+        const unsigned adst = lds_a + dma_slot * RG_ABYTES, wdst = lds_w + dma_wslot * RG_WSLOT;
         h8 fx[RD][2];
         WPacked pk;
 #pragma unroll
@@ -257,15 +251,14 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
             }
 #endif
             if constexpr (rb < NDW) {                       // packed W first: it must have landed one half-tile before x(2g + 2) is needed
-                if constexpr (rb == NDW - 1) RG_GLDS(msrc + (size_t)gc * 64, m_ring + dma_wslot * RG_MSLOT + wave * 256, 4);
-                else if constexpr (BITS == 2) RG_GLDS(wsrc[0] + (size_t)gc * TB, wdst, 16);
-                else RG_GLDS(wsrc[rb] + (size_t)gc * TB, wdst + rb * 1024, 16);
+                if constexpr (rb == NDW - 1) rg_glds4(mbase + (size_t)gc * 64, moff, lds_m + dma_wslot * RG_MSLOT);
+                else rg_glds16(qsrc, woff[rb], wdst + rb * 1024);
             } else if constexpr (rb < NDW + NXI) {
                 constexpr int j = rb - NDW;
 #ifdef AMQ_RING_ABL_NOXDMA         /* timing-only ablation: the x image is never refreshed (a 4-byte DMA keeps the vmcnt counts) */
-                RG_GLDS(msrc + (size_t)gc * 64, m_ring + dma_wslot * RG_MSLOT + wave * 256, 4);
+                rg_glds4(mbase + (size_t)gc * 64, moff, lds_m + dma_wslot * RG_MSLOT);
 #else
-                RG_GLDS(asrc[j] + hc * 64, adst + j * 8192, 16);
+                rg_glds16(xsrc, aoff[j], adst + j * 8192);
 #endif
             }
 #ifdef AMQ_RING_PRIO
@@ -415,8 +408,12 @@ static hipError_t ring_launch(const GemmArgs& a, hipStream_t st, int bm) {
 }
 
 bool gemm_ring_ok(const GemmArgs& a) {
-    // 8-byte row-segment stores / residual loads need 4-element alignment of every row
-    return (a.y_stride & 3) == 0 && a.splits <= 1 && a.K >= 128;
+    // 8-byte row-segment stores / residual loads need 4-element alignment of every row; the DMA sources are addressed as
+    // scalar base + 32-bit lane offset, so x, the packed weights and the meta must each span < 4 GiB (else: the tiled kernel)
+    const unsigned long long lim = 1ull << 32;
+    const unsigned long long xspan = ((unsigned long long)(a.M - 1) * (unsigned long long)a.x_stride + (unsigned long long)a.K) * 2ull;
+    const unsigned long long wspan = (unsigned long long)a.N * (unsigned long long)a.K * (unsigned long long)a.bits / 8ull;
+    return (a.y_stride & 3) == 0 && a.splits <= 1 && a.K >= 128 && a.M >= 1 && xspan < lim && wspan < lim;
 }
 
 // Rows per tile (0: the launch is too small for this kernel).  All tiles of a launch cost the same, so a launch runs in
