@@ -57,6 +57,11 @@ def test_version_sizes_and_validation():
     assert rc == -1
     out = (ctypes.c_int * 4)()
     assert lib.amq_query(4096, out, 4) == 4 and out[0] >= 8 and out[2] == 16 and out[3] == 128
+    # the ring kernel addresses its LDS-DMA sources as scalar base + 32-bit lane offset: a launch whose x (or packed W) spans
+    # >= 4 GiB is not its launch (it goes to the tiled kernel, where a gate is an element-wise launch behind it) -- host logic
+    assert lib.amq_gemm_gated_fused(_lib.GEMM_RING if hasattr(_lib, "GEMM_RING") else 3, 32768, 13824, 5120, 0) == 1
+    assert lib.amq_gemm_gated_fused(3, 300000, 4096, 8192, 0) == 0          # x: 300000 x 8192 x 2 B = 4.9 GB
+    assert lib.amq_gemm_gated_fused(3, 200000, 4096, 8192, 0) == 1          # 3.3 GB
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
