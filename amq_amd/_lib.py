@@ -8,9 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# AMQ_LIB_TAG selects an A/B build variant (libamq_hip_<tag>.so, `make variant`); default: the product build
-_TAG = os.environ.get("AMQ_LIB_TAG", "")
-LIB_PATH = os.path.join(_HERE, f"libamq_hip_{_TAG}.so" if _TAG else "libamq_hip.so")
+# The product always loads THIS file.  A/B build variants (`make variant`) are loaded by tools/ only, through
+# ``use_library(path)`` called explicitly before the first ``load()`` -- no environment variable changes what the product runs.
+LIB_PATH = os.path.join(_HERE, "libamq_hip.so")
 
 AMQ_OK = 0
 MODE_HQQ, MODE_FMA = 0, 1
@@ -75,6 +75,7 @@ SIGNATURES = {
     "amq_decode_tail_batch_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "amq_attn_prefill_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 10 + [_vp]),
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "amq_rope_cache_batch_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_silu_mul_f16": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, ctypes.POINTER(GemvOpts), _vp]),
@@ -111,6 +112,14 @@ def load():
     return lib
 
 
+def use_library(path):
+    """tools/ only: load an A/B build variant instead of the product library.  Must be called before the first load()."""
+    global LIB_PATH
+    if _lib is not None:
+        raise AmqError("use_library() must be called before the library is first loaded")
+    LIB_PATH = os.path.abspath(path)
+
+
 def check(rc):
     if rc != AMQ_OK:
         msg = load().amq_last_error().decode("utf-8", "replace")
@@ -124,6 +133,16 @@ def current_stream():
         return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
     except AttributeError:                      # (older / newer torch without the private fast path)
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def stream_of(device):
+    """raw handle of torch's current HIP stream on ``device`` (a torch.device with an index, or an int)"""
+    import torch
+    idx = device if isinstance(device, int) else (device.index if device.index is not None else torch.cuda.current_device())
+    try:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+    except AttributeError:
+        return ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
 
 def ptr(t):

@@ -296,9 +296,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
 
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
     const int lds = 2 * 2 * AP_TILE;                    // 64 KiB
-    static hipError_t attr1 = hipFuncSetAttribute((const void*)attn_prefill_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    static hipError_t attr2 = hipFuncSetAttribute((const void*)attn_prefill_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static unsigned long long attr1_done = 0, attr2_done = 0;
+    const hipError_t attr1 = ensure_dyn_lds(attr1_done, (const void*)attn_prefill_kernel<1>, lds);
     if (attr1 != hipSuccess) return attr1;
+    const hipError_t attr2 = ensure_dyn_lds(attr2_done, (const void*)attn_prefill_kernel<2>, lds);
     if (attr2 != hipSuccess) return attr2;
     // 128-row workgroups (QB = 2: every K / V fragment read from LDS feeds two MFMAs, a staged tile serves twice the rows) once
     // they still fill the chip several times over (2 workgroups per CU = 512 in flight); 64-row workgroups otherwise.

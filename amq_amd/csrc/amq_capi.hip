@@ -296,6 +296,18 @@ int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void
                                             (hipStream_t)stream), "rope_cache");
 }
 
+int amq_rope_cache_batch_f16(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
+                             int rope_rows, int pos0, int S, int batch, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                             void* stream) {
+    if (!q || !k || !v || !kcache || !vcache || !rope_table) return fail(AMQ_EINVAL, "null pointer");
+    if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
+    if (S < 1 || batch < 1 || n_heads < 1 || n_kv_heads < 1 || rope_rows < 1) return fail(AMQ_ESHAPE, "bad sizes");
+    if (pos0 < 0 || pos0 + S > max_seq) return fail(AMQ_ESHAPE, "rows %d..%d do not fit the cache (max_seq %d)", pos0, pos0 + S, max_seq);
+    if ((long long)S * batch * (n_heads + n_kv_heads) > (1ll << 36)) return fail(AMQ_ESHAPE, "too many rows for one launch");
+    return check_hip(amq::launch_rope_cache(q, k, v, kcache, vcache, rope_table, rope_rows, pos0, S, n_heads, n_kv_heads, max_seq,
+                                            (hipStream_t)stream, batch), "rope_cache_batch");
+}
+
 int amq_rope_rows_f16(void* q, void* k, const void* rope_table, int rope_rows, int pos0, int rows, int seq_len, int n_heads,
                       int n_kv_heads, int head_dim, void* stream) {
     if (!q || !k || !rope_table) return fail(AMQ_EINVAL, "null pointer");

@@ -749,7 +749,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_
     if (tid < ATT_D) __hip_atomic_store(wsh + (size_t)z * ATT_WS_STRIDE + tid, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == ATT_D) __hip_atomic_store(wsh + (size_t)z * ATT_WS_STRIDE + ATT_D, gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == ATT_D + 1) __hip_atomic_store(wsh + (size_t)z * ATT_WS_STRIDE + ATT_D + 1, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the stores have completed (vmcnt) before the ticket is taken
+    // Publish protocol (cdna_hip_programming.md Guideline 16, R1): the payload stores above are agent-scope (sc1,
+    // write-through); EVERY storing wave (waves 0 .. 2 hold tid 0 .. 129) drains its own vector-memory queue before the
+    // workgroup barrier, and only then does ONE lane take the ticket.  A workgroup-scope fence emits no s_waitcnt on
+    // gfx950 -- the previous form let wave 0's ticket overtake the stores of waves 1 and 2 -- and the
+    // wait is inline asm so that the compiler's wait-count pass cannot drop it.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         int* const ticket = sp.tickets + (size_t)b * n_heads + h;
@@ -795,14 +800,17 @@ hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st
 // cache row pos0 + s, value heads are copied there.  Same fp16 expression and cos/sin table as the decode kernel's
 // rotate_and_append, so a prefilled cache row equals the row a decode step would have appended.
 // (eight threads per (row, head), 16-byte accesses: see rope_rows_kernel below)
+// Several sequences (rows = batch * seq_len, caches [batch][n_kv_heads][max_seq][128]): row s belongs to sequence s / seq_len
+// at position pos0 + s % seq_len.
 __global__ __launch_bounds__(256) void rope_cache_kernel(_Float16* q, const _Float16* k, const _Float16* v, _Float16* kc,
                                                          _Float16* vc, const h2* tab, int rope_rows, int pos0, int nh, int nkv,
-                                                         int max_seq, long units) {
+                                                         int max_seq, long units, int seq_len) {
     const long u = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
     if (u >= units) return;
     const int c = threadIdx.x & 7, nhk = nh + nkv;
     const int s = (int)(u / nhk), hx = (int)(u - (long)s * nhk);
-    const int pos = pos0 + s;
+    const int bseq = s / seq_len;
+    const int pos = pos0 + (s - bseq * seq_len);
     const h2* cs = tab + (size_t)(pos < rope_rows ? pos : rope_rows - 1) * 64 + 8 * c;
     const h8 cs0 = *(const h8*)cs, cs1 = *(const h8*)(cs + 4);
     const _Float16* src = hx < nh ? q + ((size_t)s * nh + hx) * ATT_D : k + ((size_t)s * nkv + (hx - nh)) * ATT_D;
@@ -821,7 +829,7 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(_Float16* q, const _Flo
     } else {
         const int h = hx - nh;
         const _Float16* vr = v + ((size_t)s * nkv + h) * ATT_D;
-        const size_t dst = ((size_t)h * max_seq + pos) * ATT_D;
+        const size_t dst = (((size_t)bseq * nkv + h) * max_seq + pos) * ATT_D;
         *(h8*)(kc + dst + 8 * c) = r0;
         *(h8*)(kc + dst + 64 + 8 * c) = r1;
         *(h8*)(vc + dst + 8 * c) = *(const h8*)(vr + 8 * c);
@@ -830,11 +838,11 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(_Float16* q, const _Flo
 }
 
 hipError_t launch_rope_cache(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
-                             int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int max_seq, hipStream_t st) {
-    const long units = (long)S * (n_heads + n_kv_heads);
+                             int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int max_seq, hipStream_t st, int batch) {
+    const long units = (long)S * batch * (n_heads + n_kv_heads);
     hipLaunchKernelGGL(rope_cache_kernel, dim3((unsigned)((units + 31) / 32)), dim3(256), 0, st, (_Float16*)q, (const _Float16*)k,
                        (const _Float16*)v, (_Float16*)kcache, (_Float16*)vcache, (const h2*)rope_table, rope_rows, pos0, n_heads,
-                       n_kv_heads, max_seq, units);
+                       n_kv_heads, max_seq, units, S);
     return hipGetLastError();
 }
 

@@ -389,7 +389,8 @@ static hipError_t skinny_grouped_launch(const void* xf, int M, int K, SkinnySegs
     auto k = gemm_skinny_grouped_kernel<NSUB>;
     constexpr int LDS = 8 * NSUB * 4096;
     if (LDS > 64 * 1024) {
-        static hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        static unsigned long long attr_done = 0;
+        const hipError_t attr = ensure_dyn_lds(attr_done, (const void*)k, LDS);
         if (attr != hipSuccess) return attr;
     }
     hipLaunchKernelGGL(k, dim3(total_wg, (M + 63) / 64), dim3(512), LDS, st, xf, M, K, sg);
@@ -426,7 +427,8 @@ static hipError_t skinny_launch_mb(const GemmArgs& a, hipStream_t st) {
     const int ny = (a.M + 16 * MB - 1) / (16 * MB);
     auto k = gemm_skinny_kernel<BITS, MODE, MB, 1, 2, NWV, false>;
     if (LDS > 64 * 1024) {
-        static hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        static unsigned long long attr_done = 0;
+        const hipError_t attr = ensure_dyn_lds(attr_done, (const void*)k, LDS);
         if (attr != hipSuccess) return attr;
     }
     hipLaunchKernelGGL(k, dim3(nblk, ny), dim3(NWV * 64), LDS, st, a);
@@ -450,7 +452,8 @@ static hipError_t skinny_launch_xf(const GemmArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((gemm_skinny_kernel<BITS, MODE, 4, 2, 2, 8, true>), dim3((nblk + 1) / 2, ny), dim3(512), 8 * 2 * 4096, st, a);
     } else {
         auto k = gemm_skinny_kernel<BITS, MODE, 4, 4, 2, 8, true>;
-        static hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
+        static unsigned long long attr_done = 0;
+        const hipError_t attr = ensure_dyn_lds(attr_done, (const void*)k, 8 * 4 * 4096);
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL(k, dim3((nblk + 3) / 4, ny), dim3(512), 8 * 4 * 4096, st, a);
     }

@@ -394,7 +394,8 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
 template <int BITS, int MODE, int BM>
 static hipError_t ring_launch_bm(const GemmArgs& a, hipStream_t st) {
     auto k = gemm_ring_kernel<BITS, MODE, BM>;
-    static hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds(BM));
+    static unsigned long long attr_done = 0;
+    const hipError_t attr = ensure_dyn_lds(attr_done, (const void*)k, rg_lds(BM));
     if (attr != hipSuccess) return attr;
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + RG_BN - 1) / RG_BN;
     hipLaunchKernelGGL(k, dim3(ntm * ntn), dim3(RG_THREADS), rg_lds(BM), st, a, ntm, ntn);

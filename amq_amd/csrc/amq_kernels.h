@@ -7,6 +7,20 @@
 
 namespace amq {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that launches on a second GPU
+// must set it there too, and a failed first call must not stay cached for the life of the process.  One bit per
+// (call site, device ordinal): set on success only.  A racing second thread at worst repeats the (idempotent) call.
+inline hipError_t ensure_dyn_lds(unsigned long long& done_mask, const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&done_mask, __ATOMIC_RELAXED) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELAXED);
+    return e;
+}
+
 enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILU_MUL = 2 };
 enum { FMT_HQQ = 0, FMT_GPTQ = 1, FMT_AWQ = 2 };
 constexpr int GEMV_MAX_SEG = 4;
@@ -110,7 +124,8 @@ struct AttnPrefillArgs {
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
 // prefill glue (amq_decode.hip)
 hipError_t launch_rope_cache(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
-                             int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int max_seq, hipStream_t st);
+                             int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int max_seq, hipStream_t st,
+                             int batch = 1);           // q / k / v rows = batch * S; caches [batch][n_kv_heads][max_seq][128]
 hipError_t launch_rope_rows(void* q, void* k, const void* rope_table, int rope_rows, int pos0, int rows, int seq_len, int n_heads,
                             int n_kv_heads, hipStream_t st);
 hipError_t launch_silu_mul(const void* gate, const void* up, void* out, long n, hipStream_t st);

@@ -290,30 +290,37 @@ class QuantLlama:
         """the prompt pass of every sequence (each into its own slice of the caches), then the shared position / next tokens"""
         if self.B == 1:
             return self._prefill_eager(ids[0], start_pos)
-        # several sequences: the linears see all B * S rows at once (one pass over the weights), RoPE / cache write and the
-        # causal attention run per sequence on its own slice of the caches
         B, S = ids.shape
-        H, nh, nkv = self.H, self.nh, self.nkv
-        x = self.embed.index_select(0, ids.reshape(-1))
-        lin = self._rows_linear
-        for blk in self.blocks:
-            h = ops.rmsnorm(x, blk["ln1"], self.eps)
-            q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
-            a = torch.empty_like(q)
-            for b in range(B):
-                rows = slice(b * S, (b + 1) * S)
-                kc, vc = self._cache_rows(blk, b)
-                ops.rope_cache(q[rows], k[rows], v[rows], kc[0], vc[0], self.rope_tab, start_pos, nh, nkv)
-                ops.attn_prefill(q[rows], kc, vc, a[rows], S, nh, nkv, batch=1, pos0=start_pos, kv_cache=True)
-            x = lin(blk["self_attn.o_proj"], a, residual=x)
-            h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
-            act = self._rows_up_gated(blk["mlp.up_proj"], h2, lin(blk["mlp.gate_proj"], h2))
-            x = lin(blk["mlp.down_proj"], act, residual=x)
-        last = x.view(B, S, H)[:, S - 1].contiguous()
+        last = self._rows_pass(ids, start_pos, cache=True)
         ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         self.set_pos(start_pos + S)
         self.set_token(torch.argmax(self.logits, dim=1))
         return self.logits
+
+    def _rows_pass(self, ids, start_pos, cache):
+        """ONE many-row pass over B prompts of S rows (ids [B, S]): the linears see all B * S rows at once (one pass over
+        the weights), RoPE and the causal attention run as ONE launch each over all sequences.  ``cache``: the rotated keys /
+        values are written into the runner's KV caches (rows start_pos .. start_pos + S - 1 of every sequence) and the
+        attention reads them there (a batched decode runner's prompt); otherwise q / k are rotated in place and the
+        attention reads the projection outputs (the harness' GeMM mode, no cache).  Returns the last rows [B, H]."""
+        B, S = ids.shape
+        H, nh, nkv = self.H, self.nh, self.nkv
+        x = self.embed.index_select(0, ids.reshape(-1).to(self.dev))
+        lin = self._rows_linear
+        for blk in self.blocks:
+            h = ops.rmsnorm(x, blk["ln1"], self.eps)
+            q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
+            if cache:
+                ops.rope_cache(q, k, v, blk["kc"], blk["vc"], self.rope_tab, start_pos, nh, nkv)
+                a = ops.attn_prefill(q, blk["kc"], blk["vc"], torch.empty_like(q), S, nh, nkv, batch=B, pos0=start_pos, kv_cache=True)
+            else:
+                ops.rope_rows(q, k, self.rope_tab, S, nh, nkv)
+                a = ops.attn_prefill(q, k, v, torch.empty_like(q), S, nh, nkv, batch=B)      # reads the projections in place
+            x = lin(blk["self_attn.o_proj"], a, residual=x)
+            h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
+            act = self._rows_up_gated(blk["mlp.up_proj"], h2, lin(blk["mlp.gate_proj"], h2))
+            x = lin(blk["mlp.down_proj"], act, residual=x)
+        return x.view(B, S, H)[:, S - 1].contiguous()
 
     # prompt rows (exclusive, inclusive) served by the fragment-ordered few-row kernels with q/k/v and gate/up as grouped
     # launches.  7B avg-3, ms per prompt pass, this path | the row-major / tiled kernels: 16 rows 2.91 | 2.55, 24 3.03 | 3.13,
@@ -393,20 +400,7 @@ class QuantLlama:
         B, S = ids.shape
         if S > self.max_seq:
             raise ValueError("prompt longer than the RoPE table")
-        H, nh, nkv, M = self.H, self.nh, self.nkv, B * S
-        x = self.embed.index_select(0, ids.reshape(-1).to(self.dev))
-
-        lin = self._rows_linear
-        for blk in self.blocks:
-            h = ops.rmsnorm(x, blk["ln1"], self.eps)
-            q, k, v = lin(blk["self_attn.q_proj"], h), lin(blk["self_attn.k_proj"], h), lin(blk["self_attn.v_proj"], h)
-            ops.rope_rows(q, k, self.rope_tab, S, nh, nkv)
-            a = ops.attn_prefill(q, k, v, torch.empty_like(q), S, nh, nkv, batch=B)      # reads the projections in place
-            x = lin(blk["self_attn.o_proj"], a, residual=x)
-            h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
-            act = self._rows_up_gated(blk["mlp.up_proj"], h2, lin(blk["mlp.gate_proj"], h2))
-            x = lin(blk["mlp.down_proj"], act, residual=x)
-        last = x.view(B, S, H)[:, S - 1].contiguous()
+        last = self._rows_pass(ids, 0, cache=False)
         logits = torch.empty(B, self.vocab, dtype=torch.float16, device=self.dev)
         for b0 in range(0, B, 8):                   # the lm_head is streamed once per 8 sequences
             rows = slice(b0, min(B, b0 + 8))

@@ -472,8 +472,25 @@ def decode_tail(logits, embed, token, pos, x, table=None, cur=None):
 
 
 def rope_cache(q, k, v, kcache, vcache, table, pos0, n_heads, n_kv_heads):
-    """Prefill glue for ONE sequence: rotate q [S, n_heads*128] in place, rotate k [S, n_kv_heads*128] into
-    kcache[h, pos0+s], copy v into vcache (both [n_kv_heads, max_seq, 128]); ``table`` from :func:`rope_table`."""
+    """Prefill glue: rotate q [S, n_heads*128] in place, rotate k [S, n_kv_heads*128] into kcache[h, pos0+s], copy v into
+    vcache (both [n_kv_heads, max_seq, 128]); ``table`` from :func:`rope_table`.
+    Caches [B, n_kv_heads, max_seq, 128] (4-D): q / k / v hold B sequences of S = rows / B rows each, one launch for all."""
+    if kcache.dim() == 4:
+        B = kcache.shape[0]
+        rows = q.shape[0]
+        if rows % B or kcache.shape[1] != n_kv_heads or kcache.shape[3] != 128 or vcache.shape != kcache.shape:
+            raise ValueError("caches must be [B, n_kv_heads, max_seq, 128] and q rows a multiple of B")
+        S = rows // B
+        _need(q, torch.float16, "q", rows * n_heads * 128)
+        _need(k, torch.float16, "k", rows * n_kv_heads * 128)
+        _need(v, torch.float16, "v", rows * n_kv_heads * 128)
+        _need(kcache, torch.float16, "kcache")
+        _need(vcache, torch.float16, "vcache")
+        _need(table, torch.float16, "rope table")
+        _lib.check(_lib.load().amq_rope_cache_batch_f16(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(kcache), _lib.ptr(vcache),
+                                                        _lib.ptr(table), table.numel() // 128, int(pos0), S, B, n_heads, n_kv_heads,
+                                                        128, kcache.shape[2], _lib.current_stream()))
+        return
     S = q.shape[0]
     _need(q, torch.float16, "q", S * n_heads * 128)
     _need(k, torch.float16, "k", S * n_kv_heads * 128)

@@ -159,11 +159,14 @@ class HIPQuantLinear(nn.Module):
             out = ops.linear(x, self.qweight, self.meta, self.bits, self.mode, N, K, bias=self.bias)
             return out if x_dtype == torch.float16 else out.to(x_dtype)
         # few rows (decode): one ctypes call, no per-call re-validation of the module's own buffers
+        if x.device != self.qweight.device:
+            raise ValueError(f"x is on {x.device} but the module's weights are on {self.qweight.device}")
         qp, mp, bp = self._buffer_ptrs()
         x2 = x if x.is_contiguous() else x.contiguous()
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float16, device=x.device)
+        # the stream of x's device (not of whatever device is current): the pointers above belong to that device
         rc = _lib.load().amq_linear_f16(self.bits, self.mode, x2.data_ptr(), qp, mp, bp, y.data_ptr(), M, N, K, GROUP,
-                                        _lib.current_stream())
+                                        _lib.stream_of(x.device))
         if rc != 0:
             _lib.check(rc)
         return y if x_dtype == torch.float16 else y.to(x_dtype)

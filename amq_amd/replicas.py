@@ -3,9 +3,8 @@ stream per process, no collective inside the token loop.  The only communication
 is a start/stop barrier and the max-over-ranks of the elapsed time (RCCL on
 GPUs -- backend "nccl" is RCCL on ROCm -- gloo on CPU for tests)."""
 import os
-import socket
 import subprocess
-import sys
+import tempfile
 import time
 
 import torch
@@ -13,23 +12,36 @@ import torch
 
 def launch_local(n, argv, env=None, timeout=None):
     """Start ``n`` ranks of ``argv`` (a full command line) as fresh child processes of THIS process, one per GPU:
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT are set per child, stdout / stderr are inherited (rank 0
+    RANK / LOCAL_RANK / WORLD_SIZE (and the rendezvous, below) are set per child, stdout / stderr are inherited (rank 0
     prints the result line).  The caller must not have touched the GPU: children are started with Popen, never by
     re-executing a process that holds a device context.  Returns the largest exit code; if one rank fails the others
-    are terminated by PID."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    are terminated by PID.
+    Rendezvous: a FILE store in a fresh private directory (AMQ_RENDEZVOUS_FILE, read by :class:`Replicas`) -- no TCP port is
+    picked here, so there is no window in which another process can take it between the probe and rank 0's bind."""
+    rdv_dir = tempfile.mkdtemp(prefix="amq_rdv_")
+    rdv = os.path.join(rdv_dir, "store")
     procs = []
     for r in range(n):
         e = dict(os.environ if env is None else env)
-        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
-                  "MASTER_PORT": str(port)})
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "AMQ_RENDEZVOUS_FILE": rdv})
+        e.setdefault("MASTER_ADDR", "127.0.0.1")
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen(list(argv), env=e))
     t_end = None if timeout is None else time.monotonic() + timeout
     rc, live = 0, list(procs)
+    try:
+        rc = _reap(live, t_end)
+    finally:
+        for f in (rdv, rdv_dir):
+            try:
+                (os.remove if f == rdv else os.rmdir)(f)
+            except OSError:
+                pass
+    return rc
+
+
+def _reap(live, t_end):
+    rc = 0
     while live:
         for p in list(live):
             code = p.poll()
@@ -44,6 +56,7 @@ def launch_local(n, argv, env=None, timeout=None):
             for q in live:
                 q.kill()
             rc = max(rc, 124)
+            t_end = None                           # killed once; keep polling until they are reaped
         time.sleep(0.05)
     return rc
 
@@ -62,8 +75,19 @@ class Replicas:
             if backend is None:
                 backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
             kw = {"device_id": device} if backend == "nccl" else {}
+            rdv = os.environ.get("AMQ_RENDEZVOUS_FILE")            # set by launch_local: file store, no TCP port involved
+            if rdv:
+                kw["init_method"] = "file://" + rdv
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
+
+    def live_world_size(self):
+        """ranks of the LIVE process group (1 without one) -- what the collectives below actually span"""
+        return 1 if self.dist is None else int(self.dist.get_world_size())
+
+    def live_backend(self):
+        """backend name of the live process group ("nccl" is RCCL on ROCm), or "none" """
+        return "none" if self.dist is None else str(self.dist.get_backend())
 
     def barrier(self):
         if self.dist is not None:

@@ -188,6 +188,66 @@ def gemv_layer_table(dev, iters=96):
     return rows
 
 
+def mfma_roofline(dev, seed=0):
+    """The batched path's roofline, driver-visible (north_star: "MFMA utilisation on the batched path against MI355X peak";
+    reference counterpart of the measurement: GeMM mode, amq/utils/speed.py:61-71,95-105): the 28 linears of 4 Llama-2-13B
+    blocks (synthesized avg-3-bit arch) at M = 16 x 2048 = 32768 rows -- BASELINE.json configs[3]'s row count -- through
+    ops.gemm (the product dispatch), timed with HIP events on the launch stream after one warm-up pass; next to it the opt-in
+    dequantize + library GEMM route on the same launches (comparison only)."""
+    from amq_amd import arch, ops
+    from amq_amd.llama import _synthetic_linear
+    cfg = arch.MODEL_CONFIGS["Llama-2-13b-hf"]
+    a, usage = arch.synthesize_arch(cfg, TARGET_BITS, seed=0, pinned=())
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    M, nblk = 16 * 2048, 4
+    lins = []
+    for b in range(nblk):
+        for name in cfg["linear"]:
+            n, k = cfg["linear_shape"][name]
+            lins.append(_synthetic_linear(n, k, arch.arch_bits(a["linear"], name, b), gen, dev))
+    xs = {k: torch.randn(M, k, device=dev, dtype=torch.float16) * 0.05 for k in {l.K for l in lins}}
+    ys = {n: torch.empty(M, n, device=dev, dtype=torch.float16) for n in {l.N for l in lins}}
+    flops = sum(2.0 * M * l.N * l.K for l in lins)
+
+    def linears():
+        for l in lins:
+            ops.gemm(xs[l.K], l.qn, l.mn, l.bits, l.mode, l.N, l.K, out=ys[l.N])
+
+    def timed():
+        linears()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        linears()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e-3
+
+    with torch.inference_mode():
+        t = timed()
+        ops.LIB_GEMM_ROWS = 1024
+        try:
+            t_lib = timed()
+        finally:
+            ops.LIB_GEMM_ROWS = 0
+    tf = flops / t / 1e12
+    return {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+            "traffic": None, "kernel": ops.gemm_route_name(M), "launches": len(lins), "ms": t * 1e3, "rows": M,
+            "workload": "the 28 linears of 4 Llama-2-13B blocks, avg-3-bit arch (bits_usage %.3f), M = 16 x 2048 rows "
+                        "(BASELINE.json configs[3]); HIP events on the launch stream" % usage,
+            "comparison_library_route_tflops": flops / t_lib / 1e12}
+
+
+def dequant_hqq_table(dev):
+    """f-4: the standalone HQQ Format A -> fp16 dequantize kernel on three layer shapes x 2/3/4 bit (tools/dequant_hqq_bench.py:
+    warm-up, rotating buffer sets, HIP events)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dequant_hqq_bench", os.path.join(ROOT, "tools", "dequant_hqq_bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.measure(dev)
+
+
 def cpu_baseline(seed=0):
     from amq_amd import arch
     from amq_amd.hqq_format import random_hqq
@@ -253,7 +313,13 @@ def run_decode(args, rep, dev):
                      "bytes_per_launch": roof["bytes_per_launch"], "us_per_launch": roof["us_per_launch"],
                      "launches_per_token": roof["launches_per_token"]},
         "finite_logits": ok,
-        "rccl_world_size": n_gpus,
+        # what "parity-green" means in tests/ (north_star: 1e-3 relative fp16 tolerance): element-wise
+        # |y - y_ref| <= 1e-3 |y_ref| + 1e-3 rms(y_ref) against the CPU nn.Linear-on-dequantized-weights oracle -- the rms term is
+        # a floor for outputs that cancel to ~0; dequantized weights and repacks are compared bit for bit
+        "parity_bar": "|y - y_ref| <= 1e-3*|y_ref| + 1e-3*rms(y_ref) vs CPU nn.Linear on oracle-dequantized weights; weights/repack bit-exact",
+        # read from the LIVE process group (not from the command line): what the barrier / all-reduce / all-gather spanned
+        "rccl_world_size": rep.live_world_size(),
+        "rccl_backend": rep.live_backend(),
         "per_rank_tokens_per_s": [round(v, 2) for v in per_rank],
         "linear_gb_per_token": m.linear_bytes_per_token() / 1e9,
         "model_gbps": m.total_bytes_per_token(PROMPT + args.warmup + args.steps // 2) / (elapsed / args.steps) / 1e9,
@@ -263,6 +329,17 @@ def run_decode(args, rep, dev):
         torch.cuda.empty_cache()
         out["gemv_layers"] = gemv_layer_table(dev)
         out["beyond_the_metric"] = beyond_the_metric(dev)
+    if n_gpus == 1 and not args.no_mfma:
+        try:
+            out["mfma_roofline"] = mfma_roofline(dev)
+        except Exception as e:      # noqa: BLE001  (an extra of the line: never costs the headline)
+            out["mfma_roofline"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            out["dequant_hqq"] = dequant_hqq_table(dev)
+        except Exception as e:      # noqa: BLE001
+            out["dequant_hqq"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     if n_gpus == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline()
         out["cpu_baseline"] = {"value": cb["tokens_per_s_predequantized"], "unit": "tokens/s", "cores": cb["cores"],
@@ -350,6 +427,7 @@ def main():
                     help="3 (default): BASELINE.json configs[2], the headline decode metric; 4: configs[3], GeMM mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer-table", action="store_true")
+    ap.add_argument("--no-mfma", action="store_true", help="skip the batched-path (MFMA) roofline and the dequantize rows")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 256 if args.config == 3 else 3

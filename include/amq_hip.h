@@ -315,6 +315,13 @@ int amq_attn_prefill_xfrag_f16(const void* q, const void* k, const void* v, void
  * rotation inside amq_attn_decode_f16. */
 int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
                        int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int head_dim, int max_seq, void* stream);
+/* The same for `batch` sequences of S rows each in one launch: q [batch*S, n_heads*128], k / v [batch*S, n_kv_heads*128],
+ * caches [batch, n_kv_heads, max_seq, 128]; row s belongs to sequence s / S at position pos0 + s % S.  (The prompt pass of a
+ * batched decode runner; counterpart of the per-sequence loop the reference's batch-1 FT cache forces,
+ * amq/kernel/monkeypatch/ftllama_modeling.py:61-68.) */
+int amq_rope_cache_batch_f16(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
+                             int rope_rows, int pos0, int S, int batch, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                             void* stream);
 /* RoPE in place on q [rows, n_heads*128] and k [rows, n_kv_heads*128] for rows = batch * seq_len (no cache write):
  * position of row s = pos0 + s % seq_len.  For the batched prompt pass of the harness' GeMM mode (amq/utils/speed.py:61-71
  * with batch_size > 1, BASELINE.json configs[3]). */

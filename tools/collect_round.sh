@@ -10,7 +10,7 @@ out=$PWD/gpurun_out/$R
 rm -rf $out; mkdir -p $out
 timeout -k 10 600 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1
 timeout -k 10 600 python3 bench.py --config 4 > $out/bench_config4.json 2> $out/bench_config4.err || exit 1
-BENCH="bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-layer-table"
+BENCH="bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-layer-table --no-mfma"
 cd /tmp && cd - > /dev/null
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $BENCH > $out/trace.log 2>&1 || exit 1
 CMD="tools/prof_decode.py 4"

@@ -1,6 +1,6 @@
 #!/bin/bash
-# usage: tools/mb_short.sh [microbench args]  -> compact per-shape table (us per launch under graph replay)
-timeout -k 10 300 python tools/microbench.py --iters 200 --gemm 0 "$@" 2>&1 | grep "^{" | python3 -c "
+# usage: [VARIANT=<tag>] tools/mb_short.sh [microbench args]  -> compact per-shape table (us per launch under graph replay)
+timeout -k 10 300 python tools/with_variant.py "${VARIANT-product}" tools/microbench.py --iters 200 --gemm 0 "$@" 2>&1 | grep "^{" | python3 -c "
 import sys, json
 rows = {}
 for l in sys.stdin:

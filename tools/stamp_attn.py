@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of the decode attention kernel (diagnostic build -DAMQ_STAMP).  usage: AMQ_LIB_TAG=stamp python tools/stamp_attn.py [pos]"""
+"""Phase timeline of the decode attention kernel (diagnostic build -DAMQ_STAMP).  usage: python tools/with_variant.py stamp tools/stamp_attn.py [pos]"""
 import ctypes, os, sys
 import numpy as np
 import torch

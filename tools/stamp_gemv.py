@@ -2,7 +2,7 @@
 """Per-workgroup phase timeline of one GEMV launch (diagnostic build only).
 
     make -C amq_amd/csrc variant TAG=stamp EXTRA=-DAMQ_STAMP
-    AMQ_LIB_TAG=stamp python tools/stamp_gemv.py N K bits [pro] -> gpurun_out/stamps_<N>x<K>_b<bits>.npz
+    python tools/with_variant.py stamp tools/stamp_gemv.py N K bits [pro] -> gpurun_out/stamps_<N>x<K>_b<bits>.npz
 
 Runs a rotation of launches over distinct weight buffers (cold weights), stamps the
 last few, and prints phase statistics in us relative to the earliest workgroup entry."""
