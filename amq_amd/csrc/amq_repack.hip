@@ -146,14 +146,9 @@ __global__ __launch_bounds__(256) void dequant_native_kernel(const uint32_t* qn,
 // A thread takes 8 consecutive columns of one packed row -- one 8-byte (32-byte for 3 bit) load, no per-element index
 // arithmetic -- and writes the C output rows' 8 halves as 16-byte stores; 16 threads cover a packed row, so every load
 // instruction reads whole 128-byte lines and every store instruction writes 256 contiguous bytes per output row.
-// SKEW (2 / 4 bit): a thread's C output rows lie exactly step * gs * 2 bytes apart; when that is a large power of two (4096 x 4096
-// at 2 bit: four store streams 8 MiB apart) the streams alias in the memory system and the launch runs 15x slower (144.8 us,
-// profiles/r02_dequant_hqq_bench.txt).  With a skew the thread takes chunk c from packed row (i + c * skew) mod step instead:
-// the same bytes are written, by other threads, and simultaneous stores no longer share their low address bits.  The packed row is
-// then loaded once per chunk (2-bit: 4 x 8 bytes per 64 bytes written, served by L2).
 template <int BITS>
 __global__ __launch_bounds__(256) void dequant_hqq_kernel(const void* wq, const _Float16* scale, const _Float16* zero,
-                                                          int R, _Float16* out, int gs, int skew) {
+                                                          int R, _Float16* out, int gs) {
     constexpr int C = BITS == 4 ? 2 : BITS == 2 ? 4 : 10;
     const int step = BITS == 3 ? (R + 9) / 10 : R / C;     // packed rows (3 bit: rows zero-padded to a multiple of 10)
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -165,22 +160,14 @@ __global__ __launch_bounds__(256) void dequant_hqq_kernel(const void* wq, const 
         const u4 a = *(const u4*)((const uint32_t*)wq + (size_t)i * gs + c8);
         const u4 b = *(const u4*)((const uint32_t*)wq + (size_t)i * gs + c8 + 4);
         q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
-    } else if (!skew) {
+    } else {
         const u2 p = *(const u2*)((const uint8_t*)wq + (size_t)i * gs + c8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { q[e] = (p.x >> (8 * e)) & 0xFFu; q[4 + e] = (p.y >> (8 * e)) & 0xFFu; }
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        int ic = i;
-        if (BITS != 3 && skew) {
-            ic = i + c * skew;
-            ic = ic >= step ? ic - step : ic;              // c * skew < step (launcher)
-            const u2 p = *(const u2*)((const uint8_t*)wq + (size_t)ic * gs + c8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { q[e] = (p.x >> (8 * e)) & 0xFFu; q[4 + e] = (p.y >> (8 * e)) & 0xFFu; }
-        }
-        const int row = c * step + ic;
+        const int row = c * step + i;
         if (BITS == 3 && row >= R) continue;               // padding rows of the last chunks
         const _Float16 s = scale[row], z = zero[row];
         constexpr int width = BITS == 3 ? 3 : BITS;
@@ -239,28 +226,14 @@ hipError_t launch_dequantize(int bits, int mode, const void* qn, const void* mn,
     return hipGetLastError();
 }
 
-#ifdef AMQ_DEQ_SKEW          /* A/B builds: -DAMQ_DEQ_SKEW=0 turns the skew off */
-static int g_dequant_hqq_skew = AMQ_DEQ_SKEW;
-#else
-static int g_dequant_hqq_skew = -1;     // by shape
-#endif
-
 hipError_t launch_dequantize_hqq(int bits, const void* wq, const void* scale, const void* zero, int N, int K,
                                  void* w, hipStream_t st, int gs) {
     const int R = (int)((size_t)N * K / gs);
     const int step = bits == 3 ? (R + 9) / 10 : bits == 4 ? R / 2 : R / 4;
     const unsigned blocks = (unsigned)(((size_t)step * (gs >> 3) + 255) / 256);
-    // store streams of one thread lie step * gs * 2 bytes apart: skew them when that distance is a multiple of 1 MiB
-    // (see the kernel).  skew = an odd number of packed rows near step / (2 C): C * skew < step always.
-    int skew = g_dequant_hqq_skew;
-    if (skew < 0) {
-        const size_t dist = (size_t)step * gs * 2;
-        const int C = bits == 4 ? 2 : 4;
-        skew = (bits != 3 && (dist & ((1u << 20) - 1)) == 0 && step >= 64) ? ((step / (2 * C)) | 1) : 0;
-    }
-    if (bits == 4) hipLaunchKernelGGL((dequant_hqq_kernel<4>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w, gs, skew);
-    else if (bits == 3) hipLaunchKernelGGL((dequant_hqq_kernel<3>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w, gs, 0);
-    else hipLaunchKernelGGL((dequant_hqq_kernel<2>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w, gs, skew);
+    if (bits == 4) hipLaunchKernelGGL((dequant_hqq_kernel<4>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w, gs);
+    else if (bits == 3) hipLaunchKernelGGL((dequant_hqq_kernel<3>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w, gs);
+    else hipLaunchKernelGGL((dequant_hqq_kernel<2>), dim3(blocks), dim3(256), 0, st, wq, (const _Float16*)scale, (const _Float16*)zero, R, (_Float16*)w, gs);
     return hipGetLastError();
 }
 
