@@ -28,6 +28,16 @@ class Segment(ctypes.Structure):
                 ("y", _vp), ("N", _i), ("bits", _i), ("mode", _i), ("y_stride", _i)]
 
 
+class EngineLinear(ctypes.Structure):
+    """mirror of `amq_engine_linear` (include/amq_hip.h)"""
+    _fields_ = [("qweight_native", _vp), ("meta_native", _vp), ("N", _i), ("bits", _i), ("mode", _i), ("reserved", _i)]
+
+
+class EngineBlock(ctypes.Structure):
+    """mirror of `amq_engine_block`: lin = q, k, v, o, gate, up, down"""
+    _fields_ = [("lin", EngineLinear * 7), ("ln1", _vp), ("ln2", _vp), ("kcache", _vp), ("vcache", _vp)]
+
+
 class GemvOpts(ctypes.Structure):
     """mirror of `amq_gemv_opts` (include/amq_hip.h): per-call launch options, all zero = defaults"""
     _fields_ = [("math", _i), ("waves", _i), ("depth", _i), ("rpt", _i), ("dot", _i)]
@@ -76,6 +86,11 @@ SIGNATURES = {
     "amq_attn_prefill_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 10 + [_vp]),
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_cache_batch_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "amq_decode_engine_image_bytes": (_sz, [_i]),
+    "amq_decode_engine_scratch_bytes": (_sz, [_i, _i, _i]),
+    "amq_decode_engine_sync_bytes": (_sz, []),
+    "amq_decode_engine_image": (_i, [ctypes.POINTER(EngineBlock), _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "amq_decode_engine_f16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp, _vp, _sz, _i, _vp]),
     "amq_rope_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_silu_mul_f16": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, ctypes.POINTER(GemvOpts), _vp]),

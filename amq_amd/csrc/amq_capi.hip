@@ -6,6 +6,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <vector>
 
 namespace {
 
@@ -283,6 +284,75 @@ int amq_gemm_xfrag_grouped_f16(const amq_segment* segs, int nseg, const void* xf
         d.y_stride = s.y_stride ? s.y_stride : s.N;
     }
     return check_hip(amq::launch_gemm_xfrag_grouped(xf, M, K, gs, nseg, (hipStream_t)stream), "gemm_xfrag_grouped");
+}
+
+size_t amq_decode_engine_image_bytes(int n_block) { return n_block > 0 ? amq::engine_image_bytes(n_block) : 0; }
+size_t amq_decode_engine_scratch_bytes(int hidden, int inter, int n_kv_heads) {
+    if (hidden < 1 || inter < 1 || n_kv_heads < 1) return 0;
+    return amq::engine_scratch_bytes(hidden, inter, n_kv_heads);
+}
+size_t amq_decode_engine_sync_bytes(void) { return amq::engine_sync_bytes(); }
+
+static int engine_shapes_ok(int hidden, int inter, int n_heads, int n_kv_heads, int head_dim) {
+    if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
+    if (n_heads < 1 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0) return fail(AMQ_ESHAPE, "bad head counts %d / %d", n_heads, n_kv_heads);
+    if (hidden != n_heads * 128) return fail(AMQ_ESHAPE, "hidden (%d) must equal n_heads * 128", hidden);
+    if ((hidden % 128) != 0 || (inter % 128) != 0 || inter < 128) return fail(AMQ_ESHAPE, "hidden and inter must be multiples of 128");
+    if (hidden > 32768 || inter > 32768) return fail(AMQ_ESHAPE, "hidden / inter above 32768 are not staged by the engine");
+    return AMQ_OK;
+}
+
+int amq_decode_engine_image(const amq_engine_block* blocks, int n_block, int hidden, int inter, int n_heads, int n_kv_heads,
+                            int head_dim, int group, void* image) {
+    if (!blocks || !image || n_block < 1) return fail(AMQ_EINVAL, "null pointer / no blocks");
+    if (int rc = engine_shapes_ok(hidden, inter, n_heads, n_kv_heads, head_dim)) return rc;
+    const int kvd = n_kv_heads * 128;
+    const int Ns[7] = {hidden, kvd, kvd, hidden, inter, inter, hidden};
+    std::vector<amq::EngineLinearH> lin((size_t)n_block * 7);
+    std::vector<const void*> ln1(n_block), ln2(n_block);
+    std::vector<void*> kc(n_block), vc(n_block);
+    for (int b = 0; b < n_block; ++b) {
+        for (int i = 0; i < 7; ++i) {
+            const amq_engine_linear& l = blocks[b].lin[i];
+            const int K = i == 6 ? inter : hidden;
+            if (l.N != Ns[i]) return fail(AMQ_ESHAPE, "block %d linear %d: N = %d, expected %d", b, i, l.N, Ns[i]);
+            if (int rc = check_shape(l.bits, l.N, K, group)) return rc;
+            if (int rc = check_mode(l.mode)) return rc;
+            if (!l.qweight_native || !l.meta_native) return fail(AMQ_EINVAL, "block %d linear %d: null pointer", b, i);
+            if (amq::native_qweight_bytes(l.bits, l.N, K) >= (1ull << 32)) return fail(AMQ_ESHAPE, "block %d linear %d spans 4 GiB or more", b, i);
+            lin[(size_t)b * 7 + i] = amq::EngineLinearH{l.qweight_native, l.meta_native, l.N, l.bits, l.mode};
+        }
+        if (!blocks[b].ln1 || !blocks[b].ln2 || !blocks[b].kcache || !blocks[b].vcache) return fail(AMQ_EINVAL, "block %d: null pointer", b);
+        ln1[b] = blocks[b].ln1; ln2[b] = blocks[b].ln2; kc[b] = blocks[b].kcache; vc[b] = blocks[b].vcache;
+    }
+    amq::engine_fill_image(image, n_block, lin.data(), ln1.data(), ln2.data(), kc.data(), vc.data(), hidden, inter);
+    return AMQ_OK;
+}
+
+int amq_decode_engine_f16(const void* blocks_dev, int n_block, int hidden, int inter, int n_heads, int n_kv_heads, int head_dim,
+                          int max_seq, float eps, void* x, void* scratch, size_t scratch_bytes, const void* step_state,
+                          void* sync, size_t sync_bytes, int grid, void* stream) {
+    if (!blocks_dev || !x || !scratch || !step_state || !sync) return fail(AMQ_EINVAL, "null pointer");
+    if (n_block < 1) return fail(AMQ_EINVAL, "no blocks");
+    if (int rc = engine_shapes_ok(hidden, inter, n_heads, n_kv_heads, head_dim)) return rc;
+    if (max_seq < 1) return fail(AMQ_ESHAPE, "max_seq must be >= 1");
+    if (grid < 0 || grid > 1024) return fail(AMQ_EINVAL, "grid must be 0 (one workgroup per CU) or 1..1024");
+    if (scratch_bytes < amq::engine_scratch_bytes(hidden, inter, n_kv_heads))
+        return fail(AMQ_EINVAL, "scratch too small: need %zu bytes, got %zu", amq::engine_scratch_bytes(hidden, inter, n_kv_heads), scratch_bytes);
+    if (sync_bytes < amq::engine_sync_bytes()) return fail(AMQ_EINVAL, "sync workspace too small: need %zu bytes", amq::engine_sync_bytes());
+    amq::EngineDesc d{};
+    d.blocks_dev = blocks_dev; d.n_block = n_block; d.H = hidden; d.I = inter; d.n_heads = n_heads; d.n_kv_heads = n_kv_heads;
+    d.max_seq = max_seq; d.eps = eps; d.x = x; d.scratch = scratch; d.state = step_state; d.sync = sync; d.grid = grid;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return fail(AMQ_ELAUNCH, "no HIP device");
+    const int P = grid > 0 ? grid : cus;
+    if (P > cus) return fail(AMQ_EINVAL, "grid %d exceeds the %d CUs of the device: the workgroups must all be resident", P, cus);
+    if (n_heads > P) return fail(AMQ_ESHAPE, "the attention stage needs one workgroup per head (%d heads, %d workgroups)", n_heads, P);
+    if (amq::engine_lds_bytes(d, P) > LDS_LIMIT)
+        return fail(AMQ_ESHAPE, "engine LDS need (%zu bytes: max_seq %d, hidden %d, inter %d) exceeds %zu", amq::engine_lds_bytes(d, P),
+                    max_seq, hidden, inter, LDS_LIMIT);
+    return check_hip(amq::launch_decode_engine(d, (hipStream_t)stream), "decode_engine");
 }
 
 int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,

@@ -134,6 +134,30 @@ hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, 
 hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                             int N, int K, hipStream_t st, int M = 1);      // x [M, K], y [M, N], M <= 8
 
+// one decode token as one persistent launch (amq_engine.hip)
+struct EngineDesc {
+    const void* blocks_dev;   // device image of the per-block table (engine_fill_image)
+    int n_block;
+    int H, I, n_heads, n_kv_heads, max_seq;
+    float eps;
+    void* x;                  // fp16 [H]: the residual stream, in / out
+    void* scratch;            // engine_scratch_bytes(): q, k, v, attention output, gate, up
+    const void* state;        // step-state block (cos/sin row of the current position, position, error word)
+    void* sync;               // engine_sync_bytes(): barrier words, zeroed by the launch function
+    int grid;                 // workgroups; 0 = one per CU
+    int depth;                // weight-ring slots per wave: 0 = by LDS budget, else 4 or 6
+};
+struct EngineLinearH { const void* qweight; const void* meta; int N; int bits; int mode; };    // host-side view of one linear
+size_t engine_image_bytes(int n_block);
+// fills `image` (host memory) with the device table of n_block blocks: lin = [n_block][7] (q, k, v, o, gate, up, down),
+// ln / cache pointers per block
+void engine_fill_image(void* image, int n_block, const EngineLinearH* lin, const void* const* ln1, const void* const* ln2,
+                       void* const* kc, void* const* vc, int H, int I);
+size_t engine_sync_bytes();
+size_t engine_scratch_bytes(int H, int I, int n_kv_heads);
+size_t engine_lds_bytes(const EngineDesc& d, int P);
+hipError_t launch_decode_engine(const EngineDesc& d, hipStream_t st);
+
 // reference formats -> native
 hipError_t launch_repack(int fmt, int bits, const void* qsrc, const void* s_src, const void* z_src,
                          int N, int K, void* q_native, void* meta_native, hipStream_t st, int group = 128);   // group: the SOURCE format's

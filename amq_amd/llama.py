@@ -59,8 +59,13 @@ def _synthetic_linear(n, k, bits, gen, device):
 
 
 class QuantLlama:
+    # decode steps run as ONE persistent launch per token (ops.DecodeEngine) when the runner is batch 1 and its KV cache is in the
+    # single-workgroup-per-head attention regime (the same bound as ops.ATTN_SPLIT_FROM); otherwise, and with engine=False, as
+    # five launches per block
+    ENGINE_MAX_SEQ = 512
+
     def __init__(self, config, arch_linear=None, device="cuda:0", max_seq=256, seed=0, synthetic=True,
-                 hqq_layers=None, dense=None, batch=1):
+                 hqq_layers=None, dense=None, batch=1, engine=None):
         """config: an entry of arch.MODEL_CONFIGS (or its name).
         arch_linear: {'self_attn.q_proj': [bits]*n_block, ...}; default uniform 4.
         hqq_layers: {(block, name): HQQWeights} real quantized layers (else synthetic).
@@ -140,6 +145,15 @@ class QuantLlama:
         self.graph = None
         self.host_pos = 0          # host mirror of self.pos (decode_step refuses to run past the cache without a device sync)
         self._down_rows_fit = self.B <= ops.gemv_max_rows(self.I)
+        eligible = self.B == 1 and max_seq <= self.ENGINE_MAX_SEQ and self.H == self.nh * 128
+        if engine and not eligible:
+            raise ValueError("the decode engine needs batch 1 and max_seq <= %d" % self.ENGINE_MAX_SEQ)
+        self.engine = None
+        if eligible and (engine is None or engine):
+            self.engine = ops.DecodeEngine(
+                [dict({n: dict(qn=blk[n].qn, mn=blk[n].mn, bits=blk[n].bits, mode=blk[n].mode, N=blk[n].N) for n in ops.ENGINE_LINEARS},
+                      ln1=blk["ln1"], ln2=blk["ln2"], kc=blk["kc"], vc=blk["vc"]) for blk in self.blocks],
+                self.H, self.I, self.nh, self.nkv, max_seq, self.eps, self.x.view(-1), self.rope_cur)
 
     # ----------------------------------------------------------------- sizes
     def linear_bytes_per_token(self):
@@ -155,6 +169,11 @@ class QuantLlama:
         """one token: reads self.x (= embed[self.token], kept in step by set_token / the step's own tail) and self.pos
         (device), writes self.logits, self.token, self.pos and the next step's self.x"""
         H = self.H
+        if self.engine is not None:
+            self.engine.step()
+            ops.gemv_f16w(self.x.reshape(-1), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
+            ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
+            return
         for blk in self.blocks:
             ops.gemv_grouped(self.x, [blk["self_attn.q_proj"].seg(self.q), blk["self_attn.k_proj"].seg(self.k),
                                       blk["self_attn.v_proj"].seg(self.v)], H, prologue=ops.PRO_RMSNORM,
@@ -185,6 +204,8 @@ class QuantLlama:
     def check(self):
         """raise if any decode step ran with its device-side position outside the cache (synchronises)"""
         ops.check_step_state(self.step_err)
+        if self.engine is not None:
+            self.engine.check()
 
     def set_token(self, token):
         """make ``token`` (int or 1-element tensor) the input of the next decode step; also re-derives what the step
@@ -539,6 +560,7 @@ class DenseLlama(QuantLlama):
         self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
         self.host_pos = 0
+        self.engine = None           # (the one-launch-per-token engine serves the quantized runner only)
 
     def linear_bytes_per_token(self):
         return sum(blk[name].numel() * 2 for blk in self.blocks for name in self.cfg["linear"])

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (MODE_HQQ, MODE_FMA, PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL, Segment, GemvOpts,  # noqa: F401
+from ._lib import (MODE_HQQ, MODE_FMA, PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL, Segment, GemvOpts, EngineBlock, EngineLinear,  # noqa: F401
                    GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, MATH_EXACT, MATH_LINEAR)
 
 GROUP = 128
@@ -577,6 +577,84 @@ def check_step_state(err):
     """raise if a decode step ran with its device-side position outside the KV cache (synchronises)"""
     if int(err.item()) != 0:
         raise _lib.AmqError("a decode step ran with its position outside the KV cache (step skipped on the device)")
+
+
+ENGINE_LINEARS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj",
+                  "mlp.down_proj")
+
+
+class DecodeEngine:
+    """One decode token of a whole model as ONE persistent launch (include/amq_hip.h: amq_decode_engine_f16; counterpart of
+    the per-token loop of amq/kernel/monkeypatch/ftllama_modeling.py:167-230).
+
+    blocks: list of dicts, one per decoder block: the seven linears under ENGINE_LINEARS as dicts {qn, mn, bits, mode, N}
+    (native buffers), "ln1" / "ln2" fp16 [hidden], "kc" / "vc" fp16 [1, n_kv_heads, max_seq, 128] (batch 1).
+    x: fp16 [hidden] residual stream (in / out); step_cur: the fp16 [128] view of a step-state block (new_step_state()).
+    The device table, scratch and barrier words are owned by this object; step() only enqueues (graph-capturable)."""
+
+    def __init__(self, blocks, hidden, inter, n_heads, n_kv_heads, max_seq, eps, x, step_cur, grid=0):
+        lib = _lib.load()
+        dev = x.device
+        nb = len(blocks)
+        _need(x, torch.float16, "x", hidden)
+        _need(step_cur, torch.float16, "rope_cur", 128)
+        arr = (EngineBlock * nb)()
+        keep = []
+        for b, blk in enumerate(blocks):
+            for i, name in enumerate(ENGINE_LINEARS):
+                l = blk[name]
+                K = inter if name == "mlp.down_proj" else hidden
+                _check_shape(l["bits"], l["N"], K)
+                _check_native(l["qn"], l["mn"], l["bits"], l["N"], K)
+                if l["qn"].device != dev:
+                    raise ValueError("all engine buffers must live on x's device")
+                arr[b].lin[i] = EngineLinear(_lib.ptr(l["qn"]), _lib.ptr(l["mn"]), l["N"], l["bits"], l["mode"], 0)
+                keep += [l["qn"], l["mn"]]
+            _need(blk["ln1"], torch.float16, "ln1", hidden)
+            _need(blk["ln2"], torch.float16, "ln2", hidden)
+            for c in ("kc", "vc"):
+                _need(blk[c], torch.float16, c, n_kv_heads * max_seq * 128)
+            arr[b].ln1, arr[b].ln2 = _lib.ptr(blk["ln1"]), _lib.ptr(blk["ln2"])
+            arr[b].kcache, arr[b].vcache = _lib.ptr(blk["kc"]), _lib.ptr(blk["vc"])
+            keep += [blk["ln1"], blk["ln2"], blk["kc"], blk["vc"]]
+        nbytes = int(lib.amq_decode_engine_image_bytes(nb))
+        host = (ctypes.c_ubyte * nbytes)()
+        _lib.check(lib.amq_decode_engine_image(arr, nb, hidden, inter, n_heads, n_kv_heads, 128, GROUP, host))
+        self.image = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+        self.scratch = torch.zeros(int(lib.amq_decode_engine_scratch_bytes(hidden, inter, n_kv_heads)), dtype=torch.uint8, device=dev)
+        self.sync = torch.zeros(int(lib.amq_decode_engine_sync_bytes()) // 4, dtype=torch.int32, device=dev)
+        self._keep = keep
+        self.x, self.cur = x, step_cur
+        self.args = (nb, hidden, inter, n_heads, n_kv_heads, 128, int(max_seq), ctypes.c_float(eps))
+        self.grid = int(grid)
+        self._grid_used = None
+
+    def step(self):
+        if self._grid_used != self.grid:         # the barrier words count arrivals of ONE grid size across launches
+            self.sync.zero_()
+            self._grid_used = self.grid
+        _lib.check(_lib.load().amq_decode_engine_f16(_lib.ptr(self.image), *self.args, _lib.ptr(self.x), _lib.ptr(self.scratch),
+                                                     self.scratch.numel(), _lib.ptr(self.cur), _lib.ptr(self.sync),
+                                                     self.sync.numel() * 4, self.grid, _lib.current_stream()))
+
+    def check(self):
+        """raise if a barrier poll of an earlier step ran into its bound (synchronises)"""
+        word = int(self.sync[(2 + 2 * 32 - 1) * 64].item())
+        if word != 0:
+            self._grid_used = None               # (re-zeroed before the next launch)
+            raise _lib.AmqError("decode engine: a device-wide barrier timed out (barrier %d of the launch, first seen by workgroup %d)"
+                                % (word & 0xFFFF, int(self.sync[(2 + 2 * 32 - 1) * 64 + 1].item())))
+
+    def vector(self, name):
+        """fp16 view of one hand-off vector of the scratch buffer ('q', 'k', 'v', 'att', 'gate', 'up'): tests only"""
+        nb, H, I, nh, nkv = self.args[0], self.args[1], self.args[2], self.args[3], self.args[4]
+        sizes = [("q", H), ("k", nkv * 128), ("v", nkv * 128), ("att", H), ("gate", I), ("up", I)]
+        off = 0
+        for n, sz in sizes:
+            if n == name:
+                return self.scratch[off:off + 2 * sz].view(torch.float16)
+            off += (2 * sz + 255) // 256 * 256
+        raise KeyError(name)
 
 
 def rope_table(max_seq, rope_theta, device):

@@ -29,7 +29,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_version_sizes_and_validation():
     lib = _lib.load()
-    assert lib.amq_version() == 201
+    assert lib.amq_version() == 300
     # native sizes: N*K*bits/8 payload, 4 B of (scale, zero) per (row, group)
     for bits in (2, 3, 4):
         assert lib.amq_native_qweight_bytes(bits, 4096, 4096) == 4096 * 4096 * bits // 8
@@ -62,6 +62,40 @@ def test_version_sizes_and_validation():
     assert lib.amq_gemm_gated_fused(_lib.GEMM_RING if hasattr(_lib, "GEMM_RING") else 3, 32768, 13824, 5120, 0) == 1
     assert lib.amq_gemm_gated_fused(3, 300000, 4096, 8192, 0) == 0          # x: 300000 x 8192 x 2 B = 4.9 GB
     assert lib.amq_gemm_gated_fused(3, 200000, 4096, 8192, 0) == 1          # 3.3 GB
+
+
+def test_decode_engine_host_side():
+    """the one-launch-per-token engine: sizes, the host-side table builder and argument validation (no GPU needed)"""
+    lib = _lib.load()
+    assert lib.amq_decode_engine_sync_bytes() % 256 == 0 and lib.amq_decode_engine_sync_bytes() >= 66 * 256
+    assert lib.amq_decode_engine_image_bytes(32) == 32 * lib.amq_decode_engine_image_bytes(1) > 0
+    H, I, nh, nkv = 4096, 11008, 32, 32
+    r256 = lambda halves: (2 * halves + 255) // 256 * 256
+    assert lib.amq_decode_engine_scratch_bytes(H, I, nkv) == 2 * r256(H) + 2 * r256(nkv * 128) + 2 * r256(I)
+    blocks = (_lib.EngineBlock * 2)()
+    Ns = [H, nkv * 128, nkv * 128, H, I, I, H]
+    for b in range(2):
+        for i in range(7):
+            blocks[b].lin[i] = _lib.EngineLinear(4096 * (1 + i), 8192 * (1 + i), Ns[i], 2 + (i + b) % 3, 0, 0)
+        blocks[b].ln1, blocks[b].ln2, blocks[b].kcache, blocks[b].vcache = 16, 32, 48, 64
+    image = (ctypes.c_ubyte * lib.amq_decode_engine_image_bytes(2))()
+    assert lib.amq_decode_engine_image(blocks, 2, H, I, nh, nkv, 128, 128, image) == 0
+    assert any(image)                                                       # the table was written
+    blocks[1].lin[4].N = I - 16
+    assert lib.amq_decode_engine_image(blocks, 2, H, I, nh, nkv, 128, 128, image) == -2 and b"linear 4" in lib.amq_last_error()
+    blocks[1].lin[4].N = I
+    blocks[0].lin[2].bits = 5
+    assert lib.amq_decode_engine_image(blocks, 2, H, I, nh, nkv, 128, 128, image) == -1
+    blocks[0].lin[2].bits = 3
+    assert lib.amq_decode_engine_image(blocks, 2, H, I, nh, nkv, 64, 128, image) == -2          # head_dim
+    assert lib.amq_decode_engine_image(blocks, 2, H + 128, I, nh, nkv, 128, 128, image) == -2   # hidden != heads * 128
+    one = ctypes.c_void_p(16)
+    args = dict(sc=lib.amq_decode_engine_scratch_bytes(H, I, nkv), sy=lib.amq_decode_engine_sync_bytes())
+    assert lib.amq_decode_engine_f16(None, 2, H, I, nh, nkv, 128, 256, 1e-5, one, one, args["sc"], one, one, args["sy"], 0, None) == -1
+    assert lib.amq_decode_engine_f16(one, 2, H, I, nh, nkv, 128, 256, 1e-5, one, one, args["sc"] - 1, one, one, args["sy"], 0, None) == -1
+    assert b"scratch" in lib.amq_last_error()
+    assert lib.amq_decode_engine_f16(one, 2, H, I, nh, nkv, 128, 256, 1e-5, one, one, args["sc"], one, one, 64, 0, None) == -1
+    assert lib.amq_decode_engine_f16(one, 2, H, I, nh, 3, 128, 256, 1e-5, one, one, args["sc"], one, one, args["sy"], 0, None) == -2
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
