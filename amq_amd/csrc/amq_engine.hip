@@ -56,7 +56,7 @@ constexpr int EA_PF = 6;                 // K / V rows per 16-lane group held in
 // words, line 66: base = barriers completed by earlier launches
 constexpr int ENG_SYNC_WORDS = (3 + 2 * ENG_NG) * ENG_LINE;
 
-struct EngLinearD { const void* qw; const void* mt; int n_rt; int key; long qbytes; long mbytes; };   // key = bits * 2 + mode
+struct EngLinearD { const void* qw; const void* mt; int n_rt; int key; };   // key = bits * 2 + mode
 struct EngBlockD { EngLinearD lin[7]; const void* ln1; const void* ln2; void* kc; void* vc; };
 
 struct EngArgs {
@@ -71,6 +71,7 @@ struct EngArgs {
     int red_rows;                                  // row-tiles per workgroup the partial-sum buffer holds
 #ifdef AMQ_ENG_STAMP
     unsigned long long* stamps;
+    int stamp_block;
 #endif
 };
 
@@ -122,7 +123,8 @@ __device__ __forceinline__ void eng_sth_sc1(_Float16* p, _Float16 v) {
 }
 
 #ifdef AMQ_ENG_STAMP
-#define ENG_STAMP(slot_) do { if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)blockIdx.x * 64 + (slot_))] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// diagnostic build (-DAMQ_ENG_STAMP): workgroup w, block `stamp_block`: slot s <- 100 MHz realtime counter (comparable across CUs)
+#define ENG_STAMP(slot_) do { if (a.stamps && threadIdx.x == 0 && b == a.stamp_block) a.stamps[((size_t)blockIdx.x * 64 + (slot_))] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ENG_STAMP(slot_) do { } while (0)
 #endif
@@ -137,8 +139,10 @@ struct StageD {
     bool residual;              // y0 += (in place on the residual stream)
 };
 
-__device__ __forceinline__ StageD eng_stage(const EngArgs& a, int gstage) {
-    const EngBlockD* blk = a.blocks + (gstage >> 2);
+// `img`: the block table in LDS (copied there at kernel entry: read from global memory -- dependent scalar loads, cold at every
+// stage -- a change of the issue cursor's run cost ~4000 cycles, tools/stamp_engine.py: 655 cycles per TILE)
+__device__ __forceinline__ StageD eng_stage(const EngArgs& a, const EngBlockD* img, int gstage) {
+    const EngBlockD* blk = img + (gstage >> 2);
     StageD s;
     s.y1 = s.y2 = nullptr;
     switch (gstage & 3) {
@@ -163,11 +167,25 @@ __host__ __device__ __forceinline__ int eng_stage_rowtiles(int H, int I, int n_k
 }
 // this workgroup's contiguous range of a stage's row-tiles: [first, end) = [wg * T / P, (wg + 1) * T / P) -- computed once per
 // kernel into LDS (grange[2 * kind], [2 * kind + 1]): a division per stage per wave is scalar code the hot path does not need
-__device__ __forceinline__ void eng_fill_ranges(const EngArgs& a, int* grange, int wg, int P) {
+__device__ __forceinline__ void eng_fill_ranges(const EngArgs& a, int* grange, int* rinfo, int wg, int P) {
     if (threadIdx.x < 4) {
         const unsigned T = (unsigned)eng_stage_rowtiles(a.H, a.I, a.n_kv_heads, (int)threadIdx.x);
         grange[2 * threadIdx.x] = (int)(((unsigned)wg * T) / (unsigned)P);              // wg * T < 2^31 (capi bounds)
         grange[2 * threadIdx.x + 1] = (int)((((unsigned)wg + 1u) * T) / (unsigned)P);
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 71) {              // per linear of a block: this workgroup's piece of that segment
+        const int e = (int)threadIdx.x - 64;
+        const int kind = e < 3 ? EK_QKV : e == 3 ? EK_O : e < 6 ? EK_GU : EK_DOWN;
+        const int kvd = a.n_kv_heads * 128;
+        const int nrt[7] = {a.H >> 4, kvd >> 4, kvd >> 4, a.H >> 4, a.I >> 4, a.I >> 4, a.H >> 4};
+        const int first = e < 3 ? 0 : e == 3 ? 3 : e < 6 ? 4 : 6;
+        int cum = 0;
+        for (int q = first; q < e; ++q) cum += nrt[q];
+        const unsigned T = (unsigned)eng_stage_rowtiles(a.H, a.I, a.n_kv_heads, kind);
+        const int g0 = (int)(((unsigned)wg * T) / (unsigned)P), g1 = (int)((((unsigned)wg + 1u) * T) / (unsigned)P);
+        const int lo = g0 > cum ? g0 : cum, hi = g1 < cum + nrt[e] ? g1 : cum + nrt[e];
+        rinfo[2 * e] = lo - cum;
+        rinfo[2 * e + 1] = hi > lo ? hi - lo : 0;
     }
 }
 
@@ -183,10 +201,22 @@ struct Issue {
     int nt, row_adv;            // k-tiles per row-tile of this wave; tile increment from a row-tile's last k-tile to the next's first
     int gstage, seg;            // where the cursor is: GEMV stage (block * 4 + kind), segment
     int slot_addr;              // LDS byte address of the slot the next tile goes to
+#ifdef AMQ_ENG_CYCLES
+    unsigned long long c_wait, c_lds, c_issue, c_math, n_tiles, c_next;     // diagnostic: shader-clock cycles of this wave per phase
+#endif
 };
+#ifdef AMQ_ENG_CYCLES
+#define ENG_T() __builtin_amdgcn_s_memtime()
+#define ENG_ACC(field_, t0_) do { is.field_ += ENG_T() - (t0_); } while (0)
+#else
+#define ENG_T() 0ull
+#define ENG_ACC(field_, t0_) do { (void)(t0_); } while (0)
+#endif
 
-// moves the cursor to the next non-empty (segment of a stage) piece of this workgroup's work; gstage >= 4 * n_block: exhausted
-__device__ __forceinline__ void eng_next_run(const EngArgs& a, Issue& is, const int* grange, int wave) {
+// moves the cursor to the next non-empty (segment of a stage) piece of this workgroup's work; gstage >= 4 * n_block: exhausted.
+// rinfo (LDS, filled once per kernel): for linear e = 0 .. 6 of a block (q k v | o | gate up | down) the workgroup's piece of
+// that segment: rinfo[2e] = first row-tile (segment-local), rinfo[2e + 1] = row-tiles (0: none).
+__device__ __forceinline__ void eng_next_run(const EngArgs& a, Issue& is, const EngBlockD* img, const int* rinfo, int wave) {
     for (;;) {
         const int nstage = 4 * a.n_block;
         if (is.gstage >= nstage) return;
@@ -194,23 +224,18 @@ __device__ __forceinline__ void eng_next_run(const EngArgs& a, Issue& is, const 
         const int nseg = kind == EK_QKV ? 3 : kind == EK_GU ? 2 : 1;
         is.seg = ENG_UNI(is.seg + 1);
         if (is.seg >= nseg) { is.gstage = ENG_UNI(is.gstage + 1); is.seg = -1; continue; }
-        const int g0 = ENG_UNI(grange[2 * kind]), g1 = ENG_UNI(grange[2 * kind + 1]);
-        const EngLinearD* lin = a.blocks[is.gstage >> 2].lin + (kind == EK_QKV ? 0 : kind == EK_O ? 3 : kind == EK_GU ? 4 : 6);
-        int cum = 0;
-        for (int q = 0; q < is.seg; ++q) cum += lin[q].n_rt;
-        const EngLinearD& l = lin[is.seg];
-        const int n_rt = l.n_rt;
-        const int lo = g0 > cum ? g0 : cum;
-        const int hi = g1 < cum + n_rt ? g1 : cum + n_rt;
+        const int e = (kind == EK_QKV ? 0 : kind == EK_O ? 3 : kind == EK_GU ? 4 : 6) + is.seg;
+        const int j0 = ENG_UNI(rinfo[2 * e]), cnt = ENG_UNI(rinfo[2 * e + 1]);
         const int G = (kind == EK_DOWN ? a.I : a.H) >> 7;
         const int nt = (G - wave + EW - 1) / EW;
-        if (lo < hi && nt > 0) {
+        if (cnt > 0 && nt > 0) {
+            const EngLinearD& l = img[is.gstage >> 2].lin[e];
             is.bits = ENG_UNI(l.key >> 1);
             const unsigned long long qb = (unsigned long long)l.qw, m = (unsigned long long)l.mt;
             is.qw_lo = ENG_UNI((uint32_t)qb); is.qw_hi = ENG_UNI((uint32_t)(qb >> 32));
             is.mt_lo = ENG_UNI((uint32_t)m); is.mt_hi = ENG_UNI((uint32_t)(m >> 32));
-            is.tile = ENG_UNI((lo - cum) * G + wave);
-            is.left_i = ENG_UNI(nt); is.left_j = ENG_UNI(hi - lo);
+            is.tile = ENG_UNI(j0 * G + wave);
+            is.left_i = ENG_UNI(nt); is.left_j = cnt;
             is.nt = ENG_UNI(nt); is.row_adv = ENG_UNI(G - EW * (nt - 1));
             return;
         }
@@ -229,19 +254,23 @@ __device__ __forceinline__ void eng_dma4(uint32_t voff, unsigned long long sbase
 // Issue the next tile of the wave's stream into the slot at is.slot_addr: ALWAYS two vector-memory operations (packed tile,
 // its meta), so the wait count of eng_ring_wait is a constant.  An exhausted stream re-reads the sync workspace (valid, unused).
 template <int U>
-__device__ __forceinline__ void eng_issue(const EngArgs& a, Issue& is, int ring_lo, const int* grange, int wave, int lane) {
+__device__ __forceinline__ void eng_issue(const EngArgs& a, Issue& is, int ring_lo, const EngBlockD* img, const int* rinfo, int wave, int lane) {
     const bool live = is.gstage < 4 * a.n_block;
     if (live) {
         const unsigned long long qb = ((unsigned long long)is.qw_hi << 32) | is.qw_lo;
         const unsigned long long mb = ((unsigned long long)is.mt_hi << 32) | is.mt_lo;
         const uint32_t voq = (uint32_t)is.tile * (uint32_t)(256 * is.bits) + (uint32_t)lane * 16u;
         const uint32_t vom = ((uint32_t)is.tile * 16u + (uint32_t)lane) * 4u;
+#ifndef AMQ_ENG_ABL_NODMA          /* timing ablations (results wrong): no weight traffic at all / no (scale, zero) DMA */
         if (lane < 16 * is.bits) eng_dma16(voq, qb, is.slot_addr);           // 64 / 48 / 32 lanes: 1024 / 768 / 512 bytes
+#ifndef AMQ_ENG_ABL_NOMETA
         if (lane < 16) eng_dma4(vom, mb, is.slot_addr + 1024);
+#endif
+#endif
         if (--is.left_i == 0) {
             is.left_i = is.nt;
             is.tile += is.row_adv;
-            if (--is.left_j == 0) eng_next_run(a, is, grange, wave);
+            if (--is.left_j == 0) { const unsigned long long tn_ = ENG_T(); eng_next_run(a, is, img, rinfo, wave); ENG_ACC(c_next, tn_); }
         } else {
             is.tile += EW;
         }
@@ -257,7 +286,13 @@ __device__ __forceinline__ void eng_issue(const EngArgs& a, Issue& is, int ring_
 // operations of the wave -- all younger or long complete -- can only make this wait longer than needed, never too short.)
 template <int U>
 __device__ __forceinline__ void eng_ring_wait() {
+#if defined(AMQ_ENG_ABL_NODMA)
+    asm volatile("" ::: "memory");
+#elif defined(AMQ_ENG_ABL_NOMETA)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(U - 1) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (U - 1)) : "memory");
+#endif
 }
 
 // ---------------------------------------------------------------- device-wide barrier
@@ -371,14 +406,31 @@ __device__ __forceinline__ void eng_stage_x_k(const StageD& s, float eps, _Float
 
 // ---------------------------------------------------------------- one (segment of a stage) piece: consume its tiles
 template <int BITS, int MODE, int U>
-__device__ __forceinline__ void eng_run(const EngArgs& a, Issue& is, int& cslot, int lds0, int ring_off, int j0, int j1, int nt, int jj,
-                                        const _Float16* xl, float* red, const unsigned char* smem, const int* grange, int wave, int lane) {
+__device__ __forceinline__ void eng_run(const EngArgs& a, Issue& is, int& cslot, int lds0, int ring_off, int j0, int j1, int nt, int jj, int stage_rows,
+                                        const _Float16* xl, float* red, const unsigned char* smem, const EngBlockD* img, const int* rinfo,
+                                        int wave, int lane) {
     const int o = lane >> 4;
     const _Float16* xrow = xl + 8 * o;                       // M = 1: every A row of the MFMA is x row 0
     for (int j = j0; j < j1; ++j, ++jj) {
+#ifndef AMQ_ENG_NO_PRIO
+        // Issue priority falls with the wave's progress through the stage (quartiles of its row-tiles): the SIMD arbiter is
+        // oldest-first, so without it the four oldest waves of the workgroup race ahead and the youngest finish the stage
+        // alone at the two-wave issue efficiency (first timeline: wave 0 done 2.5 us before the workgroup's last wave;
+        // the same effect and remedy as amq_gemv.hip's, profiles/r01b_gemv_prio.txt)
+        {
+            const int q4 = (4 * jj) / (stage_rows > 0 ? stage_rows : 1);
+            if (q4 <= 0) __builtin_amdgcn_s_setprio(3);
+            else if (q4 == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q4 == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < nt; ++i) {
+            const unsigned long long t0_ = ENG_T();
             eng_ring_wait<U>();
+            ENG_ACC(c_wait, t0_);
+            const unsigned long long t1_ = ENG_T();
             // the lane's 4 * BITS payload bytes lie at 4 * BITS * lane of the slot (the tile as it lies in HBM), its row's pair behind
             const unsigned char* sp = smem + cslot;
             uint32_t wr[4];
@@ -386,11 +438,20 @@ __device__ __forceinline__ void eng_run(const EngArgs& a, Issue& is, int& cslot,
             else if (BITS == 2) { const u2 v = *(const u2*)(sp + 8 * lane); wr[0] = v.x; wr[1] = v.y; }
             else { const uint32_t* q = (const uint32_t*)(sp + 12 * lane); wr[0] = q[0]; wr[1] = q[1]; wr[2] = q[2]; }
             const h2 meta = *(const h2*)(sp + 1024 + 4 * (lane & 15));
+            // the tile's four x operands are requested with it: ONE exposed LDS round trip per tile (requested next to each MFMA
+            // they cost four: 4 waves per SIMD do not hide them -- tools/stamp_engine.py, first timeline: ~1 us per tile and wave)
+            const int kbase = (wave + EW * i) << 7;
+            h8 av[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[t] = *(const h8*)(xrow + kbase + 32 * t);
             // the slot is refilled only when its contents are in registers (the DMA writes LDS behind the LDS reads' backs)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            eng_issue<U>(a, is, lds0 + ring_off, grange, wave, lane);
+            ENG_ACC(c_lds, t1_);
+            const unsigned long long t2_ = ENG_T();
+            eng_issue<U>(a, is, lds0 + ring_off, img, rinfo, wave, lane);
+            ENG_ACC(c_issue, t2_);
+            const unsigned long long t3_ = ENG_T();
             cslot = cslot + ENG_SLOT == ring_off + U * ENG_SLOT ? ring_off : cslot + ENG_SLOT;
-            const int kbase = (wave + EW * i) << 7;
             h2 wv[16];
             dequant_lane_sd<BITS, MODE>(wr, meta, wv);
             f4 c_ = acc;
@@ -399,10 +460,14 @@ __device__ __forceinline__ void eng_run(const EngArgs& a, Issue& is, int& cslot,
                 h8 b;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) { b[2 * p] = wv[4 * t + p].x; b[2 * p + 1] = wv[4 * t + p].y; }
-                const h8 av = *(const h8*)(xrow + kbase + 32 * t);
-                c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[t], b, c_, 0, 0, 0);
             }
             acc = c_;
+#ifdef AMQ_ENG_CYCLES
+            asm volatile("" :: "v"(acc));
+            ENG_ACC(c_math, t3_);
+            is.n_tiles += 1;
+#endif
         }
         if (lane < 16) red[jj * (EW * 16) + wave * 16 + lane] = acc[0];
     }
@@ -411,25 +476,22 @@ __device__ __forceinline__ void eng_run(const EngArgs& a, Issue& is, int& cslot,
 // one GEMV stage for this workgroup: x has been staged in xl
 template <int U>
 __device__ __forceinline__ void eng_gemv_stage(const EngArgs& a, int gstage, Issue& is, int& cslot, int lds0, int ring_off, const _Float16* xl,
-                                               float* red, const unsigned char* smem, const int* grange, int wave, int lane) {
-    const StageD s0 = eng_stage(a, gstage);
+                                               float* red, const unsigned char* smem, const EngBlockD* img, const int* grange,
+                                               const int* rinfo, int wave, int lane) {
+    const StageD s0 = eng_stage(a, img, gstage);
     const StageD& s = s0;
     const int g0 = ENG_UNI(grange[2 * (gstage & 3)]), g1 = ENG_UNI(grange[2 * (gstage & 3) + 1]);
     const int G = s.K >> 7;
     const int nt = (G - wave + EW - 1) / EW;
-    // residual values of this workgroup's first 256 outputs (wave 0; an in-place stage owns one or two row-tiles per workgroup
-    // on a full grid): requested now and forced to land before the tile loop, so that the compiler's wait for them cannot
-    // drain the ring later
+    // residual value of this thread's output (thread c < nout finishes output c; an in-place stage owns one or two row-tiles per
+    // workgroup on a full grid): requested now and forced to land before the tile loop, so that the compiler's wait for it
+    // cannot drain the ring later
     const int nout = (g1 - g0) * 16;
-    uint32_t res[4] = {0u, 0u, 0u, 0u};
-    if (s.residual && wave == 0) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = lane + 64 * it;
-            if (c < nout) res[it] = __hip_atomic_load((const unsigned short*)(s.y0 + (size_t)g0 * 16 + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(res[it]));
+    const int tid = (int)threadIdx.x;
+    uint32_t res0 = 0u;
+    if (s.residual && tid < nout) {
+        res0 = __hip_atomic_load((const unsigned short*)(s.y0 + (size_t)g0 * 16 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" : "+v"(res0));
     }
     int cum = 0, jj = 0;
     for (int q = 0; q < s.nseg; ++q) {
@@ -439,12 +501,12 @@ __device__ __forceinline__ void eng_gemv_stage(const EngArgs& a, int gstage, Iss
             const int j0 = lo - cum, j1 = hi - cum;
             if (nt > 0) {
                 switch (l.key) {
-                    case 4 * 2 + MODE_HQQ: eng_run<4, MODE_HQQ, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, xl, red, smem, grange, wave, lane); break;
-                    case 3 * 2 + MODE_HQQ: eng_run<3, MODE_HQQ, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, xl, red, smem, grange, wave, lane); break;
-                    case 2 * 2 + MODE_HQQ: eng_run<2, MODE_HQQ, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, xl, red, smem, grange, wave, lane); break;
-                    case 4 * 2 + MODE_FMA: eng_run<4, MODE_FMA, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, xl, red, smem, grange, wave, lane); break;
-                    case 3 * 2 + MODE_FMA: eng_run<3, MODE_FMA, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, xl, red, smem, grange, wave, lane); break;
-                    default:               eng_run<2, MODE_FMA, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, xl, red, smem, grange, wave, lane); break;
+                    case 4 * 2 + MODE_HQQ: eng_run<4, MODE_HQQ, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, g1 - g0, xl, red, smem, img, rinfo, wave, lane); break;
+                    case 3 * 2 + MODE_HQQ: eng_run<3, MODE_HQQ, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, g1 - g0, xl, red, smem, img, rinfo, wave, lane); break;
+                    case 2 * 2 + MODE_HQQ: eng_run<2, MODE_HQQ, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, g1 - g0, xl, red, smem, img, rinfo, wave, lane); break;
+                    case 4 * 2 + MODE_FMA: eng_run<4, MODE_FMA, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, g1 - g0, xl, red, smem, img, rinfo, wave, lane); break;
+                    case 3 * 2 + MODE_FMA: eng_run<3, MODE_FMA, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, g1 - g0, xl, red, smem, img, rinfo, wave, lane); break;
+                    default:               eng_run<2, MODE_FMA, U>(a, is, cslot, lds0, ring_off, j0, j1, nt, jj, g1 - g0, xl, red, smem, img, rinfo, wave, lane); break;
                 }
             } else if (lane < 16) {                        // K < 128 * 16: this wave owns no tile, its partials are zero
                 for (int j = j0; j < j1; ++j) red[(jj + j - j0) * (EW * 16) + wave * 16 + lane] = 0.f;
@@ -453,10 +515,16 @@ __device__ __forceinline__ void eng_gemv_stage(const EngArgs& a, int gstage, Iss
         }
         cum += l.n_rt;
     }
+#ifndef AMQ_ENG_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);                            // epilogue, barrier and the next stage's prologue at top priority
+#endif
+    { const int b = gstage >> 2; (void)b; ENG_STAMP(1 + 8 * (gstage & 3) + 2); }
     __syncthreads();                                          // every wave's partials of every row-tile are in LDS
-    if (wave == 0) {
-        const StageD s = eng_stage(a, gstage);               // (output pointers are derived again here rather than held in SGPRs)
-        // fixed-order sum over the 16 waves, one fp16 rounding, residual as a separate fp16 add (amq_gemv.hip AMQ_FINISH)
+    { const int b = gstage >> 2; (void)b; ENG_STAMP(1 + 8 * (gstage & 3) + 3); }
+    if (tid < nout || nout > ET) {
+        const StageD s = eng_stage(a, img, gstage);          // (output pointers are derived again here rather than held in SGPRs)
+        // fixed-order sum over the 16 waves, one fp16 rounding, residual as a separate fp16 add (amq_gemv.hip AMQ_FINISH); output c
+        // by thread c: every storing wave drains its own stores before the barrier's workgroup barrier (Guideline 16, R1)
         const int n0 = s.lin[0].n_rt, n1 = s.nseg > 1 ? n0 + s.lin[1].n_rt : 0x7fffffff;
         auto finish = [&](int c, bool have_res, uint32_t resv) {
             const float* rp = red + (c >> 4) * (EW * 16) + (c & 15);
@@ -472,14 +540,11 @@ __device__ __forceinline__ void eng_gemv_stage(const EngArgs& a, int gstage, Iss
             }
             eng_sth_sc1(dst + (c & 15), y);
         };
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = lane + 64 * it;
-            if (c < nout) finish(c, true, res[it]);
-        }
-        for (int c = lane + 256; c < nout; c += 64) finish(c, false, 0u);      // small grids only: more than 16 row-tiles per workgroup
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // publish: the storing wave drains before the barrier's arrival
+        if (tid < nout) finish(tid, true, res0);
+        for (int c = tid + ET; c < nout; c += ET) finish(c, false, 0u);        // small grids only: more than 64 row-tiles per workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // publish: every storing wave drains before the barrier's arrival
     }
+    { const int b = gstage >> 2; (void)b; ENG_STAMP(1 + 8 * (gstage & 3) + 4); }
 }
 
 // ---------------------------------------------------------------- attention stage (workgroup = one head)
@@ -674,14 +739,18 @@ __global__ __launch_bounds__(ET) void decode_engine_kernel(EngArgs a) {
     float* reds = red + (size_t)a.red_rows * (EW * 16);                  // [16]
     int* flag = (int*)(reds + EW);
     int* grange = flag + 4;                                              // [4 kinds][first, end)
+    int* rinfo = grange + 8;                                             // [7 linears][first row-tile, count]
+    EngBlockD* img = (EngBlockD*)(rinfo + 16);                           // the block table (n_block entries)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = blockIdx.x, P = gridDim.x;
     // the wave's ring: U slots behind the x / partial-sum regions.  Two views of one address: `ring_off` = byte offset into smem
     // (what the compiler-visible LDS reads use), lds0 + ring_off = the LDS byte address the DMA's M0 takes.
     const int lds0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int ring_off = ENG_UNI(a.lds_x_bytes + a.red_rows * (EW * 16) * 4 + EW * 4 + 48 + wave * (U * ENG_SLOT));
-    eng_fill_ranges(a, grange, wg, P);
+    const int img_bytes = (a.n_block * (int)sizeof(EngBlockD) + 15) & ~15;
+    const int ring_off = ENG_UNI(a.lds_x_bytes + a.red_rows * (EW * 16) * 4 + EW * 4 + 48 + 64 + img_bytes + wave * (U * ENG_SLOT));
+    eng_fill_ranges(a, grange, rinfo, wg, P);
+    for (int w = threadIdx.x; w < a.n_block * (int)(sizeof(EngBlockD) / 4); w += ET) ((uint32_t*)img)[w] = ((const uint32_t*)a.blocks)[w];
     __syncthreads();
 
     Issue is;
@@ -689,8 +758,12 @@ __global__ __launch_bounds__(ET) void decode_engine_kernel(EngArgs a) {
     is.bits = 4; is.tile = 0; is.left_i = is.left_j = 1; is.nt = 1; is.row_adv = 0;
     is.qw_lo = is.qw_hi = is.mt_lo = is.mt_hi = 0;
     is.slot_addr = lds0 + ring_off;
-    eng_next_run(a, is, grange, wave);
-    for (int u = 0; u < U; ++u) eng_issue<U>(a, is, lds0 + ring_off, grange, wave, lane);
+#ifdef AMQ_ENG_CYCLES
+    is.c_wait = is.c_lds = is.c_issue = is.c_math = is.n_tiles = is.c_next = 0;
+    const unsigned long long tk0_ = ENG_T();
+#endif
+    eng_next_run(a, is, img, rinfo, wave);
+    for (int u = 0; u < U; ++u) eng_issue<U>(a, is, lds0 + ring_off, img, rinfo, wave, lane);
     int cslot = ring_off;                                                // consume cursor (offset into smem)
     const unsigned base = (unsigned)ENG_UNI(*(const int*)(a.sync + (2 + 2 * ENG_NG) * ENG_LINE));   // written by the previous launch
     unsigned epoch = base;
@@ -699,7 +772,7 @@ __global__ __launch_bounds__(ET) void decode_engine_kernel(EngArgs a) {
     if (!pos_ok && wg == 0 && threadIdx.x == 0) *(int*)((char*)const_cast<void*>(a.state) + 260) = 1;   // sticky error word (amq_decode.hip)
 
     for (int b = 0; b < a.n_block; ++b) {
-        const EngBlockD* blk = a.blocks + b;
+        const EngBlockD* blk = img + b;
 #pragma unroll 1
         for (int kind = 0; kind < 4; ++kind) {
             if (b > 0 || kind > 0) {
@@ -707,22 +780,37 @@ __global__ __launch_bounds__(ET) void decode_engine_kernel(EngArgs a) {
             }
             if (kind == EK_O) {
                 // the attention stage sits between q/k/v and o_proj
+                ENG_STAMP(1 + 8 * kind + 5);
                 if (pos_ok && wg < a.n_heads) eng_attention(a, blk, wg, pos, smem);
+                ENG_STAMP(1 + 8 * kind + 6);
                 if (!eng_grid_sync(a.sync, ++epoch, wg, P, flag)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
             }
-            const StageD s = eng_stage(a, 4 * b + kind);
+            ENG_STAMP(1 + 8 * kind + 0);
+            const StageD s = eng_stage(a, img, 4 * b + kind);
             if (s.pro == PRO_RMSNORM) eng_stage_x_k<PRO_RMSNORM>(s, a.eps, xl, reds);
             else if (s.pro == PRO_SILU_MUL) eng_stage_x_k<PRO_SILU_MUL>(s, a.eps, xl, reds);
             else eng_stage_x_k<PRO_NONE>(s, a.eps, xl, reds);
-            eng_gemv_stage<U>(a, 4 * b + kind, is, cslot, lds0, ring_off, xl, red, smem, grange, wave, lane);
+            ENG_STAMP(1 + 8 * kind + 1);
+            eng_gemv_stage<U>(a, 4 * b + kind, is, cslot, lds0, ring_off, xl, red, smem, img, grange, rinfo, wave, lane);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the trailing (unused) DMAs must not land after the workgroup has gone
     // every workgroup read `base` before its first barrier and this point lies behind the last one: nobody reads it again in this launch
     if (wg == 0 && threadIdx.x == 0) a.sync[(2 + 2 * ENG_NG) * ENG_LINE] = epoch;
+#ifdef AMQ_ENG_CYCLES
+    if (a.stamps && threadIdx.x == 0) {
+        unsigned long long* o = a.stamps + (size_t)blockIdx.x * 64 + 40;
+        o[0] = is.c_wait; o[1] = is.c_lds; o[2] = is.c_issue; o[3] = is.c_math; o[4] = is.n_tiles; o[5] = is.c_next; o[6] = ENG_T() - tk0_;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- host side
+#ifdef AMQ_ENG_STAMP
+static unsigned long long* g_eng_stamps = nullptr;
+static int g_eng_stamp_block = 1;
+extern "C" int amq_debug_engine_stamps(void* p, int block) { g_eng_stamps = (unsigned long long*)p; g_eng_stamp_block = block; return 0; }
+#endif
 size_t engine_sync_bytes() { return (size_t)ENG_SYNC_WORDS * 4; }
 size_t engine_image_bytes(int n_block) { return (size_t)n_block * sizeof(EngBlockD); }
 
@@ -735,8 +823,7 @@ void engine_fill_image(void* image, int n_block, const EngineLinearH* lin, const
             const int K = i == 6 ? I : H;
             EngLinearD& d = out[b].lin[i];
             d.qw = l.qweight; d.mt = l.meta; d.n_rt = l.N / 16; d.key = l.bits * 2 + l.mode;
-            d.qbytes = (long)native_qweight_bytes(l.bits, l.N, K);
-            d.mbytes = (long)native_meta_bytes(l.N, K);
+            (void)K;
         }
         out[b].ln1 = ln1[b]; out[b].ln2 = ln2[b]; out[b].kc = kc[b]; out[b].vc = vc[b];
     }
@@ -760,7 +847,7 @@ static size_t engine_x_bytes(const EngineDesc& d) {
 }
 
 static size_t engine_fixed_lds(const EngineDesc& d, int P) {
-    return engine_x_bytes(d) + (size_t)engine_red_rows(d, P) * (EW * 16) * 4 + EW * 4 + 48;
+    return engine_x_bytes(d) + (size_t)engine_red_rows(d, P) * (EW * 16) * 4 + EW * 4 + 48 + 64 + (((size_t)d.n_block * sizeof(EngBlockD) + 15) & ~(size_t)15);
 }
 // ring depth the LDS budget allows: 6 slots per wave (102 KB of weights in flight per CU), else 4; 0: does not fit
 static int engine_depth(const EngineDesc& d, int P) {
@@ -792,7 +879,7 @@ hipError_t launch_decode_engine(const EngineDesc& d, hipStream_t st) {
     a.lds_x_bytes = (int)engine_x_bytes(d);
     a.red_rows = engine_red_rows(d, P);
 #ifdef AMQ_ENG_STAMP
-    a.stamps = nullptr;
+    a.stamps = g_eng_stamps; a.stamp_block = g_eng_stamp_block;
 #endif
     const int u = engine_depth(d, P);
     if (u == 0) return hipErrorInvalidValue;

@@ -63,6 +63,7 @@ class QuantLlama:
     # single-workgroup-per-head attention regime (the same bound as ops.ATTN_SPLIT_FROM); otherwise, and with engine=False, as
     # five launches per block
     ENGINE_MAX_SEQ = 512
+    ENGINE_DEFAULT = False      # what engine=None means (the engine is opt-in until it beats the five-launch step: DESIGN.md 4)
 
     def __init__(self, config, arch_linear=None, device="cuda:0", max_seq=256, seed=0, synthetic=True,
                  hqq_layers=None, dense=None, batch=1, engine=None):
@@ -149,7 +150,9 @@ class QuantLlama:
         if engine and not eligible:
             raise ValueError("the decode engine needs batch 1 and max_seq <= %d" % self.ENGINE_MAX_SEQ)
         self.engine = None
-        if eligible and (engine is None or engine):
+        if engine is None:
+            engine = self.ENGINE_DEFAULT
+        if eligible and engine:
             self.engine = ops.DecodeEngine(
                 [dict({n: dict(qn=blk[n].qn, mn=blk[n].mn, bits=blk[n].bits, mode=blk[n].mode, N=blk[n].N) for n in ops.ENGINE_LINEARS},
                       ln1=blk["ln1"], ln2=blk["ln2"], kc=blk["kc"], vc=blk["vc"]) for blk in self.blocks],

@@ -53,12 +53,12 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 measured
 MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16
 
 
-def build_model(device, seed=0, max_seq=1024, model=MODEL, pinned=None, batch=1):
+def build_model(device, seed=0, max_seq=1024, model=MODEL, pinned=None, batch=1, engine=None):
     from amq_amd import arch
     from amq_amd.llama import QuantLlama
     cfg = arch.MODEL_CONFIGS[model]
     a, usage = arch.synthesize_arch(cfg, TARGET_BITS, seed=0, pinned=arch.PINNED_7B if pinned is None else pinned)
-    m = QuantLlama(cfg, a["linear"], device=device, max_seq=max_seq, seed=seed, batch=batch)
+    m = QuantLlama(cfg, a["linear"], device=device, max_seq=max_seq, seed=seed, batch=batch, engine=engine)
     return m, a, usage
 
 
@@ -278,7 +278,7 @@ def load_traffic():
 def run_decode(args, rep, dev):
     rank, n_gpus = rep.rank, rep.world
     max_seq = PROMPT + args.warmup + args.steps + 8
-    m, a, usage = build_model(dev, seed=rank, max_seq=max_seq)
+    m, a, usage = build_model(dev, seed=rank, max_seq=max_seq, engine=False if args.five_launch else (True if args.engine else None))
     ids = torch.randint(0, m.vocab - 1, (PROMPT,), generator=torch.Generator().manual_seed(rank)).to(dev)
     m.prefill(ids)                                  # un-timed (GeMV-mode protocol)
     m.capture()
@@ -427,6 +427,9 @@ def main():
                     help="3 (default): BASELINE.json configs[2], the headline decode metric; 4: configs[3], GeMM mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer-table", action="store_true")
+    ap.add_argument("--engine", action="store_true", help="A/B: decode steps through the one-launch-per-token engine")
+    ap.add_argument("--five-launch", action="store_true",
+                    help="A/B: decode steps as five launches per block instead of the one-launch-per-token engine")
     ap.add_argument("--no-mfma", action="store_true", help="skip the batched-path (MFMA) roofline and the dequantize rows")
     args = ap.parse_args()
     if args.steps is None:

@@ -139,4 +139,4 @@ def test_engine_refuses_what_it_does_not_run():
         QuantLlama(cfg, None, device="cuda:0", max_seq=4096, seed=0, engine=True)        # long caches: the split attention path
     with pytest.raises(ValueError, match="decode engine"):
         QuantLlama(cfg, None, device="cuda:0", max_seq=64, seed=0, batch=2, engine=True)
-    assert QuantLlama(cfg, None, device="cuda:0", max_seq=4096, seed=0).engine is None   # auto: falls back to five launches
+    assert QuantLlama(cfg, None, device="cuda:0", max_seq=4096, seed=0).engine is None   # auto: five launches
