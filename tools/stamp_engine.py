@@ -13,7 +13,7 @@ from amq_amd import _lib
 
 dev = torch.device("cuda:0")
 block = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-m, a, usage = bench.build_model(dev, seed=0, max_seq=64 + 64)
+m, a, usage = bench.build_model(dev, seed=0, max_seq=64 + 64, engine=True)
 lib = _lib.load()
 P = torch.cuda.get_device_properties(dev).multi_processor_count
 st = torch.zeros(P * 64, dtype=torch.int64, device=dev)
