@@ -98,3 +98,58 @@ def test_llama13b_block_batched_prompt_pass_at_config4_size():
     scale = own.float().abs().max()
     assert (own.float() - lib.float()).abs().max() <= 1e-2 * scale
     assert (own[5].float() - one[0].float()).abs().max() <= 1e-2 * scale
+
+
+# ---- BASELINE.json configs[1]: "Llama-2-7B uniform 4-bit (AWQ pack)" -- the reference formats' own arithmetic at size.
+# Buffers imported from the reference's GPTQ / AWQ caches carry MODE_FMA (w = fma(q, s, c), the CUDA kernels' dequant:
+# auto_gptq_kernel.cu:206, gemv_cuda.cu:151; module side hqq/backends/ft.py:103-145, autogptq.py:111-156).  The packed
+# buffers are built by the ORACLE's packers (numpy restatements pinned to the reference's captures in
+# tests/test_oracle_golden.py) from random integers, imported through amq_repack_from_awq / amq_repack_from_gptq, and the
+# GEMV is then checked at the three 7B layer shapes: weights bit-identical to the oracle's kernel dequant, GEMV == row 0 of
+# the MFMA GEMM == fp32 matmul on those weights, exact homogeneity, determinism.
+FMA_CASES = [(fmt, bits, n, k) for (n, k) in SHAPES[:3] for fmt, bits in (("awq", 4), ("gptq", 4), ("gptq", 3), ("gptq", 2))]
+
+
+@pytest.mark.parametrize("fmt,bits,n,k", FMA_CASES, ids=["%s%d-%dx%d" % c for c in FMA_CASES])
+def test_fullsize_reference_formats_fma_arithmetic(fmt, bits, n, k):
+    import numpy as np
+    from amq_amd import ops
+    from oracle import awq_ref, gptq_ref
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n + 3 * k + bits)
+    q = rng.integers(0, 2 ** bits, size=(n, k), dtype=np.uint8)
+    s = (rng.uniform(0.75, 1.25, size=(k // 128, n)) * 0.5 / (np.sqrt(k) * np.sqrt((4.0 ** bits - 1) / 12))).astype(np.float16)
+    z = rng.uniform((2 ** bits - 1) / 2 - 0.5, (2 ** bits - 1) / 2 + 0.5, size=(k // 128, n)).astype(np.float16)
+    if fmt == "awq":
+        qweight = awq_ref.pack_intweight(q)
+        scaled_zeros = (-(z.astype(np.float32) * s.astype(np.float32))).astype(np.float16)
+        qn, mn = ops.repack_from_awq(torch.from_numpy(qweight).to(dev), torch.from_numpy(s).to(dev),
+                                     torch.from_numpy(scaled_zeros).to(dev), n, k)
+        w_ref = awq_ref.dequant_kernel(qweight, s, scaled_zeros)
+    else:
+        qweight = gptq_ref.pack_qweight(q, bits)
+        scales = s.astype(np.float32)
+        zeros = (z.astype(np.float16) * s).astype(np.float32)                  # GPTQLinear.zeros = fp16(z * s) kept as fp32
+        qn, mn = ops.repack_from_gptq(torch.from_numpy(qweight).to(dev), torch.from_numpy(scales).to(dev),
+                                      torch.from_numpy(zeros).to(dev), bits, n, k)
+        w_ref = gptq_ref.dequant_kernel(qweight, scales, zeros, bits)
+    w = ops.dequantize(qn, mn, bits, ops.MODE_FMA, n, k)
+    assert np.array_equal(w.cpu().numpy().view(np.uint16), w_ref.view(np.uint16)), "weights differ from the reference kernels' fma dequant"
+    x = torch.randn(1, k, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).half()
+    y = ops.gemv(x, qn, mn, bits, ops.MODE_FMA, n, k)
+    xm = torch.cat([x, torch.randn(16, k, device=dev).half()])
+    ym = ops.gemm(xm, qn, mn, bits, ops.MODE_FMA, n, k)
+    rms = y.float().pow(2).mean().sqrt()
+    assert (y[0].float() - ym[0].float()).abs().max() <= 2.0 ** -9 * y.float().abs().max() + 1e-3 * rms
+    ref = x.float() @ w.float().t()
+    assert torch.all((y.float() - ref).abs() <= 1e-3 * ref.abs() + 1e-3 * rms)
+    y2 = ops.gemv(x * 2, qn, mn, bits, ops.MODE_FMA, n, k)
+    normal = y.float().abs() >= 2.0 ** -13
+    assert torch.equal(y2[normal], (y * 2)[normal])
+    assert torch.equal(ops.gemv(x, qn, mn, bits, ops.MODE_FMA, n, k), y)
+    # the module built from the same buffers dispatches to the same kernels
+    if fmt == "awq":
+        from amq_amd.quant_linear import HIPQuantLinear
+        mod = HIPQuantLinear.from_ft_buffers(torch.from_numpy(qweight).to(dev), torch.from_numpy(s).to(dev),
+                                             torch.from_numpy(scaled_zeros).to(dev))
+        assert mod.mode == ops.MODE_FMA and torch.equal(mod(x), y)
