@@ -1,0 +1,153 @@
+// amq_torch_ext.cpp -- host-side fast path of the drop-in modules: ONE call per forward, no ctypes marshalling.
+//
+// The reference's modules call pybind functions that take torch::Tensor arguments
+//   (auto_gptq.vecquant{2,3,4}matmul_faster_old: hqq/backends/autogptq.py:171-243; faster_transformer.gemv_4bit / gemm_4bit:
+//    hqq/backends/ft.py:129-145);
+// this is the same level of binding over libamq_hip.so's C ABI (include/amq_hip.h): the tensor checks, the output
+// allocation, the current-stream query and the library call happen in C++.  A HIPQuantLinear.forward through ctypes costs
+// ~10 us on the host (tools/module_walk_bench.py); through here ~3 us.
+// The library is NOT linked: init(path) dlopens it and resolves the entry points, so this file builds with g++ against the
+// torch headers alone (no HIP compiler, __graft_entry__.build()).  Every function raises (never falls back) on a bad argument
+// or a non-zero library status.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <dlfcn.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Segment { const void* qweight; const void* meta; const void* bias; const void* residual; void* y; int N, bits, mode, y_stride; };
+struct GemvOpts { int math, waves, depth, rpt, dot; };
+
+using linear_fn = int (*)(int, int, const void*, const void*, const void*, const void*, void*, int, int, int, int, void*);
+using grouped_fn = int (*)(const Segment*, int, const void*, const void*, const void*, float, int, int, int, int, int, const GemvOpts*, void*);
+using rmsnorm_fn = int (*)(const void*, const void*, void*, int, int, float, void*);
+using silu_mul_fn = int (*)(const void*, const void*, void*, size_t, void*);
+using err_fn = const char* (*)();
+
+void* g_lib = nullptr;
+linear_fn g_linear = nullptr;
+grouped_fn g_grouped = nullptr;
+rmsnorm_fn g_rmsnorm = nullptr;
+silu_mul_fn g_silu_mul = nullptr;
+err_fn g_err = nullptr;
+
+void need_lib() {
+    if (!g_lib) throw std::runtime_error("amq torch extension: init(path to libamq_hip.so) has not been called");
+}
+void check_rc(int rc, const char* what) {
+    if (rc != 0) throw std::runtime_error(std::string("libamq_hip ") + what + " failed (" + std::to_string(rc) + "): " + (g_err ? g_err() : ""));
+}
+void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+void check_x(const at::Tensor& x, int64_t K) {
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kHalf && x.is_contiguous(), "x: expected a contiguous fp16 tensor on the GPU");
+    TORCH_CHECK(x.dim() >= 1 && x.size(-1) == K, "x: last dim ", x.size(-1), " != K=", K);
+}
+void check_native(const at::Tensor& qw, const at::Tensor& mt, int64_t bits, int64_t N, int64_t K, const at::Tensor& x) {
+    TORCH_CHECK(bits >= 2 && bits <= 4 && N % 16 == 0 && K % 128 == 0, "bits must be 2..4, N % 16 == 0, K % 128 == 0");
+    TORCH_CHECK(qw.scalar_type() == at::kInt && qw.is_contiguous() && qw.numel() == N * K * bits / 32, "qweight: not a native payload of this shape");
+    TORCH_CHECK(mt.scalar_type() == at::kHalf && mt.is_contiguous() && mt.numel() == N * (K / 128) * 2, "meta: not a native meta buffer of this shape");
+    TORCH_CHECK(qw.device() == x.device() && mt.device() == x.device(), "x and the weights must be on the same device");
+}
+
+}  // namespace
+
+void init(const std::string& path) {
+    if (g_lib) return;
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!h) throw std::runtime_error(std::string("amq torch extension: cannot load ") + path + ": " + dlerror());
+    g_linear = (linear_fn)dlsym(h, "amq_linear_f16");
+    g_grouped = (grouped_fn)dlsym(h, "amq_gemv_grouped_f16");
+    g_rmsnorm = (rmsnorm_fn)dlsym(h, "amq_rmsnorm_f16");
+    g_silu_mul = (silu_mul_fn)dlsym(h, "amq_silu_mul_f16");
+    g_err = (err_fn)dlsym(h, "amq_last_error");
+    if (!g_linear || !g_grouped || !g_rmsnorm || !g_silu_mul || !g_err) throw std::runtime_error("amq torch extension: libamq_hip.so lacks an entry point");
+    g_lib = h;
+}
+
+// y[..., N] = x[..., K] . W^T (+ bias) for M = numel / K <= 8 rows (amq_linear_f16: the weight-streaming GEMV)
+at::Tensor linear(const at::Tensor& x, const at::Tensor& qweight, const at::Tensor& meta, const c10::optional<at::Tensor>& bias,
+                  int64_t bits, int64_t mode, int64_t N, int64_t K) {
+    need_lib();
+    check_x(x, K);
+    check_native(qweight, meta, bits, N, K, x);
+    const int64_t M = x.numel() / K;
+    TORCH_CHECK(M >= 1 && M <= 8, "linear: 1..8 rows (got ", M, "); more rows take ops.linear / ops.gemm");
+    if (bias) TORCH_CHECK(bias->scalar_type() == at::kHalf && bias->numel() == N && bias->device() == x.device(), "bias: fp16 [N] on x's device");
+    auto sizes = x.sizes().vec();
+    sizes.back() = N;
+    at::Tensor y = at::empty(sizes, x.options());
+    check_rc(g_linear((int)bits, (int)mode, x.data_ptr(), qweight.data_ptr(), meta.data_ptr(), bias ? bias->data_ptr() : nullptr,
+                      y.data_ptr(), (int)M, (int)N, (int)K, 128, stream_of(x)), "amq_linear_f16");
+    return y;
+}
+
+// several linears over the same x as segments of ONE launch (q/k/v, gate/up): amq_gemv_grouped_f16.  prologue 0 none,
+// 1 RMSNorm (aux = gamma [K], eps), 2 SiLU*mul (aux = up [.., K]).  Returns one output tensor per segment.
+std::vector<at::Tensor> grouped(const at::Tensor& x, const std::vector<at::Tensor>& qweights, const std::vector<at::Tensor>& metas,
+                                const std::vector<int64_t>& Ns, const std::vector<int64_t>& bits, const std::vector<int64_t>& modes,
+                                int64_t K, int64_t prologue, const c10::optional<at::Tensor>& aux, double eps) {
+    need_lib();
+    check_x(x, K);
+    const size_t n = qweights.size();
+    TORCH_CHECK(n >= 1 && n <= 4 && metas.size() == n && Ns.size() == n && bits.size() == n && modes.size() == n, "1..4 segments");
+    const int64_t M = x.numel() / K;
+    TORCH_CHECK(M >= 1 && M <= 16, "grouped: 1..16 rows (got ", M, ")");
+    Segment segs[4];
+    std::vector<at::Tensor> ys;
+    ys.reserve(n);
+    auto sizes = x.sizes().vec();
+    for (size_t i = 0; i < n; ++i) {
+        check_native(qweights[i], metas[i], bits[i], Ns[i], K, x);
+        sizes.back() = Ns[i];
+        ys.push_back(at::empty(sizes, x.options()));
+        segs[i] = Segment{qweights[i].data_ptr(), metas[i].data_ptr(), nullptr, nullptr, ys[i].data_ptr(), (int)Ns[i], (int)bits[i], (int)modes[i], 0};
+    }
+    const void* x2 = nullptr;
+    const void* gamma = nullptr;
+    if (prologue == 1) {
+        TORCH_CHECK(aux && aux->scalar_type() == at::kHalf && aux->numel() == K && aux->device() == x.device(), "RMSNorm prologue: gamma fp16 [K]");
+        gamma = aux->data_ptr();
+    } else if (prologue == 2) {
+        TORCH_CHECK(aux && aux->scalar_type() == at::kHalf && aux->numel() == x.numel() && aux->is_contiguous() && aux->device() == x.device(),
+                    "SiLU*mul prologue: up fp16 of x's shape");
+        x2 = aux->data_ptr();
+    } else {
+        TORCH_CHECK(prologue == 0, "unknown prologue");
+    }
+    check_rc(g_grouped(segs, (int)n, x.data_ptr(), x2, gamma, (float)eps, (int)prologue, (int)M, (int)K, 128, 0, nullptr, stream_of(x)),
+             "amq_gemv_grouped_f16");
+    return ys;
+}
+
+at::Tensor rmsnorm(const at::Tensor& x, const at::Tensor& gamma, double eps) {
+    need_lib();
+    const int64_t K = x.size(-1);
+    check_x(x, K);
+    TORCH_CHECK(gamma.scalar_type() == at::kHalf && gamma.numel() == K && gamma.device() == x.device(), "gamma: fp16 [K] on x's device");
+    at::Tensor y = at::empty_like(x);
+    check_rc(g_rmsnorm(x.data_ptr(), gamma.data_ptr(), y.data_ptr(), (int)(x.numel() / K), (int)K, (float)eps, stream_of(x)), "amq_rmsnorm_f16");
+    return y;
+}
+
+at::Tensor silu_mul(const at::Tensor& gate, const at::Tensor& up) {
+    need_lib();
+    TORCH_CHECK(gate.is_cuda() && gate.scalar_type() == at::kHalf && gate.is_contiguous() && up.scalar_type() == at::kHalf && up.is_contiguous() &&
+                    up.numel() == gate.numel() && up.device() == gate.device() && gate.numel() % 8 == 0,
+                "silu_mul: two contiguous fp16 tensors of one size (a multiple of 8) on one device");
+    at::Tensor y = at::empty_like(gate);
+    check_rc(g_silu_mul(gate.data_ptr(), up.data_ptr(), y.data_ptr(), (size_t)gate.numel(), stream_of(gate)), "amq_silu_mul_f16");
+    return y;
+}
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.def("init", &init, "dlopen libamq_hip.so and resolve the entry points");
+    m.def("linear", &linear, "y = x . W^T (+ bias), 1..8 rows");
+    m.def("grouped", &grouped, "several linears over one x in one launch");
+    m.def("rmsnorm", &rmsnorm);
+    m.def("silu_mul", &silu_mul);
+}

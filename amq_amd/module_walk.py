@@ -11,8 +11,8 @@ modules, eager and captured into a hipGraph.
 import torch
 import torch.nn as nn
 
-from . import ops
-from .quant_linear import HIPQuantLinear
+from . import _ext, ops
+from .quant_linear import HIPLlamaMLP, HIPQuantLinear
 
 
 class _RMSNorm(nn.Module):
@@ -21,6 +21,9 @@ class _RMSNorm(nn.Module):
         self.weight, self.eps = weight, eps
 
     def forward(self, x):
+        ext = _ext.get()
+        if ext is not None:
+            return ext.rmsnorm(x, self.weight, self.eps)
         return ops.rmsnorm(x, self.weight, self.eps)
 
 
@@ -41,12 +44,17 @@ class _Attention(nn.Module):
 
 
 class _MLP(nn.Module):
+    """LlamaMLP as HF writes it (what an unfused swap leaves)"""
+
     def __init__(self, blk):
         super().__init__()
         self.gate_proj, self.up_proj, self.down_proj = (_module_of(blk["mlp." + n]) for n in ("gate_proj", "up_proj", "down_proj"))
+        self.act_fn = nn.SiLU()
 
     def forward(self, h):
-        return self.down_proj(ops.silu_mul(self.gate_proj(h), self.up_proj(h)))      # act_fn(gate) * up, LlamaMLP
+        ext = _ext.get()
+        g, u = self.gate_proj(h), self.up_proj(h)
+        return self.down_proj(ext.silu_mul(g, u) if ext is not None else ops.silu_mul(g, u))      # act_fn(gate) * up, LlamaMLP
 
 
 class _Block(nn.Module):
@@ -73,13 +81,17 @@ class ModuleWalkLlama(nn.Module):
     """HF-shaped decoder stack over a QuantLlama's weights, caches and step state (``runner`` keeps owning them: prefill
     with the runner, then step with either)."""
 
-    def __init__(self, runner):
+    def __init__(self, runner, group_siblings=True):
         super().__init__()
         if getattr(runner, "B", 1) != 1:
             raise ValueError("the module walk mirrors the reference's batch-1 step")
         self.r = runner
         self.layers = nn.ModuleList(_Block(blk, runner) for blk in runner.blocks)
         self.graph = None
+        if group_siblings:                      # what prepare_for_inference(backend="hip") does to a swapped model
+            from .patching import fuse_llama_mlps, group_sibling_linears
+            group_sibling_linears(self)
+            fuse_llama_mlps(self)
 
     @torch.inference_mode()
     def _step(self):
@@ -91,7 +103,7 @@ class ModuleWalkLlama(nn.Module):
         ops.decode_tail(r.logits, r.embed, r.token, r.pos, r.x, table=r.rope_tab, cur=r.rope_cur)
 
     def n_module_calls(self):
-        return sum(1 for m in self.modules() if isinstance(m, (HIPQuantLinear, _RMSNorm, _Attention, _MLP, _Block)))
+        return sum(1 for m in self.modules() if isinstance(m, (HIPQuantLinear, HIPLlamaMLP, _RMSNorm, _Attention, _MLP, _Block)))
 
     def capture(self):
         if self.graph is not None:

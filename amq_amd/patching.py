@@ -20,7 +20,10 @@ import os
 import torch
 
 from .hqq_format import HQQWeights, from_hqq_layer
-from .quant_linear import HIPQuantLinear
+from .quant_linear import HIPLlamaMLP, HIPQuantLinear, LinearGroup
+
+# sibling linears of one parent module that read the same input (HF LlamaAttention / LlamaMLP attribute names)
+SIBLING_GROUPS = (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))
 
 HIP_BACKENDS = ("hip", "gptq", "ft")
 
@@ -110,8 +113,42 @@ def _walk_hip(model, fct):
             _walk_hip(layer, fct)
 
 
-def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False, load_path=None):
-    """patching.py:143-223 for the HIP backend."""
+def group_sibling_linears(model):
+    """Install a :class:`LinearGroup` wherever a module holds HIPQuantLinear children named like one of SIBLING_GROUPS with equal
+    input sizes: their few-row forwards then run as ONE grouped launch.  Returns the number of groups made.  The modules
+    themselves (buffers, state_dict keys) are not changed."""
+    made = 0
+    for parent in model.modules():
+        for names in SIBLING_GROUPS:
+            mods = [getattr(parent, n, None) for n in names]
+            if all(isinstance(m, HIPQuantLinear) for m in mods) and len({m.infeatures for m in mods}) == 1 \
+                    and not any("_group" in m.__dict__ for m in mods):
+                LinearGroup(mods)
+                made += 1
+    return made
+
+
+def fuse_llama_mlps(model):
+    """Replace every SiLU-gated MLP whose gate / up / down projections are (bias-free) HIPQuantLinear modules by
+    :class:`HIPLlamaMLP` (two launches per few-row forward).  Recognised by structure: children ``gate_proj``, ``up_proj``,
+    ``down_proj`` and an ``act_fn`` that is SiLU.  Returns the number of modules replaced."""
+    n = 0
+    for parent in list(model.modules()):
+        for name, mod in list(parent.named_children()):
+            if isinstance(mod, HIPLlamaMLP):
+                continue
+            kids = [getattr(mod, k, None) for k in ("gate_proj", "up_proj", "down_proj")]
+            act = getattr(mod, "act_fn", None)
+            is_silu = isinstance(act, torch.nn.SiLU) or type(act).__name__ in ("SiLUActivation", "SiLU")
+            if all(isinstance(k, HIPQuantLinear) and k.bias is None for k in kids) and is_silu:
+                setattr(parent, name, HIPLlamaMLP(*kids))
+                n += 1
+    return n
+
+
+def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False, load_path=None, group_siblings=True, fuse_mlp=True):
+    """patching.py:143-223 for the HIP backend.  ``group_siblings`` (default on; not in the reference): q/k/v and gate/up
+    siblings are additionally tied into grouped launches (group_sibling_linears)."""
     if backend not in HIP_BACKENDS:
         raise RuntimeError(f"backend '{backend}' is not available in amq_amd (use one of {HIP_BACKENDS})")
     if allow_merge:
@@ -128,6 +165,10 @@ def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False
         print("No load_path provided, using the model as is")
         patch_linearlayers(model, patch_hqq_to_hip, verbose=verbose)
     _walk_hip(model, patch_add_weight_param)
+    if group_siblings:
+        group_sibling_linears(model)
+    if fuse_mlp:                      # (not in the reference's generic patcher; its FT path swaps whole Llama sub-modules too)
+        fuse_llama_mlps(model)
     return model
 
 

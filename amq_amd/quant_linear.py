@@ -14,11 +14,73 @@ weight-streaming GEMV, many rows the tiled MFMA GEMM (the reference switches at
 rows < 128, autogptq.py:163, and tokens < 8, ft.py:129).  There is no eager /
 CPU fallback: without a GPU or the built library, forward raises.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
-from . import _lib, ops
+from . import _ext, _lib, ops
 from .hqq_format import GROUP, HQQWeights, from_hqq_layer, pack_rows
+
+GROUP_MAX_ROWS = 8          # few-row forwards of grouped siblings run as ONE grouped GEMV launch (more rows: each member's GEMM)
+
+
+class LinearGroup:
+    """Sibling linears that read the SAME input -- q/k/v of an attention block, gate/up of an MLP -- as segments of ONE
+    ``amq_gemv_grouped_f16`` launch (each with its own bit-width), without touching the parent module: HF's forward keeps calling
+    ``self.q_proj(h)``, ``self.k_proj(h)``, ``self.v_proj(h)`` (modeling_llama.py; amq_speed_benchmark.py:231-256 only swaps the
+    linears).  The first member called with a tensor launches all segments and keeps the siblings' outputs; the siblings' calls
+    with that same tensor (same storage, version, shape) take theirs -- each output is handed out once.  The members stay
+    ordinary modules with their own buffers, so state_dict keys, ``.to()`` and the reference's cache files are unchanged.
+    What it buys (tools/module_walk_bench.py): 13 -> 10 launches per block for a module swap alone."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        if len({m.infeatures for m in self.members}) != 1:
+            raise ValueError("grouped linears must share their input size")
+        self._key = None
+        self._xref = None
+        self._outs = [None] * len(self.members)
+        for i, m in enumerate(self.members):
+            m.__dict__["_group"] = (self, i)
+
+    def __deepcopy__(self, memo):
+        # (copy.deepcopy of the model: amq_speed_benchmark.py:231) the copy groups the COPIED members
+        import copy
+        new = LinearGroup.__new__(LinearGroup)
+        memo[id(self)] = new
+        new.members = [copy.deepcopy(m, memo) for m in self.members]
+        new._key, new._outs, new._xref = None, [None] * len(new.members), None
+        for i, m in enumerate(new.members):
+            m.__dict__["_group"] = (new, i)
+        return new
+
+    def take(self, idx, x):
+        """output of member ``idx`` for input ``x`` (fp16, GPU, <= GROUP_MAX_ROWS rows), launching the group if needed"""
+        # "the same input": the same live tensor OBJECT (weak reference), same storage and shape, and -- where autograd tracks it
+        # (inference tensors do not) -- the same version
+        key = (x.data_ptr(), -1 if x.is_inference() else x._version, tuple(x.shape))
+        same = self._key == key and self.__dict__.get("_xref") is not None and self._xref() is x
+        if not same or self._outs[idx] is None:
+            ms = self.members
+            if any(m.bias is not None for m in ms) or any(m.qweight.device != x.device for m in ms):
+                return None
+            x2 = x if x.is_contiguous() else x.contiguous()
+            ext = _ext.get()
+            K = ms[0].infeatures
+            if ext is not None:
+                outs = ext.grouped(x2, [m.qweight for m in ms], [m.meta for m in ms], [m.outfeatures for m in ms],
+                                   [m.bits for m in ms], [m.mode for m in ms], K, 0, None, 0.0)
+            else:
+                outs = [torch.empty(x.shape[:-1] + (m.outfeatures,), dtype=torch.float16, device=x.device) for m in ms]
+                ops.gemv_grouped(x2, [dict(qn=m.qweight, mn=m.meta, bits=m.bits, mode=m.mode, N=m.outfeatures, y=y.view(-1, m.outfeatures))
+                                      for m, y in zip(ms, outs)], K)
+            self._outs = list(outs)
+            self._key = key
+            self._xref = weakref.ref(x)
+        y = self._outs[idx]
+        self._outs[idx] = None
+        return y
 
 
 class HIPQuantLinear(nn.Module):
@@ -158,9 +220,18 @@ class HIPQuantLinear(nn.Module):
         if M > 8 or M == 0 or not x.is_cuda:        # many rows: the GEMM route (workspace handling lives in ops.gemm)
             out = ops.linear(x, self.qweight, self.meta, self.bits, self.mode, N, K, bias=self.bias)
             return out if x_dtype == torch.float16 else out.to(x_dtype)
-        # few rows (decode): one ctypes call, no per-call re-validation of the module's own buffers
         if x.device != self.qweight.device:
             raise ValueError(f"x is on {x.device} but the module's weights are on {self.qweight.device}")
+        grp = self.__dict__.get("_group")
+        if grp is not None and M <= GROUP_MAX_ROWS:  # q/k/v, gate/up: one grouped launch for all siblings (LinearGroup)
+            y = grp[0].take(grp[1], x)
+            if y is not None:
+                return y if x_dtype == torch.float16 else y.to(x_dtype)
+        ext = _ext.get()
+        if ext is not None:                          # one C++ call: checks, output allocation, stream query, amq_linear_f16
+            y = ext.linear(x if x.is_contiguous() else x.contiguous(), self.qweight, self.meta, self.bias, self.bits, self.mode, N, K)
+            return y if x_dtype == torch.float16 else y.to(x_dtype)
+        # few rows (decode) through ctypes: one call, no per-call re-validation of the module's own buffers
         qp, mp, bp = self._buffer_ptrs()
         x2 = x if x.is_contiguous() else x.contiguous()
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float16, device=x.device)
@@ -178,3 +249,39 @@ class HIPQuantLinear(nn.Module):
     def extra_repr(self):
         return (f"in_features={self.infeatures}, out_features={self.outfeatures}, bits={self.bits}, "
                 f"group_size={self.group_size}, bias={self.bias is not None}, mode={self.mode}")
+
+
+class HIPLlamaMLP(nn.Module):
+    """LlamaMLP over three HIPQuantLinear children -- ``down_proj(act_fn(gate_proj(x)) * up_proj(x))`` with act_fn = SiLU
+    (transformers modeling_llama.py) -- as TWO launches for few rows: gate / up as segments of one grouped GEMV, then down_proj
+    with the SiLU * mul product formed in its prologue (``AMQ_PRO_SILU_MUL``: the same fp16 expression as the separate
+    element-wise kernel, so the result is bit-identical to the unfused walk).  The reference's FT path replaces whole Llama
+    sub-modules in the same way (kernel/monkeypatch/ftllama_modeling.py:39-46, 127-155).  The children keep their names, so
+    state_dict keys (``mlp.gate_proj.qweight`` ...) and the cache files do not change.  More than GROUP_MAX_ROWS rows, biases
+    or non-fp16 inputs take the plain composition."""
+
+    def __init__(self, gate_proj, up_proj, down_proj):
+        super().__init__()
+        self.gate_proj, self.up_proj, self.down_proj = gate_proj, up_proj, down_proj
+
+    def forward(self, x):
+        g_, u_, d_ = self.gate_proj, self.up_proj, self.down_proj
+        K = g_.infeatures
+        if (x.dtype is torch.float16 and x.is_cuda and x.shape[-1] == K and 0 < x.numel() // K <= GROUP_MAX_ROWS
+                and g_.bias is None and u_.bias is None and d_.bias is None and x.device == g_.qweight.device):
+            x2 = x if x.is_contiguous() else x.contiguous()
+            ext = _ext.get()
+            if ext is not None:
+                g, u = ext.grouped(x2, [g_.qweight, u_.qweight], [g_.meta, u_.meta], [g_.outfeatures, u_.outfeatures],
+                                   [g_.bits, u_.bits], [g_.mode, u_.mode], K, 0, None, 0.0)
+                return ext.grouped(g, [d_.qweight], [d_.meta], [d_.outfeatures], [d_.bits], [d_.mode], d_.infeatures, 2, u, 0.0)[0]
+            I = g_.outfeatures
+            g = torch.empty(x.shape[:-1] + (I,), dtype=torch.float16, device=x.device)
+            u = torch.empty_like(g)
+            ops.gemv_grouped(x2, [dict(qn=g_.qweight, mn=g_.meta, bits=g_.bits, mode=g_.mode, N=I, y=g.view(-1, I)),
+                                  dict(qn=u_.qweight, mn=u_.meta, bits=u_.bits, mode=u_.mode, N=I, y=u.view(-1, I))], K)
+            y = torch.empty(x.shape[:-1] + (d_.outfeatures,), dtype=torch.float16, device=x.device)
+            ops.gemv_grouped(g.view(-1, I), [dict(qn=d_.qweight, mn=d_.meta, bits=d_.bits, mode=d_.mode, N=d_.outfeatures,
+                                                  y=y.view(-1, d_.outfeatures))], I, prologue=ops.PRO_SILU_MUL, x2=u.view(-1, I))
+            return y
+        return d_(torch.nn.functional.silu(g_(x)) * u_(x))

@@ -1,0 +1,90 @@
+"""The reference's actual caller shape (VERDICT r2 missing #2): an HF ``LlamaForCausalLM`` whose seven linears per block are
+swapped by ``prepare_for_inference`` and then driven by HF's own forward (amq/amq_speed_benchmark.py:137-139, 152, 231-256;
+hqq/utils/patching.py:143-223).  A tiny random model (no network); the oracle side is the SAME HF model with nn.Linear layers
+holding the oracle's dequantized fp16 weights."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+transformers = pytest.importorskip("transformers")
+
+
+def _tiny_llama(n_kv_heads):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                      num_key_value_heads=n_kv_heads, vocab_size=1000, max_position_embeddings=256, rms_norm_eps=1e-5,
+                      attn_implementation="eager")
+    torch.manual_seed(0)
+    return LlamaForCausalLM(cfg).to(torch.float16).to("cuda:0").eval()
+
+
+def _quantize_linears(model, bits_cycle=(4, 2, 3, 3, 2, 4, 3)):
+    """replace every decoder linear by an HQQ stand-in (random HQQ weights of the layer's shape); returns the model and a
+    reference copy whose nn.Linear weights are the ORACLE's dequantized weights"""
+    from amq_amd.hqq_format import random_hqq
+    from amq_amd.patching import HQQWeightsModule
+    from oracle import hqq_ref
+    ref = copy.deepcopy(model)
+    names = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+    i = 0
+    for layer, rlayer in zip(model.model.layers, ref.model.layers):
+        for parent, rparent in ((layer.self_attn, rlayer.self_attn), (layer.mlp, rlayer.mlp)):
+            for name in names:
+                lin = getattr(parent, name, None)
+                if lin is None:
+                    continue
+                n, k = lin.weight.shape
+                bits = bits_cycle[i % len(bits_cycle)]
+                h = random_hqq(n, k, bits, seed=100 + i)
+                i += 1
+                w = hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (n, k))
+                getattr(rparent, name).weight.data = torch.from_numpy(w.astype(np.float16)).to("cuda:0")
+                setattr(parent, name, HQQWeightsModule(h.to(torch.device("cuda:0"))))
+    return model, ref
+
+
+@pytest.mark.parametrize("n_kv_heads", [2, 1])
+@pytest.mark.parametrize("seq", [1, 5, 24])
+def test_hf_llama_with_swapped_linears_matches_oracle_weights(n_kv_heads, seq):
+    from amq_amd.patching import prepare_for_inference
+    from amq_amd.quant_linear import HIPQuantLinear
+    model, ref = _quantize_linears(_tiny_llama(n_kv_heads))
+    prepare_for_inference(model, backend="hip")
+    from amq_amd.quant_linear import HIPLlamaMLP
+    assert sum(isinstance(m, HIPLlamaMLP) for m in model.modules()) == 2          # both decoder MLPs fused (SiLU-gated, bias-free)
+    mods = [m for m in model.modules() if isinstance(m, HIPQuantLinear)]
+    assert len(mods) == 14 and all("_group" in m.__dict__ for m in mods if m.name in ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj"))
+    ids = torch.randint(0, 1000, (1, seq), generator=torch.Generator().manual_seed(seq)).to("cuda:0")
+    with torch.inference_mode():
+        y = model(ids).logits.float()
+        y_ref = ref(ids).logits.float()
+    assert torch.isfinite(y).all()
+    # HF's own fp16 matmuls on the oracle weights accumulate in a different order: logits agree to fp16 rounding of the stack
+    assert (y - y_ref).abs().max() <= 2e-2 * y_ref.abs().max()
+    # grouped and ungrouped swaps are the same function, bit for bit (one launch vs three: same kernel per segment)
+    model2, _ = _quantize_linears(_tiny_llama(n_kv_heads))
+    prepare_for_inference(model2, backend="hip", group_siblings=False, fuse_mlp=False)
+    with torch.inference_mode():
+        y2 = model2(ids).logits.float()
+    assert torch.equal(y, y2)
+
+
+def test_hf_swapped_model_survives_deepcopy_and_state_dict_roundtrip(tmp_path):
+    """amq_speed_benchmark.py:231 deep-copies the patched model; patching.py:178-208 caches its state_dict"""
+    from amq_amd.patching import prepare_for_inference
+    model, _ = _quantize_linears(_tiny_llama(2))
+    cache = str(tmp_path / "tiny_HIPLinear.pt")
+    prepare_for_inference(model, backend="hip", load_path=cache)          # writes the cache
+    ids = torch.randint(0, 1000, (1, 3), generator=torch.Generator().manual_seed(9)).to("cuda:0")
+    with torch.inference_mode():
+        y = model(ids).logits.clone()
+        y_copy = copy.deepcopy(model)(ids).logits
+    assert torch.equal(y, y_copy)
+    fresh, _ = _quantize_linears(_tiny_llama(2))
+    prepare_for_inference(fresh, backend="hip", load_path=cache)          # loads it instead of re-packing
+    with torch.inference_mode():
+        assert torch.equal(fresh(ids).logits, y)
+    assert any(k.endswith("q_proj.qweight") for k in model.state_dict())  # per-linear keys, as in the reference's caches

@@ -13,8 +13,9 @@ from amq_amd.module_walk import ModuleWalkLlama
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device("cuda:0")
-m, a, usage = bench.build_model(dev, max_seq=64 + 8 * steps + 64)
-mw = ModuleWalkLlama(m)
+m, a, usage = bench.build_model(dev, max_seq=64 + 12 * steps + 64)
+mw = ModuleWalkLlama(m)                       # q/k/v and gate/up grouped, as prepare_for_inference(backend="hip") leaves a swapped model
+mw_plain = ModuleWalkLlama(m, group_siblings=False)
 ids = torch.randint(0, m.vocab - 1, (64,), generator=torch.Generator().manual_seed(0)).to(dev)
 
 
@@ -42,6 +43,10 @@ out["logit_distance_runner_vs_walk"] = float((la - lb).abs().max() / la.abs().ma
 out["runner_graph_tokens_per_s"] = run(lambda: m.decode_step(True), steps)
 out["module_walk_eager_tokens_per_s"] = run(lambda: mw.decode_step(False), steps)
 out["module_walk_graph_tokens_per_s"] = run(lambda: mw.decode_step(True), steps)
+out["module_walk_ungrouped_eager_tokens_per_s"] = run(lambda: mw_plain.decode_step(False), steps)
+out["module_walk_ungrouped_graph_tokens_per_s"] = run(lambda: mw_plain.decode_step(True), steps)
+from amq_amd import _ext
+out["torch_extension"] = _ext.get() is not None
 # host cost of one forward (no device wait in the loop: measures the enqueue path; the queue is drained every 512 calls)
 lin = mw.layers[0].self_attn.o_proj
 x = torch.randn(1, m.H, device=dev).half()
