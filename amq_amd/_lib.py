@@ -86,6 +86,7 @@ SIGNATURES = {
     "amq_attn_prefill_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 10 + [_vp]),
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_cache_batch_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "amq_gemv_qkv_attn_f16": (_i, [ctypes.POINTER(Segment), _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "amq_decode_engine_image_bytes": (_sz, [_i]),
     "amq_decode_engine_scratch_bytes": (_sz, [_i, _i, _i]),
     "amq_decode_engine_sync_bytes": (_sz, []),

@@ -286,6 +286,31 @@ int amq_gemm_xfrag_grouped_f16(const amq_segment* segs, int nseg, const void* xf
     return check_hip(amq::launch_gemm_xfrag_grouped(xf, M, K, gs, nseg, (hipStream_t)stream), "gemm_xfrag_grouped");
 }
 
+int amq_gemv_qkv_attn_f16(const amq_segment* segs, const void* x, const void* gamma, float eps, int K, int group, void* kcache,
+                          void* vcache, void* out, const void* step_state, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                          void* tickets, void* stream) {
+    if (!segs || !x || !gamma || !kcache || !vcache || !out || !step_state || !tickets) return fail(AMQ_EINVAL, "null pointer");
+    if (head_dim != 128) return fail(AMQ_ESHAPE, "head_dim must be 128 (got %d)", head_dim);
+    if (n_heads < 1 || n_kv_heads < 1 || (n_heads % n_kv_heads) != 0 || n_heads > 255) return fail(AMQ_ESHAPE, "bad head counts %d / %d", n_heads, n_kv_heads);
+    if (K > 8192) return fail(AMQ_ESHAPE, "K = %d: the fused launch serves K <= 8192", K);
+    if (max_seq < 1 || amq::gemv_qkv_attn_lds_bytes(K, max_seq) > LDS_LIMIT) return fail(AMQ_ESHAPE, "max_seq=%d too long for the single-pass decode attention", max_seq);
+    const int Ns[3] = {n_heads * 128, n_kv_heads * 128, n_kv_heads * 128};
+    amq::GemvArgs a{};
+    for (int i = 0; i < 3; ++i) {
+        const amq_segment& s = segs[i];
+        if (int rc = check_shape(s.bits, s.N, K, group)) return rc;
+        if (int rc = check_mode(s.mode)) return rc;
+        if (s.N != Ns[i]) return fail(AMQ_ESHAPE, "segment %d: N = %d, expected %d", i, s.N, Ns[i]);
+        if (!s.qweight_native || !s.meta_native || !s.y) return fail(AMQ_EINVAL, "segment %d: null pointer", i);
+        if (s.bias || s.residual) return fail(AMQ_EUNSUPPORTED, "segment %d: bias / residual are not part of the fused q/k/v + attention launch", i);
+        amq::GemvSeg& d = a.seg[i];
+        d.qweight = s.qweight_native; d.meta = s.meta_native; d.y = s.y; d.N = s.N; d.bits = s.bits; d.mode = s.mode; d.y_stride = s.N;
+    }
+    a.nseg = 3; a.M = 1; a.K = K; a.x_stride = K; a.x = x; a.gamma = gamma; a.eps = eps; a.prologue = amq::PRO_RMSNORM;
+    amq::AttnArgs t{segs[0].y, segs[1].y, segs[2].y, kcache, vcache, out, nullptr, 0, n_heads, n_kv_heads, max_seq, 10000.0f, nullptr, step_state};
+    return check_hip(amq::launch_gemv_qkv_attn(a, t, (int*)tickets, (hipStream_t)stream), "gemv_qkv_attn");
+}
+
 size_t amq_decode_engine_image_bytes(int n_block) { return n_block > 0 ? amq::engine_image_bytes(n_block) : 0; }
 size_t amq_decode_engine_scratch_bytes(int hidden, int inter, int n_kv_heads) {
     if (hidden < 1 || inter < 1 || n_kv_heads < 1) return 0;

@@ -134,6 +134,11 @@ hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, 
 hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                             int N, int K, hipStream_t st, int M = 1);      // x [M, K], y [M, N], M <= 8
 
+// q / k / v GEMV + decode attention in one launch (amq_gemv.hip): a's segments 0 .. 2 = q, k, v (M = 1, RMSNorm prologue, gamma / eps
+// set); t: caches, output, step-state block (rope_cur), head counts, max_seq; tickets: int32 [n_heads], zero before and after
+hipError_t launch_gemv_qkv_attn(GemvArgs& a, const AttnArgs& t, int* tickets, hipStream_t st);
+size_t gemv_qkv_attn_lds_bytes(int K, int max_seq);
+
 // one decode token as one persistent launch (amq_engine.hip)
 struct EngineDesc {
     const void* blocks_dev;   // device image of the per-block table (engine_fill_image)

@@ -63,6 +63,10 @@ class QuantLlama:
     # single-workgroup-per-head attention regime (the same bound as ops.ATTN_SPLIT_FROM); otherwise, and with engine=False, as
     # five launches per block
     ENGINE_MAX_SEQ = 512
+    # q/k/v + attention of a block as ONE launch (ops.gemv_qkv_attn; batch 1, short cache, hidden <= 8192): 4 launches per block
+    # instead of 5.  Built, bit-identical (tests/test_gpu_qkv_attn.py) and SLOWER -- 15.7 us per fused launch against 9.2 + 5.1,
+    # 755 vs 830 tokens/s (profiles/r03_qkv_attn_fused_negative.txt) -- so it is off unless a caller sets fuse_qkv_attn.
+    FUSE_QKV_ATTN = False
     ENGINE_DEFAULT = False      # what engine=None means (the engine is opt-in until it beats the five-launch step: DESIGN.md 4)
 
     def __init__(self, config, arch_linear=None, device="cuda:0", max_seq=256, seed=0, synthetic=True,
@@ -146,6 +150,9 @@ class QuantLlama:
         self.graph = None
         self.host_pos = 0          # host mirror of self.pos (decode_step refuses to run past the cache without a device sync)
         self._down_rows_fit = self.B <= ops.gemv_max_rows(self.I)
+        self.can_fuse_qkv_attn = self.B == 1 and max_seq <= ops.ATTN_SPLIT_FROM and self.H <= 8192
+        self.fuse_qkv_attn = self.FUSE_QKV_ATTN and self.can_fuse_qkv_attn
+        self._tickets = torch.zeros(max(self.nh, 64), dtype=torch.int32, device=dev)
         eligible = self.B == 1 and max_seq <= self.ENGINE_MAX_SEQ and self.H == self.nh * 128
         if engine and not eligible:
             raise ValueError("the decode engine needs batch 1 and max_seq <= %d" % self.ENGINE_MAX_SEQ)
@@ -178,11 +185,16 @@ class QuantLlama:
             ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
             return
         for blk in self.blocks:
-            ops.gemv_grouped(self.x, [blk["self_attn.q_proj"].seg(self.q), blk["self_attn.k_proj"].seg(self.k),
-                                      blk["self_attn.v_proj"].seg(self.v)], H, prologue=ops.PRO_RMSNORM,
-                             gamma=blk["ln1"], eps=self.eps)
-            ops.attn_decode(self.q, self.k, self.v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, self.theta,
-                            cur=self.rope_cur)
+            if self.fuse_qkv_attn:
+                ops.gemv_qkv_attn(self.x, [blk["self_attn.q_proj"].seg(self.q.view(-1)), blk["self_attn.k_proj"].seg(self.k.view(-1)),
+                                           blk["self_attn.v_proj"].seg(self.v.view(-1))], H, blk["ln1"], self.eps, blk["kc"], blk["vc"],
+                                  self.att.view(-1), self.rope_cur, self.nh, self.nkv, self._tickets)
+            else:
+                ops.gemv_grouped(self.x, [blk["self_attn.q_proj"].seg(self.q), blk["self_attn.k_proj"].seg(self.k),
+                                          blk["self_attn.v_proj"].seg(self.v)], H, prologue=ops.PRO_RMSNORM,
+                                 gamma=blk["ln1"], eps=self.eps)
+                ops.attn_decode(self.q, self.k, self.v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, self.theta,
+                                cur=self.rope_cur)
             ops.gemv_grouped(self.att, [blk["self_attn.o_proj"].seg(self.x, residual=self.x)], H)
             ops.gemv_grouped(self.x, [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H,
                              prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=self.eps)

@@ -579,6 +579,32 @@ def check_step_state(err):
         raise _lib.AmqError("a decode step ran with its position outside the KV cache (step skipped on the device)")
 
 
+def gemv_qkv_attn(x, segments, K, gamma, eps, kcache, vcache, out, cur, n_heads, n_kv_heads, tickets):
+    """q / k / v GEMV (RMSNorm prologue) + decode attention of one block as ONE launch (include/amq_hip.h: amq_gemv_qkv_attn_f16).
+    segments: three dicts {qn, mn, bits, mode, N, y} (q, k, v; y fp16 [N]); caches [1, n_kv_heads, max_seq, 128]; ``cur``: the
+    fp16 [128] view of a step-state block; ``tickets``: int32 [>= n_heads], zero (left zero)."""
+    xx = _prep_x(x, K)
+    if xx.shape[0] != 1 or len(segments) != 3:
+        raise ValueError("one row, three segments (q, k, v)")
+    arr = (Segment * 3)()
+    for i, s in enumerate(segments):
+        _check_shape(s["bits"], s["N"], K)
+        _check_native(s["qn"], s["mn"], s["bits"], s["N"], K)
+        _need(s["y"], torch.float16, "y", s["N"])
+        arr[i] = Segment(_lib.ptr(s["qn"]), _lib.ptr(s["mn"]), None, None, _lib.ptr(s["y"]), s["N"], s["bits"], s["mode"], 0)
+    max_seq = kcache.shape[2]
+    _need(gamma, torch.float16, "gamma", K)
+    _need(kcache, torch.float16, "kcache", n_kv_heads * max_seq * 128)
+    _need(vcache, torch.float16, "vcache", n_kv_heads * max_seq * 128)
+    _need(out, torch.float16, "out", n_heads * 128)
+    _need(cur, torch.float16, "rope_cur", 128)
+    if tickets.dtype != torch.int32 or tickets.numel() < n_heads or not tickets.is_cuda:
+        raise ValueError("tickets: int32 [n_heads] on the GPU")
+    _lib.check(_lib.load().amq_gemv_qkv_attn_f16(arr, _lib.ptr(xx), _lib.ptr(gamma), ctypes.c_float(eps), K, GROUP, _lib.ptr(kcache),
+                                                 _lib.ptr(vcache), _lib.ptr(out), _lib.ptr(cur), n_heads, n_kv_heads, 128, max_seq,
+                                                 _lib.ptr(tickets), _lib.current_stream()))
+
+
 ENGINE_LINEARS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj",
                   "mlp.down_proj")
 

@@ -279,6 +279,8 @@ def run_decode(args, rep, dev):
     rank, n_gpus = rep.rank, rep.world
     max_seq = PROMPT + args.warmup + args.steps + 8
     m, a, usage = build_model(dev, seed=rank, max_seq=max_seq, engine=False if args.five_launch else (True if args.engine else None))
+    if args.fuse_qkv_attn:
+        m.fuse_qkv_attn = True
     ids = torch.randint(0, m.vocab - 1, (PROMPT,), generator=torch.Generator().manual_seed(rank)).to(dev)
     m.prefill(ids)                                  # un-timed (GeMV-mode protocol)
     m.capture()
@@ -428,6 +430,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer-table", action="store_true")
     ap.add_argument("--engine", action="store_true", help="A/B: decode steps through the one-launch-per-token engine")
+    ap.add_argument("--fuse-qkv-attn", action="store_true", help="A/B: q/k/v + attention of a block as one launch (4 launches per block)")
     ap.add_argument("--five-launch", action="store_true",
                     help="A/B: decode steps as five launches per block instead of the one-launch-per-token engine")
     ap.add_argument("--no-mfma", action="store_true", help="skip the batched-path (MFMA) roofline and the dequantize rows")

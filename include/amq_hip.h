@@ -309,6 +309,16 @@ int amq_attn_prefill_f16(const void* q, const void* k, const void* v, void* out,
 int amq_attn_prefill_xfrag_f16(const void* q, const void* k, const void* v, void* out_xf, int S, int pos0, int n_heads,
                                int n_kv_heads, int head_dim, long long q_rstride, long long k_rstride, long long k_hstride,
                                long long v_rstride, long long v_hstride, void* stream);
+/* q / k / v projections + decode attention of one block in ONE launch (batch 1): segments[0..2] = q, k, v exactly as for
+ * amq_gemv_grouped_f16 with AMQ_PRO_RMSNORM (their y = the q / k / v vectors, still written), then amq_attn_decode_cur_f16's step
+ * inside the same kernel: the workgroups that produce a head's 24 row-tiles arrive on that head's ticket, the workgroup owning
+ * the head's first q row-tile waits for it (bounded) and runs the attention.  out, the cache rows and the q / k / v vectors are
+ * bit-identical to the two separate calls.  tickets: int32 [n_heads], zero before the first call (each call leaves them zero).
+ * K <= 8192.  A ticket that does not fill (never observed) or a position outside the cache raises the step state's error word. */
+int amq_gemv_qkv_attn_f16(const amq_segment* segments /* host, 3 */, const void* x, const void* gamma, float eps, int K, int group,
+                          void* kcache, void* vcache, void* out, const void* step_state, int n_heads, int n_kv_heads, int head_dim,
+                          int max_seq, void* tickets, void* stream);
+
 /* ---- one decode token as ONE persistent launch -----------------------------------------------------------------------
  * The whole per-token loop body of the reference's patched decoder (amq/kernel/monkeypatch/ftllama_modeling.py:167-230: for
  * every block RMSNorm -> q/k/v -> RoPE + cache append + attention -> o_proj + residual -> RMSNorm -> gate/up -> SiLU*mul ->

@@ -25,6 +25,7 @@ def _pair(cfg, al, max_seq, seed, grid=0):
     if grid:
         me.engine.grid = grid
     mr = QuantLlama(cfg, al, device="cuda:0", max_seq=max_seq, seed=seed, engine=False)
+    mr.fuse_qkv_attn = False                                    # five separate launches (the fused q/k/v + attention launch is 8-wave only)
     for be, br in zip(me.blocks, mr.blocks):                    # same generator, same draws
         for name in cfg["linear"]:
             assert torch.equal(be[name].qn, br[name].qn) and torch.equal(be[name].mn, br[name].mn)
