@@ -6,7 +6,29 @@
 #include <vector>
 using namespace amq;
 
-enum { V_FULL = 0, V_FULL_LDS = 1, V_DEQ = 2, V_MFMA = 3, V_LIN = 4 };
+enum { V_FULL = 0, V_FULL_LDS = 1, V_DEQ = 2, V_MFMA = 3, V_LIN = 4, V_LUT = 5, V_LUT_DEQ = 6 };
+
+// every lane's 32 weights of a tile share one (scale, zero), so a 2-bit lane has only FOUR distinct exact fp16 values:
+// compute them once with the exact two-rounding path (two pair operations instead of sixteen) and SELECT per weight pair with
+// v_perm_b32 on the 8-byte table {T0, T1 | T2, T3}: selector bytes (2 q0, 2 q0 + 1, 2 q1 + 4.., ..) = A * 0x202 + 0x01000100 with
+// A = (u >> 2s) & 0x00030003.  Bit-identical weights by construction.  Cost per pair: shift + and (VOP2) + mad_u24 + perm (VOP3).
+__device__ __forceinline__ void dequant_lane_lut2(const uint32_t* w, h2 meta, h2* out) {
+    const SdMeta m = sd_meta<2, MODE_HQQ>(meta);
+    // the four table values: pairs (q = 0, 1) and (q = 2, 3) through the product's own pair arithmetic
+    const h2 t01 = sd_pair<2, MODE_HQQ, 8>(0x01000000u, m);          // low half q = 0, high half q = 1 (field at bit 8)
+    const h2 t23 = sd_pair<2, MODE_HQQ, 8>(0x03000200u, m);          // q = 2, 3
+    const uint32_t lo = as_u32(t01), hi = as_u32(t23);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const uint32_t u = w[d];
+#pragma unroll
+        for (int sft = 0; sft < 8; ++sft) {
+            const uint32_t a = (u >> (2 * sft)) & 0x00030003u;
+            const uint32_t sel = __umul24(a, 0x202u) + 0x01000100u;               // bytes (2 q0, 2 q0 + 1, 2 q1, 2 q1 + 1)
+            out[8 * d + sft] = as_h2(__builtin_amdgcn_perm(hi, lo, sel));
+        }
+    }
+}
 
 template <int BITS>
 __device__ __forceinline__ void unpack_sub(const uint32_t* w, h2* out) {   // and-only (linear math)
@@ -44,9 +66,10 @@ __global__ void tile_kernel(uint64_t* out, uint32_t seed, int iters) {
         asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(meta));   // payload "arrives": nothing hoistable
         h2 wv[16];
         if (VAR == V_LIN) unpack_sub<BITS>(w, wv);
+        else if (VAR == V_LUT || VAR == V_LUT_DEQ) dequant_lane_lut2(w, meta, wv);
         else if (VAR != V_MFMA) dequant_lane_sd<BITS, MODE_HQQ>(w, meta, wv);
         else { for (int p = 0; p < 16; ++p) wv[p] = as_h2(w[p & 3]); }
-        if (VAR == V_DEQ) {
+        if (VAR == V_DEQ || VAR == V_LUT_DEQ) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) asm volatile("" ::"v"(wv[p]));
         } else {
@@ -56,7 +79,7 @@ __global__ void tile_kernel(uint64_t* out, uint32_t seed, int iters) {
                 h8 b;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) { b[2 * p] = wv[4 * t + p].x; b[2 * p + 1] = wv[4 * t + p].y; }
-                const h8 av = (VAR == V_FULL_LDS || VAR == V_LIN) ? *(const h8*)(xl + kbase + 8 * o + 32 * t) : areg;
+                const h8 av = (VAR == V_FULL_LDS || VAR == V_LIN || VAR == V_LUT) ? *(const h8*)(xl + kbase + 8 * o + 32 * t) : areg;
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b, acc, 0, 0, 0);
             }
             if (VAR == V_LIN) {   // per-group fp32 fix-up of the linear-math body
@@ -94,7 +117,23 @@ static void run(const char* name, uint64_t* d_out) {
     printf("\n");
 }
 
+__global__ void lut_check_kernel(uint32_t* bad) {
+    uint32_t w[2] = {threadIdx.x * 2654435761u + blockIdx.x * 40503u, threadIdx.x * 97u + blockIdx.x * 2246822519u};
+    const h2 meta = {(_Float16)(0.013f + 0.0001f * (float)(threadIdx.x & 31)), (_Float16)(1.37f + 0.01f * (float)(blockIdx.x & 63))};
+    h2 a[16], b[16];
+    dequant_lane_sd<2, MODE_HQQ>(w, meta, a);
+    dequant_lane_lut2(w, meta, b);
+    for (int p = 0; p < 16; ++p) if (as_u32(a[p]) != as_u32(b[p])) atomicAdd(bad, 1u);
+}
+
 int main() {
+    {
+        uint32_t* d_bad; uint32_t h_bad = 0;
+        hipMalloc(&d_bad, 4); hipMemset(d_bad, 0, 4);
+        hipLaunchKernelGGL(lut_check_kernel, dim3(256), dim3(256), 0, 0, d_bad);
+        hipMemcpy(&h_bad, d_bad, 4, hipMemcpyDeviceToHost);
+        printf("2-bit LUT weights vs dequant_lane_sd over 65536 lanes x 16 pairs: %u mismatching pairs\n", h_bad);
+    }
     uint64_t* d_out;
     hipMalloc(&d_out, 1 << 20);
     printf("shader cycles per tile per SIMD: mean / max over waves of (wave wall cycles for N tiles) / N / waves-per-SIMD\n");
@@ -109,5 +148,7 @@ int main() {
     run<2, V_FULL_LDS>("b2 dequant+mfma (A LDS)", d_out);
     run<2, V_DEQ>("b2 dequant only", d_out);
     run<2, V_LIN>("b2 linear", d_out);
+    run<2, V_LUT>("b2 LUT+perm +mfma (A LDS)", d_out);
+    run<2, V_LUT_DEQ>("b2 LUT+perm only", d_out);
     return 0;
 }
