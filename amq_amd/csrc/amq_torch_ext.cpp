@@ -26,6 +26,7 @@ using linear_fn = int (*)(int, int, const void*, const void*, const void*, const
 using grouped_fn = int (*)(const Segment*, int, const void*, const void*, const void*, float, int, int, int, int, int, const GemvOpts*, void*);
 using rmsnorm_fn = int (*)(const void*, const void*, void*, int, int, float, void*);
 using silu_mul_fn = int (*)(const void*, const void*, void*, size_t, void*);
+using attn_cur_fn = int (*)(const void*, const void*, const void*, void*, void*, void*, const void*, int, int, int, int, int, void*);
 using err_fn = const char* (*)();
 
 void* g_lib = nullptr;
@@ -33,6 +34,7 @@ linear_fn g_linear = nullptr;
 grouped_fn g_grouped = nullptr;
 rmsnorm_fn g_rmsnorm = nullptr;
 silu_mul_fn g_silu_mul = nullptr;
+attn_cur_fn g_attn_cur = nullptr;
 err_fn g_err = nullptr;
 
 void need_lib() {
@@ -64,8 +66,9 @@ void init(const std::string& path) {
     g_grouped = (grouped_fn)dlsym(h, "amq_gemv_grouped_f16");
     g_rmsnorm = (rmsnorm_fn)dlsym(h, "amq_rmsnorm_f16");
     g_silu_mul = (silu_mul_fn)dlsym(h, "amq_silu_mul_f16");
+    g_attn_cur = (attn_cur_fn)dlsym(h, "amq_attn_decode_cur_f16");
     g_err = (err_fn)dlsym(h, "amq_last_error");
-    if (!g_linear || !g_grouped || !g_rmsnorm || !g_silu_mul || !g_err) throw std::runtime_error("amq torch extension: libamq_hip.so lacks an entry point");
+    if (!g_linear || !g_grouped || !g_rmsnorm || !g_silu_mul || !g_attn_cur || !g_err) throw std::runtime_error("amq torch extension: libamq_hip.so lacks an entry point");
     g_lib = h;
 }
 
@@ -124,6 +127,77 @@ std::vector<at::Tensor> grouped(const at::Tensor& x, const std::vector<at::Tenso
     return ys;
 }
 
+// the same launch with everything about the WEIGHTS checked once: a module keeps the handle (LinearGroup, HIPLlamaMLP) and a forward
+// converts one tensor instead of five Python lists.  The handle holds the weight tensors, so their storage cannot go away under it;
+// the owner drops the handle when its buffers are replaced (.to(), load_state_dict).
+struct Group {
+    std::vector<at::Tensor> qw, mt;
+    std::vector<Segment> segs;
+    int64_t K;
+
+    Group(const std::vector<at::Tensor>& qweights, const std::vector<at::Tensor>& metas, const std::vector<int64_t>& Ns,
+          const std::vector<int64_t>& bits, const std::vector<int64_t>& modes, int64_t K_) : qw(qweights), mt(metas), K(K_) {
+        const size_t n = qw.size();
+        TORCH_CHECK(n >= 1 && n <= 4 && mt.size() == n && Ns.size() == n && bits.size() == n && modes.size() == n, "1..4 segments");
+        for (size_t i = 0; i < n; ++i) {
+            TORCH_CHECK(qw[i].is_cuda() && qw[i].device() == qw[0].device(), "the weights of a group live on one GPU");
+            check_native(qw[i], mt[i], bits[i], Ns[i], K, qw[0]);
+            segs.push_back(Segment{qw[i].data_ptr(), mt[i].data_ptr(), nullptr, nullptr, nullptr, (int)Ns[i], (int)bits[i], (int)modes[i], 0});
+        }
+    }
+
+    std::vector<at::Tensor> run(const at::Tensor& x, int64_t prologue, const c10::optional<at::Tensor>& aux, double eps) const {
+        need_lib();
+        check_x(x, K);
+        TORCH_CHECK(x.device() == qw[0].device(), "x and the weights must be on the same device");
+        const int64_t M = x.numel() / K;
+        TORCH_CHECK(M >= 1 && M <= 16, "grouped: 1..16 rows (got ", M, ")");
+        Segment local[4];
+        std::vector<at::Tensor> ys;
+        ys.reserve(segs.size());
+        auto sizes = x.sizes().vec();
+        for (size_t i = 0; i < segs.size(); ++i) {
+            sizes.back() = segs[i].N;
+            ys.push_back(at::empty(sizes, x.options()));
+            local[i] = segs[i];
+            local[i].y = ys[i].data_ptr();
+        }
+        const void* x2 = nullptr;
+        const void* gamma = nullptr;
+        if (prologue == 1) {
+            TORCH_CHECK(aux && aux->scalar_type() == at::kHalf && aux->numel() == K && aux->device() == x.device(), "RMSNorm prologue: gamma fp16 [K]");
+            gamma = aux->data_ptr();
+        } else if (prologue == 2) {
+            TORCH_CHECK(aux && aux->scalar_type() == at::kHalf && aux->numel() == x.numel() && aux->is_contiguous() && aux->device() == x.device(),
+                        "SiLU*mul prologue: up fp16 of x's shape");
+            x2 = aux->data_ptr();
+        } else {
+            TORCH_CHECK(prologue == 0, "unknown prologue");
+        }
+        check_rc(g_grouped(local, (int)segs.size(), x.data_ptr(), x2, gamma, (float)eps, (int)prologue, (int)M, (int)K, 128, 0, nullptr, stream_of(x)),
+                 "amq_gemv_grouped_f16");
+        return ys;
+    }
+};
+
+// one decode step of attention over the step-state block's cos/sin row (amq_attn_decode_cur_f16): rotates q / k, appends k / v to
+// the caches at the block's position, returns softmax(q K^T / sqrt(128)) V as a new tensor of q's shape
+at::Tensor attn_decode_cur(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v, const at::Tensor& kcache, const at::Tensor& vcache,
+                           const at::Tensor& cur, int64_t n_heads, int64_t n_kv_heads) {
+    need_lib();
+    TORCH_CHECK(kcache.dim() == 4 && kcache.size(1) == n_kv_heads && kcache.size(3) == 128 && vcache.sizes() == kcache.sizes(),
+                "caches: [B, n_kv_heads, max_seq, 128]");
+    const int64_t B = kcache.size(0), max_seq = kcache.size(2);
+    for (const at::Tensor* t : {&q, &k, &v, &kcache, &vcache, &cur})
+        TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kHalf && t->is_contiguous() && t->device() == q.device(), "attn_decode_cur: contiguous fp16 tensors on one GPU");
+    TORCH_CHECK(q.numel() == B * n_heads * 128 && k.numel() == B * n_kv_heads * 128 && v.numel() == k.numel() && cur.numel() == 128,
+                "attn_decode_cur: q [B, n_heads*128], k / v [B, n_kv_heads*128], cur [128]");
+    at::Tensor out = at::empty_like(q);
+    check_rc(g_attn_cur(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), cur.data_ptr(), (int)B,
+                        (int)n_heads, (int)n_kv_heads, 128, (int)max_seq, stream_of(q)), "amq_attn_decode_cur_f16");
+    return out;
+}
+
 at::Tensor rmsnorm(const at::Tensor& x, const at::Tensor& gamma, double eps) {
     need_lib();
     const int64_t K = x.size(-1);
@@ -148,6 +222,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("init", &init, "dlopen libamq_hip.so and resolve the entry points");
     m.def("linear", &linear, "y = x . W^T (+ bias), 1..8 rows");
     m.def("grouped", &grouped, "several linears over one x in one launch");
+    pybind11::class_<Group, std::shared_ptr<Group>>(m, "Group")
+        .def(pybind11::init<const std::vector<at::Tensor>&, const std::vector<at::Tensor>&, const std::vector<int64_t>&, const std::vector<int64_t>&,
+                            const std::vector<int64_t>&, int64_t>())
+        .def("run", &Group::run, "the group's launch over x: (x, prologue, aux, eps) -> one output per member");
+    m.def("attn_decode_cur", &attn_decode_cur);
     m.def("rmsnorm", &rmsnorm);
     m.def("silu_mul", &silu_mul);
 }

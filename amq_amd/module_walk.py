@@ -12,13 +12,13 @@ import torch
 import torch.nn as nn
 
 from . import _ext, ops
-from .quant_linear import HIPLlamaMLP, HIPQuantLinear
+from .quant_linear import HIPLlamaMLP, HIPQuantLinear, HIPRMSNorm
 
 
 class _RMSNorm(nn.Module):
     def __init__(self, weight, eps):
         super().__init__()
-        self.weight, self.eps = weight, eps
+        self.weight, self.eps = weight, eps          # (a plain tensor of the runner: shared, not a Parameter)
 
     def forward(self, x):
         ext = _ext.get()
@@ -38,6 +38,9 @@ class _Attention(nn.Module):
     def forward(self, h):
         r = self.r
         q, k, v = self.q_proj(h), self.k_proj(h), self.v_proj(h)
+        ext = _ext.get()
+        if ext is not None and r.rope_cur is not None and ops.attn_decode_splits(self.kc.shape[2]) == 1:
+            return self.o_proj(ext.attn_decode_cur(q, k, v, self.kc, self.vc, r.rope_cur, r.nh, r.nkv))
         att = torch.empty_like(q)
         ops.attn_decode(q, k, v, self.kc, self.vc, att, r.pos, r.nh, r.nkv, r.theta, cur=r.rope_cur)
         return self.o_proj(att)
@@ -81,7 +84,7 @@ class ModuleWalkLlama(nn.Module):
     """HF-shaped decoder stack over a QuantLlama's weights, caches and step state (``runner`` keeps owning them: prefill
     with the runner, then step with either)."""
 
-    def __init__(self, runner, group_siblings=True):
+    def __init__(self, runner, group_siblings=True, fuse_norms=True):
         super().__init__()
         if getattr(runner, "B", 1) != 1:
             raise ValueError("the module walk mirrors the reference's batch-1 step")
@@ -89,9 +92,11 @@ class ModuleWalkLlama(nn.Module):
         self.layers = nn.ModuleList(_Block(blk, runner) for blk in runner.blocks)
         self.graph = None
         if group_siblings:                      # what prepare_for_inference(backend="hip") does to a swapped model
-            from .patching import fuse_llama_mlps, group_sibling_linears
+            from .patching import fuse_llama_mlps, fuse_llama_norms, group_sibling_linears
             group_sibling_linears(self)
             fuse_llama_mlps(self)
+            if fuse_norms:
+                fuse_llama_norms(self)
 
     @torch.inference_mode()
     def _step(self):
@@ -103,7 +108,7 @@ class ModuleWalkLlama(nn.Module):
         ops.decode_tail(r.logits, r.embed, r.token, r.pos, r.x, table=r.rope_tab, cur=r.rope_cur)
 
     def n_module_calls(self):
-        return sum(1 for m in self.modules() if isinstance(m, (HIPQuantLinear, HIPLlamaMLP, _RMSNorm, _Attention, _MLP, _Block)))
+        return sum(1 for m in self.modules() if isinstance(m, (HIPQuantLinear, HIPLlamaMLP, HIPRMSNorm, _RMSNorm, _Attention, _MLP, _Block)))
 
     def capture(self):
         if self.graph is not None:

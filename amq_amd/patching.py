@@ -20,7 +20,7 @@ import os
 import torch
 
 from .hqq_format import HQQWeights, from_hqq_layer
-from .quant_linear import HIPLlamaMLP, HIPQuantLinear, LinearGroup
+from .quant_linear import HIPLlamaMLP, HIPQuantLinear, HIPRMSNorm, LinearGroup
 
 # sibling linears of one parent module that read the same input (HF LlamaAttention / LlamaMLP attribute names)
 SIBLING_GROUPS = (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))
@@ -146,9 +146,39 @@ def fuse_llama_mlps(model):
     return n
 
 
-def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False, load_path=None, group_siblings=True, fuse_mlp=True):
+# RMSNorm classes whose forward is weight * x / sqrt(mean(x^2) + eps) with fp32 statistics (HF LlamaRMSNorm; module_walk's own)
+RMSNORM_CLASSES = ("LlamaRMSNorm", "_RMSNorm")
+
+
+def fuse_llama_norms(model):
+    """In every Llama decoder layer -- a module with children ``input_layernorm``, ``self_attn``, ``post_attention_layernorm``,
+    ``mlp`` -- whose q/k/v projections are one LinearGroup and whose MLP is a HIPLlamaMLP, wrap the two RMSNorms in
+    :class:`HIPRMSNorm`: few-row forwards then form the norm in the prologue of the grouped launch that follows it (9 -> 7
+    launches per block for a module swap).  Only the norm classes of RMSNORM_CLASSES are touched.  Returns the number wrapped."""
+    n = 0
+    for layer in list(model.modules()):
+        attn, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
+        if attn is None or mlp is None:
+            continue
+        qkv = [getattr(attn, k, None) for k in SIBLING_GROUPS[0]]
+        grp = qkv[0].__dict__.get("_group") if all(isinstance(m, HIPQuantLinear) and m.bias is None for m in qkv) else None
+        if grp is not None and not (len(grp[0].members) == 3 and all(a is b for a, b in zip(grp[0].members, qkv))):
+            grp = None
+        for name, consumer in (("input_layernorm", grp[0] if grp is not None else None),
+                               ("post_attention_layernorm", mlp if isinstance(mlp, HIPLlamaMLP) else None)):
+            norm = getattr(layer, name, None)
+            if consumer is None or norm is None or type(norm).__name__ not in RMSNORM_CLASSES or getattr(norm, "weight", None) is None:
+                continue
+            setattr(layer, name, HIPRMSNorm(norm, consumer))
+            n += 1
+    return n
+
+
+def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False, load_path=None, group_siblings=True, fuse_mlp=True,
+                          fuse_norms=True):
     """patching.py:143-223 for the HIP backend.  ``group_siblings`` (default on; not in the reference): q/k/v and gate/up
-    siblings are additionally tied into grouped launches (group_sibling_linears)."""
+    siblings are additionally tied into grouped launches (group_sibling_linears); ``fuse_mlp`` / ``fuse_norms``: SiLU-gated MLPs
+    and the decoder layers' RMSNorms are fused into those launches (fuse_llama_mlps, fuse_llama_norms)."""
     if backend not in HIP_BACKENDS:
         raise RuntimeError(f"backend '{backend}' is not available in amq_amd (use one of {HIP_BACKENDS})")
     if allow_merge:
@@ -169,6 +199,8 @@ def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False
         group_sibling_linears(model)
     if fuse_mlp:                      # (not in the reference's generic patcher; its FT path swaps whole Llama sub-modules too)
         fuse_llama_mlps(model)
+    if fuse_norms and group_siblings:
+        fuse_llama_norms(model)
     return model
 
 

@@ -41,8 +41,24 @@ class LinearGroup:
         self._key = None
         self._xref = None
         self._outs = [None] * len(self.members)
+        self._norm = None                       # a deferred RMSNorm waiting for this group's launch (HIPRMSNorm)
+        self._h = None                          # (C++ launch handle, the qweight / meta tensors it was built over)
         for i, m in enumerate(self.members):
             m.__dict__["_group"] = (self, i)
+
+    # -- the producer side of a fused RMSNorm (HIPRMSNorm): the norm hands its RAW input on and the group's launch forms the
+    #    normalised row in its prologue (AMQ_PRO_RMSNORM)
+    def accepts_norm(self, x):
+        ms = self.members
+        if x.shape[-1] != ms[0].infeatures:
+            return False
+        ext = _ext.get()
+        if ext is not None:                     # (the handle was built over bias-free members on one device)
+            return self._handle(ext) is not None and ms[0]._buffers["qweight"].device == x.device
+        return not any(m.bias is not None for m in ms) and all(m.qweight.device == x.device for m in ms)
+
+    def defer_norm(self, norm, x):
+        _defer(self, norm, x)
 
     def __deepcopy__(self, memo):
         # (copy.deepcopy of the model: amq_speed_benchmark.py:231) the copy groups the COPIED members
@@ -50,37 +66,112 @@ class LinearGroup:
         new = LinearGroup.__new__(LinearGroup)
         memo[id(self)] = new
         new.members = [copy.deepcopy(m, memo) for m in self.members]
-        new._key, new._outs, new._xref = None, [None] * len(new.members), None
+        new._key, new._outs, new._xref, new._norm, new._h = None, [None] * len(new.members), None, None, None
         for i, m in enumerate(new.members):
             m.__dict__["_group"] = (new, i)
         return new
+
+    def _handle(self, ext):
+        """the C++ launch handle of this group (``_amq_ext.Group``: weights checked once, held by the handle), rebuilt when a
+        member's buffers were replaced (.to(), load_state_dict); None when the group cannot take the grouped launch"""
+        ms = self.members
+        h = self._h
+        if h is not None and all(m._buffers["qweight"] is q and m._buffers["meta"] is t for m, q, t in zip(ms, h[1], h[2])):
+            return h[0]
+        if any(m.bias is not None for m in ms) or len({m.qweight.device for m in ms}) != 1:
+            self._h = None
+            return None
+        qw, mt = [m.qweight for m in ms], [m.meta for m in ms]
+        self._h = (ext.Group(qw, mt, [m.outfeatures for m in ms], [m.bits for m in ms], [m.mode for m in ms], ms[0].infeatures), qw, mt)
+        return self._h[0]
 
     def take(self, idx, x):
         """output of member ``idx`` for input ``x`` (fp16, GPU, <= GROUP_MAX_ROWS rows), launching the group if needed"""
         # "the same input": the same live tensor OBJECT (weak reference), same storage and shape, and -- where autograd tracks it
         # (inference tensors do not) -- the same version
-        key = (x.data_ptr(), -1 if x.is_inference() else x._version, tuple(x.shape))
-        same = self._key == key and self.__dict__.get("_xref") is not None and self._xref() is x
+        key = (x.data_ptr(), -1 if x.is_inference() else x._version, x.shape)
+        same = self._key == key and self._xref is not None and self._xref() is x
         if not same or self._outs[idx] is None:
             ms = self.members
-            if any(m.bias is not None for m in ms) or any(m.qweight.device != x.device for m in ms):
-                return None
-            x2 = x if x.is_contiguous() else x.contiguous()
             ext = _ext.get()
-            K = ms[0].infeatures
+            x2 = x if x.is_contiguous() else x.contiguous()
             if ext is not None:
-                outs = ext.grouped(x2, [m.qweight for m in ms], [m.meta for m in ms], [m.outfeatures for m in ms],
-                                   [m.bits for m in ms], [m.mode for m in ms], K, 0, None, 0.0)
+                h = self._handle(ext)
+                if h is None:
+                    return None
+                pro, gamma, eps = _claim_norm(self, x)
+                outs = h.run(x2, pro, gamma, eps)
             else:
+                if any(m.bias is not None for m in ms) or any(m.qweight.device != x.device for m in ms):
+                    return None
+                pro, gamma, eps = _claim_norm(self, x)
                 outs = [torch.empty(x.shape[:-1] + (m.outfeatures,), dtype=torch.float16, device=x.device) for m in ms]
                 ops.gemv_grouped(x2, [dict(qn=m.qweight, mn=m.meta, bits=m.bits, mode=m.mode, N=m.outfeatures, y=y.view(-1, m.outfeatures))
-                                      for m, y in zip(ms, outs)], K)
+                                      for m, y in zip(ms, outs)], ms[0].infeatures, prologue=pro, gamma=gamma, eps=eps)
             self._outs = list(outs)
             self._key = key
             self._xref = weakref.ref(x)
         y = self._outs[idx]
         self._outs[idx] = None
         return y
+
+    def __getstate__(self):
+        # (pickling a whole model: torch.save(model)) launch handles, weak references and pending outputs are not state
+        d = dict(self.__dict__)
+        d.update(_key=None, _xref=None, _h=None, _norm=None, _outs=[None] * len(self.members))
+        return d
+
+
+def _defer(consumer, norm, x):
+    """record that ``x`` is the RAW input of ``norm`` and that ``consumer``'s next launch has to normalise it"""
+    p = consumer.__dict__.get("_norm")
+    if p is not None:
+        raise RuntimeError("a deferred RMSNorm output was never consumed by the grouped linears it was fused into "
+                           "(the module that follows the norm does not read it through q/k/v or gate/up): "
+                           "call prepare_for_inference(..., fuse_norms=False) for this model")
+    consumer.__dict__["_norm"] = (norm, x.data_ptr(), x.numel())
+
+
+def _claim_norm(consumer, x):
+    """(prologue, gamma, eps) of ``consumer``'s launch over ``x``; a pending norm must be for exactly this tensor"""
+    p = consumer.__dict__.get("_norm")
+    if p is None:
+        return 0, None, 0.0
+    consumer.__dict__["_norm"] = None
+    norm, ptr, numel = p
+    if ptr != x.data_ptr() or numel != x.numel():
+        raise RuntimeError("a deferred RMSNorm was followed by a forward over a different tensor than the norm's input")
+    return ops.PRO_RMSNORM, norm.weight, float(norm.variance_epsilon)
+
+
+class HIPRMSNorm(nn.Module):
+    """LlamaRMSNorm (transformers modeling_llama.py; the reference swaps it for its FT kernel, kernel/monkeypatch/
+    ftllama_modeling.py:39-46) fused into the launch that consumes it: for few rows (<= GROUP_MAX_ROWS, fp16, on the GPU) the
+    forward returns its input UNCHANGED and tells its consumer -- the q/k/v LinearGroup for ``input_layernorm``, the
+    HIPLlamaMLP for ``post_attention_layernorm`` -- to form weight * x / rms(x) in the prologue of its grouped GEMV
+    (AMQ_PRO_RMSNORM, the arithmetic of amq_rmsnorm_f16).  Valid because in a Llama decoder layer the norm's output is read by
+    those projections only; a norm whose deferred output is not consumed, or is followed by another tensor, raises.  Anything
+    else (more rows, other dtypes) runs the wrapped module.  ``weight`` is the wrapped module's own Parameter, so state_dict
+    keys are unchanged."""
+
+    def __init__(self, inner, consumer):
+        super().__init__()
+        self.weight = inner.weight
+        self.variance_epsilon = float(getattr(inner, "variance_epsilon", getattr(inner, "eps", 0.0)))
+        self.__dict__["_inner"] = inner          # not registered: the state_dict keeps ``<norm>.weight`` only
+        self.__dict__["_consumer"] = consumer
+
+    def forward(self, x):
+        c = self.__dict__["_consumer"]
+        K = self.weight.numel()
+        if (x.dtype is torch.float16 and x.is_cuda and x.is_contiguous() and x.shape[-1] == K and 0 < x.numel() // K <= GROUP_MAX_ROWS
+                and self.weight.dtype is torch.float16 and self.weight.device == x.device and c.accepts_norm(x)):
+            c.defer_norm(self, x)
+            return x
+        return self.__dict__["_inner"](x)
+
+    def extra_repr(self):
+        return f"{self.weight.numel()}, eps={self.variance_epsilon}, fused into {type(self.__dict__['_consumer']).__name__}"
 
 
 class HIPQuantLinear(nn.Module):
@@ -251,6 +342,10 @@ class HIPQuantLinear(nn.Module):
                 f"group_size={self.group_size}, bias={self.bias is not None}, mode={self.mode}")
 
 
+# HIPLlamaMLP -> its C++ launch handles (kept OUTSIDE the module: deepcopy / pickling of a model never meets a handle)
+_MLP_HANDLES = weakref.WeakKeyDictionary()
+
+
 class HIPLlamaMLP(nn.Module):
     """LlamaMLP over three HIPQuantLinear children -- ``down_proj(act_fn(gate_proj(x)) * up_proj(x))`` with act_fn = SiLU
     (transformers modeling_llama.py) -- as TWO launches for few rows: gate / up as segments of one grouped GEMV, then down_proj
@@ -264,6 +359,15 @@ class HIPLlamaMLP(nn.Module):
         super().__init__()
         self.gate_proj, self.up_proj, self.down_proj = gate_proj, up_proj, down_proj
 
+    def accepts_norm(self, x):
+        """a fused post_attention_layernorm (HIPRMSNorm) may hand its raw input on: exactly the fast path's condition"""
+        g_, u_, d_ = self.gate_proj, self.up_proj, self.down_proj
+        return (x.shape[-1] == g_.infeatures and g_.bias is None and u_.bias is None and d_.bias is None
+                and x.device == g_.qweight.device == u_.qweight.device)
+
+    def defer_norm(self, norm, x):
+        _defer(self, norm, x)
+
     def forward(self, x):
         g_, u_, d_ = self.gate_proj, self.up_proj, self.down_proj
         K = g_.infeatures
@@ -271,17 +375,25 @@ class HIPLlamaMLP(nn.Module):
                 and g_.bias is None and u_.bias is None and d_.bias is None and x.device == g_.qweight.device):
             x2 = x if x.is_contiguous() else x.contiguous()
             ext = _ext.get()
+            pro, gamma, eps = _claim_norm(self, x)
             if ext is not None:
-                g, u = ext.grouped(x2, [g_.qweight, u_.qweight], [g_.meta, u_.meta], [g_.outfeatures, u_.outfeatures],
-                                   [g_.bits, u_.bits], [g_.mode, u_.mode], K, 0, None, 0.0)
-                return ext.grouped(g, [d_.qweight], [d_.meta], [d_.outfeatures], [d_.bits], [d_.mode], d_.infeatures, 2, u, 0.0)[0]
+                h = _MLP_HANDLES.get(self)       # (C++ launch handles: weights checked once; rebuilt when a buffer was replaced)
+                if h is None or any(m._buffers["qweight"] is not q or m._buffers["meta"] is not t for m, q, t in zip((g_, u_, d_), h[2], h[3])):
+                    qw, mt = [g_.qweight, u_.qweight, d_.qweight], [g_.meta, u_.meta, d_.meta]
+                    h = _MLP_HANDLES[self] = (ext.Group(qw[:2], mt[:2], [g_.outfeatures, u_.outfeatures], [g_.bits, u_.bits], [g_.mode, u_.mode], K),
+                                              ext.Group(qw[2:], mt[2:], [d_.outfeatures], [d_.bits], [d_.mode], d_.infeatures), qw, mt)
+                g, u = h[0].run(x2, pro, gamma, eps)
+                return h[1].run(g, 2, u, 0.0)[0]
             I = g_.outfeatures
             g = torch.empty(x.shape[:-1] + (I,), dtype=torch.float16, device=x.device)
             u = torch.empty_like(g)
             ops.gemv_grouped(x2, [dict(qn=g_.qweight, mn=g_.meta, bits=g_.bits, mode=g_.mode, N=I, y=g.view(-1, I)),
-                                  dict(qn=u_.qweight, mn=u_.meta, bits=u_.bits, mode=u_.mode, N=I, y=u.view(-1, I))], K)
+                                  dict(qn=u_.qweight, mn=u_.meta, bits=u_.bits, mode=u_.mode, N=I, y=u.view(-1, I))], K,
+                             prologue=pro, gamma=gamma, eps=eps)
             y = torch.empty(x.shape[:-1] + (d_.outfeatures,), dtype=torch.float16, device=x.device)
             ops.gemv_grouped(g.view(-1, I), [dict(qn=d_.qweight, mn=d_.meta, bits=d_.bits, mode=d_.mode, N=d_.outfeatures,
                                                   y=y.view(-1, d_.outfeatures))], I, prologue=ops.PRO_SILU_MUL, x2=u.view(-1, I))
             return y
+        if self.__dict__.get("_norm") is not None:
+            raise RuntimeError("a deferred RMSNorm reached HIPLlamaMLP's unfused path")
         return d_(torch.nn.functional.silu(g_(x)) * u_(x))

@@ -64,12 +64,68 @@ def test_hf_llama_with_swapped_linears_matches_oracle_weights(n_kv_heads, seq):
     assert torch.isfinite(y).all()
     # HF's own fp16 matmuls on the oracle weights accumulate in a different order: logits agree to fp16 rounding of the stack
     assert (y - y_ref).abs().max() <= 2e-2 * y_ref.abs().max()
+    from amq_amd.quant_linear import HIPRMSNorm
+    assert sum(isinstance(m, HIPRMSNorm) for m in model.modules()) == 4           # both norms of both layers fused into their consumers
     # grouped and ungrouped swaps are the same function, bit for bit (one launch vs three: same kernel per segment)
     model2, _ = _quantize_linears(_tiny_llama(n_kv_heads))
     prepare_for_inference(model2, backend="hip", group_siblings=False, fuse_mlp=False)
+    model3, _ = _quantize_linears(_tiny_llama(n_kv_heads))
+    prepare_for_inference(model3, backend="hip", fuse_norms=False)
+    assert not any(isinstance(m, HIPRMSNorm) for m in model3.modules())
     with torch.inference_mode():
         y2 = model2(ids).logits.float()
-    assert torch.equal(y, y2)
+        y3 = model3(ids).logits.float()
+    assert torch.equal(y3, y2)
+    # the fused norms replace HF's torch-op RMSNorm by the GEMV prologue for <= 8 rows (same formula, fp32 statistics, another
+    # summation order); more rows run HF's module itself
+    if seq > 8:
+        assert torch.equal(y, y2)
+    else:
+        assert (y - y2).abs().max() <= 4e-3 * y2.abs().max()
+
+
+def test_deferred_norm_that_is_not_consumed_raises():
+    """HIPRMSNorm hands its raw input on; if the grouped launch it was fused into never runs, the next forward fails loudly"""
+    from amq_amd.patching import prepare_for_inference
+    from amq_amd.quant_linear import HIPRMSNorm
+    model, _ = _quantize_linears(_tiny_llama(2))
+    prepare_for_inference(model, backend="hip")
+    layer = model.model.layers[0]
+    assert isinstance(layer.input_layernorm, HIPRMSNorm) and isinstance(layer.post_attention_layernorm, HIPRMSNorm)
+    x = torch.randn(1, 1, 256, device="cuda:0").half()
+    with torch.inference_mode():
+        assert layer.input_layernorm(x) is x                      # deferred: the q/k/v launch will normalise
+        with pytest.raises(RuntimeError, match="never consumed"):
+            layer.input_layernorm(x)
+        layer.self_attn.q_proj.__dict__["_group"][0].__dict__["_norm"] = None
+        layer.input_layernorm(x)
+        with pytest.raises(RuntimeError, match="different tensor"):
+            layer.self_attn.q_proj(torch.randn(1, 1, 256, device="cuda:0").half())
+        # many rows are not deferred: HF's own module runs
+        xm = torch.randn(1, 24, 256, device="cuda:0").half()
+        assert layer.post_attention_layernorm(xm) is not xm
+
+
+def test_fused_norm_equals_rmsnorm_kernel_then_grouped_launch():
+    """the RMSNorm prologue of the grouped GEMV is the arithmetic of amq_rmsnorm_f16: deferred norm + q/k/v == rmsnorm kernel + q/k/v"""
+    from amq_amd import ops
+    from amq_amd.patching import prepare_for_inference
+    model, _ = _quantize_linears(_tiny_llama(2))
+    prepare_for_inference(model, backend="hip")
+    layer = model.model.layers[1]
+    for rows in (1, 3, 8):
+        x = torch.randn(1, rows, 256, generator=torch.Generator().manual_seed(rows)).half().to("cuda:0")
+        with torch.inference_mode():
+            h = layer.input_layernorm(x)
+            got = [p(h) for p in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj)]
+            hn = ops.rmsnorm(x.view(rows, 256), layer.input_layernorm.weight.data, layer.input_layernorm.variance_epsilon).view(1, rows, 256)
+            want = [p(hn) for p in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj)]
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+            y = layer.mlp(layer.post_attention_layernorm(x))
+            yn = layer.mlp(ops.rmsnorm(x.view(rows, 256), layer.post_attention_layernorm.weight.data,
+                                       layer.post_attention_layernorm.variance_epsilon).view(1, rows, 256))
+            assert torch.equal(y, yn)
 
 
 def test_hf_swapped_model_survives_deepcopy_and_state_dict_roundtrip(tmp_path):

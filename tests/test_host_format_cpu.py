@@ -67,3 +67,61 @@ def test_checkpoint_loader_reads_reference_files():
     exp = np.load(os.path.join(root, "expected.npz"))
     assert set(json.loads(str(exp["arch"]))) == set(hqq_format.PACKING and ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj",
                                                                             "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"])
+
+
+def test_fuse_llama_norms_structure_state_dict_and_deepcopy():
+    """patching.fuse_llama_norms (host logic only, no launch): a decoder-layer-shaped module gets its two RMSNorms wrapped, the
+    state_dict keys do not change, a deep copy (amq_speed_benchmark.py:231) ties the COPIED norms to the COPIED consumers, and
+    other norm classes / layers with a biased projection are left alone"""
+    import copy
+    import torch.nn as nn
+    from amq_amd import patching
+    from amq_amd.quant_linear import HIPLlamaMLP, HIPQuantLinear, HIPRMSNorm, LinearGroup
+
+    class LlamaRMSNorm(nn.Module):
+        def __init__(self, n):
+            super().__init__()
+            self.weight, self.variance_epsilon = nn.Parameter(torch.ones(n, dtype=torch.float16)), 1e-5
+
+        def forward(self, x):
+            return x * self.weight
+
+    class OtherNorm(LlamaRMSNorm):
+        pass
+
+    class Attn(nn.Module):
+        def __init__(self, bias=False):
+            super().__init__()
+            for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                setattr(self, n, HIPQuantLinear(4, 128, 256, 256, bias=torch.zeros(256) if bias and n == "k_proj" else None))
+
+    class MLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gate_proj, self.up_proj, self.down_proj = HIPQuantLinear(3, 128, 256, 512), HIPQuantLinear(2, 128, 256, 512), HIPQuantLinear(4, 128, 512, 256)
+            self.act_fn = nn.SiLU()
+
+    class Layer(nn.Module):
+        def __init__(self, norm=LlamaRMSNorm, bias=False):
+            super().__init__()
+            self.input_layernorm, self.post_attention_layernorm = norm(256), norm(256)
+            self.self_attn, self.mlp = Attn(bias), MLP()
+
+    model = nn.ModuleList([Layer(), Layer(OtherNorm), Layer(bias=True)])
+    keys = sorted(model.state_dict())
+    assert patching.group_sibling_linears(model) == 6 and patching.fuse_llama_mlps(model) == 3
+    assert patching.fuse_llama_norms(model) == 2 + 0 + 1          # layer 1: unknown norm class; layer 2: biased k_proj keeps input_layernorm
+    assert sorted(model.state_dict()) == keys
+    l0 = model[0]
+    assert isinstance(l0.input_layernorm, HIPRMSNorm) and isinstance(l0.post_attention_layernorm, HIPRMSNorm)
+    assert isinstance(l0.input_layernorm.__dict__["_consumer"], LinearGroup) and l0.post_attention_layernorm.__dict__["_consumer"] is l0.mlp
+    assert not isinstance(model[1].input_layernorm, HIPRMSNorm) and not isinstance(model[2].input_layernorm, HIPRMSNorm)
+    assert isinstance(model[2].post_attention_layernorm, HIPRMSNorm) and isinstance(l0.mlp, HIPLlamaMLP)
+    c0 = copy.deepcopy(model)[0]
+    assert c0.input_layernorm.__dict__["_consumer"] is c0.self_attn.q_proj.__dict__["_group"][0]
+    assert c0.post_attention_layernorm.__dict__["_consumer"] is c0.mlp and c0.mlp is not l0.mlp
+    assert c0.input_layernorm.weight is c0.input_layernorm.__dict__["_inner"].weight
+    # CPU tensors are never deferred: the wrapped module runs
+    x = torch.ones(1, 256, dtype=torch.float16)
+    assert l0.input_layernorm(x) is not x
+    assert patching.fuse_llama_norms(model) == 0                  # idempotent
