@@ -178,7 +178,7 @@ int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qn, const
 }
 
 size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K) {
-    if (M < 1 || N < 1 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_RING128) return 0;
+    if (M < 1 || N < 1 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_WS) return 0;
     const int s = amq::gemm_pick_splits(M, N, K, route);
     return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -186,7 +186,7 @@ size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K) {
 int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
                        const void* residual, void* y, int M, int N, int K, int group, int x_stride, int y_stride,
                        void* workspace, size_t workspace_bytes, void* stream) {
-    if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_RING128) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
+    if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_WS) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
@@ -202,7 +202,7 @@ int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void*
 }
 
 int amq_gemm_gated_fused(int route, int M, int N, int K, int use_workspace) {
-    if (M < 1 || N < 16 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_RING128) return 0;
+    if (M < 1 || N < 16 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_WS) return 0;
     amq::GemmArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, M, N, K, 4, AMQ_MODE_HQQ, K, N, nullptr,
                     use_workspace ? amq::gemm_pick_splits(M, N, K, route) : 1};
     return amq::gemm_gate_fused(a, route) ? 1 : 0;
@@ -211,7 +211,7 @@ int amq_gemm_gated_fused(int route, int M, int N, int K, int use_workspace) {
 int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
                        const void* gate, void* y, int M, int N, int K, int group, int x_stride, void* workspace,
                        size_t workspace_bytes, void* stream) {
-    if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_RING128) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
+    if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_WS) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!x || !qn || !mn || !y || !gate) return fail(AMQ_EINVAL, "null pointer");

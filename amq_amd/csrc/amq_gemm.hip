@@ -506,7 +506,7 @@ static hipError_t skinny_launch(const GemmArgs& a, hipStream_t st) {
 // short (measured above: at 64 rows the kernel wins for 4096x4096, loses for N = 11008 -- 688 workgroups, 2.7 rounds --
 // and for K = 11008 -- 1.4 MB of x per workgroup)
 static bool gemm_is_skinny(int M, int N, int K, int route) {
-    if (route == GEMM_ROUTE_TILED || route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128) return false;
+    if (route == GEMM_ROUTE_TILED || route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128 || route == GEMM_ROUTE_WS) return false;
     if (route == GEMM_ROUTE_SKINNY) return M <= 64;
     return M <= GEMM_SKINNY_MAX || (M <= 2 * GEMM_SKINNY_MAX && M <= 64 && (N >> 4) <= 320 && K <= 6144);
 }
@@ -521,7 +521,7 @@ int gemm_pick_splits(int M, int N, int K, int route) {
     const long wg = (long)((M + 63) / 64) * ((N + bn - 1) / bn);      // 64-row tiles (what such launches use)
     const int G = K >> 7;
     if (gemm_is_skinny(M, N, K, route)) return 1;                        // gemm_skinny_kernel: no partials
-    if (route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128 || (route == GEMM_ROUTE_AUTO && gemm_takes_ring(M, N, K))) return 1;
+    if (route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128 || route == GEMM_ROUTE_WS || (route == GEMM_ROUTE_AUTO && gemm_takes_ring(M, N, K))) return 1;
     if (wg >= target * 3 / 4 || G < 4 || (N & 7)) return 1;
     int s = (int)((target + wg - 1) / wg);
     if (s > 8) s = 8;
@@ -572,7 +572,7 @@ static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int rout
 // a.gate (y = fp16(silu(gate)) * fp16(x . W^T (+ bias)), no residual): formed in the epilogue by the ring and the few-row
 // kernels; the tiled kernel (with or without split-K) is followed by the element-wise launch instead -- same expression, same bits.
 bool gemm_gate_fused(const GemmArgs& a, int route) {
-    const bool ring = (route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128 ||
+    const bool ring = (route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128 || route == GEMM_ROUTE_WS ||
                        (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K))) && gemm_ring_ok(a);
     return ring || gemm_is_skinny(a.M, a.N, a.K, route);
 }
@@ -589,6 +589,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route) {
 static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route) {
     if (route == GEMM_ROUTE_RING && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
     if (route == GEMM_ROUTE_RING128 && gemm_ring_ok(a)) return launch_gemm_ring(a, st, 128);
+    if (route == GEMM_ROUTE_WS && gemm_ring_ok(a)) return launch_gemm_ws(a, st);
     if (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K) && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
     if (gemm_is_skinny(a.M, a.N, a.K, route)) {
         if (a.mode == MODE_HQQ) {

@@ -71,11 +71,12 @@ struct GemmArgs {
     const void* gate;       // few-row kernel only: fp16 [M, y_stride]; y = fp16(silu(gate)) * fp16(acc (+ bias)) (LlamaMLP), or null
 };
 // route: which kernel family serves the launch (AUTO: by shape; the others force one for tests / A-B tools)
-enum { GEMM_ROUTE_AUTO = 0, GEMM_ROUTE_TILED = 1, GEMM_ROUTE_SKINNY = 2, GEMM_ROUTE_RING = 3, GEMM_ROUTE_RING128 = 4 };
+enum { GEMM_ROUTE_AUTO = 0, GEMM_ROUTE_TILED = 1, GEMM_ROUTE_SKINNY = 2, GEMM_ROUTE_RING = 3, GEMM_ROUTE_RING128 = 4, GEMM_ROUTE_WS = 5 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route = GEMM_ROUTE_AUTO);
 bool gemm_gate_fused(const GemmArgs& a, int route);                 // a.gate applied in the kernel's epilogue (else: element-wise launch behind it)
 hipError_t launch_gemm_ring(const GemmArgs& a, hipStream_t st, int bm = 0);      // amq_gemm_ring.hip: 256 (or 128) x 256 tiles, LDS rings, counted waits; bm 0 = by shape
 bool gemm_ring_ok(const GemmArgs& a);
+hipError_t launch_gemm_ws(const GemmArgs& a, hipStream_t st);                  // amq_gemm_ws.hip: 256 x 128 tiles, 4 MFMA waves + 4 DMA / unpack waves (same shape conditions: gemm_ring_ok)
 int gemm_ring_rows(int M, int N);                                   // 256 / 128 rows per ring tile, 0: launch too small
 bool gemm_takes_ring(int M, int N, int K);                          // GEMM_ROUTE_AUTO's choice for the shape
 hipError_t launch_gemm_xfrag(const GemmArgs& a, hipStream_t st);     // a.x in fragment order (launch_xfrag)

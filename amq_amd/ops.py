@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (MODE_HQQ, MODE_FMA, PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL, Segment, GemvOpts, EngineBlock, EngineLinear,  # noqa: F401
-                   GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, MATH_EXACT, MATH_LINEAR)
+                   GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, GEMM_WS, MATH_EXACT, MATH_LINEAR)
 
 GROUP = 128
 

@@ -563,11 +563,13 @@ def _sampled_rows_check(y, x, w_dev, rows, what):
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("m,n,k,route", [(640, 12288, 512, 1), (2048, 3072, 256, 1), (517, 6144, 384, 1),
                                          (640, 12288, 512, 3), (2048, 3072, 256, 3), (517, 6144, 384, 3), (300, 1040, 1152, 3),
-                                         (640, 12288, 512, 4), (517, 6144, 384, 4), (300, 1040, 1152, 4), (129, 2048, 256, 4)])
+                                         (640, 12288, 512, 4), (517, 6144, 384, 4), (300, 1040, 1152, 4), (129, 2048, 256, 4),
+                                         (640, 12288, 512, 5), (517, 6144, 384, 5), (300, 1040, 1152, 5), (129, 2048, 256, 5), (2048, 3072, 128, 5)])
 def test_gemm_big_tiles(bits, m, n, k, route):
     """the many-row MFMA kernels on shapes that select their LARGE tiles (route 1: gemm_kernel<.,.,128,2> needs
     ceil(M/128) * ceil(N/128) >= 384 workgroups; route 3: the ring kernel, 256-row tiles when they fill the chip; route 4: the
-    ring kernel forced to 128-row tiles), ragged M tails, bias and an in-place
+    ring kernel forced to 128-row tiles; route 5: the wave-specialised kernel, amq_gemm_ws.hip, 256 x 128 tiles -- N = 1040 leaves a
+    ragged last column tile, K = 128 a single group), ragged M tails, bias and an in-place
     residual, against the CPU oracle linear on the reference's dequantized weights."""
     from amq_amd import ops
     h, qn, mn, w_ref = _random_case(bits, n, k, seed=31 * bits + m, bias=True)
@@ -618,7 +620,7 @@ def test_gemm_xfrag_grouped_equals_single_launches(m, k, specs):
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("m,n,k,route", [(20, 1024, 512, 0), (64, 2048, 256, 2), (300, 1040, 1152, 0), (300, 1040, 1152, 1),
                                          (200, 2048, 4096, 0),                       # tiled kernel + split-K, then the element-wise launch
-                                         (2048, 3072, 256, 3), (517, 6144, 384, 4), (2500, 4096, 512, 0)])
+                                         (2048, 3072, 256, 3), (517, 6144, 384, 4), (2500, 4096, 512, 0), (517, 1040, 384, 5)])
 def test_gemm_gated_equals_separate_silu_mul(bits, m, n, k, route):
     """y = fp16(silu(gate)) * fp16(x . W^T + bias) formed by the GEMM (ring / few-row epilogue, or the element-wise launch
     behind the tiled kernel) == amq_silu_mul_f16 on the separately computed projection, bit for bit; in place on the gate."""
@@ -658,13 +660,15 @@ def test_gemm_13b_shapes_at_size(bits, n, k, m):
     rms = ref.pow(2).mean().sqrt()
     rows = torch.tensor(sorted({0, 1, m // 3, m // 2, m - 2, m - 1}), device=dev)
     outs = {}
-    for route in (ops.GEMM_TILED, ops.GEMM_RING, ops.GEMM_RING128):
+    for route in (ops.GEMM_TILED, ops.GEMM_RING, ops.GEMM_RING128, ops.GEMM_WS):
         y = ops.gemm(x, l.qn, l.mn, bits, l.mode, n, k, route=route)
         assert torch.all((y.float() - ref).abs() <= 1e-3 * ref.abs() + 1e-3 * rms), route
         _sampled_rows_check(y, x, w, rows, f"13B {n}x{k} {bits}b M={m} route {route}")
         outs[route] = y
     d = (outs[ops.GEMM_TILED].float() - outs[ops.GEMM_RING].float()).abs()
     assert torch.all(d <= 2.0 ** -9 * ref.abs() + 1e-3 * rms)
+    # the wave-specialised kernel accumulates every output over k in the ring kernel's order (same MFMA chain): same bits
+    assert torch.equal(outs[ops.GEMM_WS], outs[ops.GEMM_RING])
 
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
@@ -687,3 +691,4 @@ def test_gemm_ring_fma_mode(bits, m, n, k):
     assert torch.all((ring.float() - ref).abs() <= 1e-3 * ref.abs() + 1e-3 * rms)
     assert torch.all((ring.float() - tiled.float()).abs() <= 2.0 ** -9 * ref.abs() + 1e-3 * rms)
     assert torch.equal(ops.gemm(x, qn, mf, bits, ops.MODE_FMA, n, k, route=ops.GEMM_RING), ring)
+    assert torch.equal(ops.gemm(x, qn, mf, bits, ops.MODE_FMA, n, k, route=ops.GEMM_WS), ring)      # (amq_gemm_ws.hip: same accumulation order)
