@@ -265,8 +265,8 @@ def cpu_baseline(seed=0):
 
 def load_traffic():
     """HBM bytes per GEMV launch from this round's committed rocprofv3 PMC pass over the CURRENT kernels
-    (profiles/r02_gemv_pmc.json, tools/collect_round.sh), or None -- never a stale constant."""
-    p = os.path.join(ROOT, "profiles", "r02_gemv_pmc.json")
+    (profiles/r03_gemv_pmc.json, tools/collect_round.sh r03), or None -- never a stale constant."""
+    p = os.path.join(ROOT, "profiles", "r03_gemv_pmc.json")
     if os.path.exists(p):
         try:
             return json.load(open(p)).get("hbm_bytes_per_launch")
