@@ -146,7 +146,9 @@ struct Group {
         }
     }
 
-    std::vector<at::Tensor> run(const at::Tensor& x, int64_t prologue, const c10::optional<at::Tensor>& aux, double eps) const {
+    // residual (single-member groups: o_proj, down_proj): y = residual + fp16(x . W^T), the runner's epilogue form
+    std::vector<at::Tensor> run(const at::Tensor& x, int64_t prologue, const c10::optional<at::Tensor>& aux, double eps,
+                                const c10::optional<at::Tensor>& residual) const {
         need_lib();
         check_x(x, K);
         TORCH_CHECK(x.device() == qw[0].device(), "x and the weights must be on the same device");
@@ -161,6 +163,12 @@ struct Group {
             ys.push_back(at::empty(sizes, x.options()));
             local[i] = segs[i];
             local[i].y = ys[i].data_ptr();
+        }
+        if (residual) {
+            TORCH_CHECK(segs.size() == 1 && residual->scalar_type() == at::kHalf && residual->is_contiguous() && residual->device() == x.device() &&
+                            residual->numel() == M * segs[0].N,
+                        "residual: a contiguous fp16 tensor of the (single) output's shape");
+            local[0].residual = residual->data_ptr();
         }
         const void* x2 = nullptr;
         const void* gamma = nullptr;
@@ -225,7 +233,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     pybind11::class_<Group, std::shared_ptr<Group>>(m, "Group")
         .def(pybind11::init<const std::vector<at::Tensor>&, const std::vector<at::Tensor>&, const std::vector<int64_t>&, const std::vector<int64_t>&,
                             const std::vector<int64_t>&, int64_t>())
-        .def("run", &Group::run, "the group's launch over x: (x, prologue, aux, eps) -> one output per member");
+        .def("run", &Group::run, pybind11::arg("x"), pybind11::arg("prologue"), pybind11::arg("aux"), pybind11::arg("eps"),
+             pybind11::arg("residual") = pybind11::none(), "the group's launch over x: (x, prologue, aux, eps[, residual]) -> one output per member");
     m.def("attn_decode_cur", &attn_decode_cur);
     m.def("rmsnorm", &rmsnorm);
     m.def("silu_mul", &silu_mul);

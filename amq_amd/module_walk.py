@@ -84,7 +84,7 @@ class ModuleWalkLlama(nn.Module):
     """HF-shaped decoder stack over a QuantLlama's weights, caches and step state (``runner`` keeps owning them: prefill
     with the runner, then step with either)."""
 
-    def __init__(self, runner, group_siblings=True, fuse_norms=True):
+    def __init__(self, runner, group_siblings=True, fuse_norms=True, fuse_layers=True):
         super().__init__()
         if getattr(runner, "B", 1) != 1:
             raise ValueError("the module walk mirrors the reference's batch-1 step")
@@ -97,6 +97,9 @@ class ModuleWalkLlama(nn.Module):
             fuse_llama_mlps(self)
             if fuse_norms:
                 fuse_llama_norms(self)
+            if fuse_layers:
+                from .patching import fuse_llama_layers
+                fuse_llama_layers(self)
 
     @torch.inference_mode()
     def _step(self):

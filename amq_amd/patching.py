@@ -174,11 +174,78 @@ def fuse_llama_norms(model):
     return n
 
 
+def _fused_attention(layer, h, residual, call):
+    """``residual + self_attn(h)`` with the add formed in o_proj's epilogue when that call can take it (HIPQuantLinear._forward_residual):
+    the residual is offered to o_proj through a one-shot holder for the duration of the attention call only."""
+    o_proj = getattr(layer.self_attn, "o_proj", None)
+    if not isinstance(o_proj, HIPQuantLinear) or not residual.is_cuda or residual.dtype is not torch.float16:
+        return residual + call(h)
+    hold = [residual]
+    o_proj.__dict__["_residual"] = hold
+    try:
+        out = call(h)
+    finally:
+        o_proj.__dict__.pop("_residual", None)
+    return out if hold[0] is None else residual + out
+
+
+def _hf_llama_layer_forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                            position_embeddings=None, **kwargs):
+    """transformers 5.x ``LlamaDecoderLayer.forward`` (modeling_llama.py) with the two ``residual + hidden_states`` adds folded into
+    the o_proj / down_proj launches: same modules, same order, same values (the epilogue adds the residual to the fp16-rounded
+    projection, i.e. the two roundings of the separate add)."""
+    attn = lambda h: self.self_attn(hidden_states=h, attention_mask=attention_mask, position_ids=position_ids,
+                                    past_key_values=past_key_values, use_cache=use_cache, position_embeddings=position_embeddings,
+                                    **kwargs)[0]
+    hidden_states = _fused_attention(self, self.input_layernorm(hidden_states), hidden_states, attn)
+    h = self.post_attention_layernorm(hidden_states)
+    if isinstance(self.mlp, HIPLlamaMLP):
+        return self.mlp(h, residual=hidden_states)
+    return hidden_states + self.mlp(h)
+
+
+def _walk_block_forward(self, x):
+    """module_walk._Block.forward (the HF layer's shape without HF's argument plumbing), fused the same way"""
+    x = _fused_attention(self, self.input_layernorm(x), x, self.self_attn)
+    h = self.post_attention_layernorm(x)
+    if isinstance(self.mlp, HIPLlamaMLP):
+        return self.mlp(h, residual=x)
+    return x + self.mlp(h)
+
+
+_HF_LAYER_PARAMS = ["self", "hidden_states", "attention_mask", "position_ids", "past_key_values", "use_cache", "position_embeddings", "kwargs"]
+
+
+def fuse_llama_layers(model):
+    """Fold the decoder layers' residual adds into the o_proj / down_proj launches: the layer instance's ``forward`` is replaced
+    by a function that runs the SAME sub-modules in the same order and offers each residual to the projection that precedes its add
+    (7 -> 5 launches per block for few rows; more rows, biases or other dtypes fall back to the plain add).  Only layers whose
+    forward is known are touched: transformers' ``LlamaDecoderLayer`` with exactly the 5.x signature (its body is what
+    ``_hf_llama_layer_forward`` restates) and module_walk's ``_Block``; the reference's FT path replaces Llama forwards the same
+    way (kernel/monkeypatch/ftllama_modeling.py:39-46, 127-155).  Returns the number of layers patched."""
+    import inspect
+    import types
+    n = 0
+    for layer in model.modules():
+        cls = type(layer)
+        if "forward" in layer.__dict__ or not all(hasattr(layer, k) for k in ("input_layernorm", "self_attn", "post_attention_layernorm", "mlp")):
+            continue
+        if cls.__name__ == "_Block" and cls.__module__.endswith("module_walk"):
+            layer.forward = types.MethodType(_walk_block_forward, layer)
+        elif cls.__name__ == "LlamaDecoderLayer" and list(inspect.signature(cls.forward).parameters) == _HF_LAYER_PARAMS:
+            layer.forward = types.MethodType(_hf_llama_layer_forward, layer)
+        else:
+            continue
+        n += 1
+    return n
+
+
 def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False, load_path=None, group_siblings=True, fuse_mlp=True,
-                          fuse_norms=True):
+                          fuse_norms=True, fuse_layers=True):
     """patching.py:143-223 for the HIP backend.  ``group_siblings`` (default on; not in the reference): q/k/v and gate/up
     siblings are additionally tied into grouped launches (group_sibling_linears); ``fuse_mlp`` / ``fuse_norms``: SiLU-gated MLPs
-    and the decoder layers' RMSNorms are fused into those launches (fuse_llama_mlps, fuse_llama_norms)."""
+    and the decoder layers' RMSNorms are fused into those launches (fuse_llama_mlps, fuse_llama_norms); ``fuse_layers``: the decoder
+    layers' residual adds move into the o_proj / down_proj epilogues (fuse_llama_layers)."""
     if backend not in HIP_BACKENDS:
         raise RuntimeError(f"backend '{backend}' is not available in amq_amd (use one of {HIP_BACKENDS})")
     if allow_merge:
@@ -201,6 +268,8 @@ def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False
         fuse_llama_mlps(model)
     if fuse_norms and group_siblings:
         fuse_llama_norms(model)
+    if fuse_layers:                   # the decoder layers' residual adds into the o_proj / down_proj epilogues
+        fuse_llama_layers(model)
     return model
 
 

@@ -313,6 +313,12 @@ class HIPQuantLinear(nn.Module):
             return out if x_dtype == torch.float16 else out.to(x_dtype)
         if x.device != self.qweight.device:
             raise ValueError(f"x is on {x.device} but the module's weights are on {self.qweight.device}")
+        hold = self.__dict__.get("_residual")
+        if hold is not None and hold[0] is not None:  # (fused decoder layer, patching.fuse_llama_layers) y = residual + fp16(x . W^T) in the epilogue
+            y = self._forward_residual(x, hold[0])
+            if y is not None:
+                hold[0] = None                        # consumed: the caller does not add it again
+                return y
         grp = self.__dict__.get("_group")
         if grp is not None and M <= GROUP_MAX_ROWS:  # q/k/v, gate/up: one grouped launch for all siblings (LinearGroup)
             y = grp[0].take(grp[1], x)
@@ -333,6 +339,20 @@ class HIPQuantLinear(nn.Module):
             _lib.check(rc)
         return y if x_dtype == torch.float16 else y.to(x_dtype)
 
+    def _forward_residual(self, x, residual):
+        """``residual + self(x)`` as ONE launch (the residual added in the GEMV's epilogue: the same two fp16 roundings as the
+        separate add), or None when this call cannot take it (then the caller adds).  fp16 x on the GPU, <= 8 rows, no bias."""
+        ext = _ext.get()
+        if (ext is None or self.bias is not None or x.dtype is not torch.float16 or residual.dtype is not torch.float16
+                or residual.shape[:-1] != x.shape[:-1] or residual.shape[-1] != self.outfeatures or residual.device != x.device
+                or not residual.is_contiguous()):
+            return None
+        h = _LIN_HANDLES.get(self)
+        if h is None or h[1] is not self._buffers["qweight"] or h[2] is not self._buffers["meta"]:
+            h = _LIN_HANDLES[self] = (ext.Group([self.qweight], [self.meta], [self.outfeatures], [self.bits], [self.mode], self.infeatures),
+                                      self.qweight, self.meta)
+        return h[0].run(x if x.is_contiguous() else x.contiguous(), 0, None, 0.0, residual)[0]
+
     def dequantize(self):
         """W[N,K] fp16 exactly as Quantizer.dequantize would give it (MODE_HQQ)."""
         return ops.dequantize(self.qweight, self.meta, self.bits, self.mode, self.outfeatures, self.infeatures)
@@ -342,8 +362,9 @@ class HIPQuantLinear(nn.Module):
                 f"group_size={self.group_size}, bias={self.bias is not None}, mode={self.mode}")
 
 
-# HIPLlamaMLP -> its C++ launch handles (kept OUTSIDE the module: deepcopy / pickling of a model never meets a handle)
+# HIPLlamaMLP / HIPQuantLinear -> C++ launch handles (kept OUTSIDE the modules: deepcopy / pickling of a model never meets a handle)
 _MLP_HANDLES = weakref.WeakKeyDictionary()
+_LIN_HANDLES = weakref.WeakKeyDictionary()
 
 
 class HIPLlamaMLP(nn.Module):
@@ -368,9 +389,13 @@ class HIPLlamaMLP(nn.Module):
     def defer_norm(self, norm, x):
         _defer(self, norm, x)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual`` (optional, fused decoder layers): returns residual + mlp(x), the add formed in down_proj's epilogue"""
         g_, u_, d_ = self.gate_proj, self.up_proj, self.down_proj
         K = g_.infeatures
+        if residual is not None and not (residual.dtype is torch.float16 and residual.is_contiguous() and residual.device == x.device
+                                         and residual.shape[:-1] == x.shape[:-1] and residual.shape[-1] == d_.outfeatures):
+            return residual + self.forward(x)
         if (x.dtype is torch.float16 and x.is_cuda and x.shape[-1] == K and 0 < x.numel() // K <= GROUP_MAX_ROWS
                 and g_.bias is None and u_.bias is None and d_.bias is None and x.device == g_.qweight.device):
             x2 = x if x.is_contiguous() else x.contiguous()
@@ -383,7 +408,7 @@ class HIPLlamaMLP(nn.Module):
                     h = _MLP_HANDLES[self] = (ext.Group(qw[:2], mt[:2], [g_.outfeatures, u_.outfeatures], [g_.bits, u_.bits], [g_.mode, u_.mode], K),
                                               ext.Group(qw[2:], mt[2:], [d_.outfeatures], [d_.bits], [d_.mode], d_.infeatures), qw, mt)
                 g, u = h[0].run(x2, pro, gamma, eps)
-                return h[1].run(g, 2, u, 0.0)[0]
+                return h[1].run(g, 2, u, 0.0, residual)[0]
             I = g_.outfeatures
             g = torch.empty(x.shape[:-1] + (I,), dtype=torch.float16, device=x.device)
             u = torch.empty_like(g)
@@ -392,8 +417,11 @@ class HIPLlamaMLP(nn.Module):
                              prologue=pro, gamma=gamma, eps=eps)
             y = torch.empty(x.shape[:-1] + (d_.outfeatures,), dtype=torch.float16, device=x.device)
             ops.gemv_grouped(g.view(-1, I), [dict(qn=d_.qweight, mn=d_.meta, bits=d_.bits, mode=d_.mode, N=d_.outfeatures,
-                                                  y=y.view(-1, d_.outfeatures))], I, prologue=ops.PRO_SILU_MUL, x2=u.view(-1, I))
+                                                  y=y.view(-1, d_.outfeatures),
+                                                  residual=None if residual is None else residual.view(-1, d_.outfeatures))],
+                             I, prologue=ops.PRO_SILU_MUL, x2=u.view(-1, I))
             return y
         if self.__dict__.get("_norm") is not None:
             raise RuntimeError("a deferred RMSNorm reached HIPLlamaMLP's unfused path")
-        return d_(torch.nn.functional.silu(g_(x)) * u_(x))
+        out = d_(torch.nn.functional.silu(g_(x)) * u_(x))
+        return out if residual is None else residual + out

@@ -68,14 +68,16 @@ def test_hf_llama_with_swapped_linears_matches_oracle_weights(n_kv_heads, seq):
     assert sum(isinstance(m, HIPRMSNorm) for m in model.modules()) == 4           # both norms of both layers fused into their consumers
     # grouped and ungrouped swaps are the same function, bit for bit (one launch vs three: same kernel per segment)
     model2, _ = _quantize_linears(_tiny_llama(n_kv_heads))
-    prepare_for_inference(model2, backend="hip", group_siblings=False, fuse_mlp=False)
+    prepare_for_inference(model2, backend="hip", group_siblings=False, fuse_mlp=False, fuse_layers=False)      # the plain module swap
+    assert not any("forward" in l.__dict__ for l in model2.model.layers)
     model3, _ = _quantize_linears(_tiny_llama(n_kv_heads))
-    prepare_for_inference(model3, backend="hip", fuse_norms=False)
+    prepare_for_inference(model3, backend="hip", fuse_norms=False)                # grouped, fused MLP, residual adds in the epilogues
     assert not any(isinstance(m, HIPRMSNorm) for m in model3.modules())
+    assert all("forward" in l.__dict__ for l in model3.model.layers) and all("forward" in l.__dict__ for l in model.model.layers)
     with torch.inference_mode():
         y2 = model2(ids).logits.float()
         y3 = model3(ids).logits.float()
-    assert torch.equal(y3, y2)
+    assert torch.equal(y3, y2)          # (the residual adds formed in the o_proj / down_proj epilogues round like the separate adds)
     # the fused norms replace HF's torch-op RMSNorm by the GEMV prologue for <= 8 rows (same formula, fp32 statistics, another
     # summation order); more rows run HF's module itself
     if seq > 8:

@@ -125,3 +125,54 @@ def test_fuse_llama_norms_structure_state_dict_and_deepcopy():
     x = torch.ones(1, 256, dtype=torch.float16)
     assert l0.input_layernorm(x) is not x
     assert patching.fuse_llama_norms(model) == 0                  # idempotent
+
+
+def test_fuse_llama_layers_only_touches_known_forwards():
+    """patching.fuse_llama_layers: a ``LlamaDecoderLayer`` whose forward has exactly the transformers 5.x parameter list gets the fused
+    forward (instance attribute: state_dict unchanged, deepcopy keeps it bound to the COPY); another signature, or another class, is
+    left alone; on CPU tensors the fused forward is the plain composition"""
+    import copy
+    import torch.nn as nn
+    from amq_amd import patching
+
+    class Norm(nn.Module):
+        def forward(self, x):
+            return x * 2
+
+    class Attn(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.o_proj = nn.Linear(4, 4, bias=False)
+
+        def forward(self, hidden_states=None, **kw):
+            return self.o_proj(hidden_states), None
+
+    class MLP(nn.Module):
+        def forward(self, x):
+            return x + 1
+
+    def make(name, good_signature):
+        if good_signature:
+            def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                        position_embeddings=None, **kwargs):
+                raise AssertionError("the original forward must not run once fused")
+        else:
+            def forward(self, hidden_states, attention_mask=None):
+                return hidden_states
+        cls = type(name, (nn.Module,), {"forward": forward})
+        layer = cls()
+        layer.input_layernorm, layer.post_attention_layernorm, layer.self_attn, layer.mlp = Norm(), Norm(), Attn(), MLP()
+        return layer
+
+    model = nn.ModuleList([make("LlamaDecoderLayer", True), make("LlamaDecoderLayer", False), make("OtherLayer", True)])
+    keys = sorted(model.state_dict())
+    assert patching.fuse_llama_layers(model) == 1 and patching.fuse_llama_layers(model) == 0
+    assert "forward" in model[0].__dict__ and "forward" not in model[1].__dict__ and "forward" not in model[2].__dict__
+    assert sorted(model.state_dict()) == keys
+    x = torch.randn(2, 4)
+    a = x + model[0].self_attn.o_proj(x * 2)                      # residual + attn(norm(x))
+    want = a + (a * 2 + 1)                                        # residual + mlp(norm(.))
+    assert torch.allclose(model[0](x), want)
+    c = copy.deepcopy(model)[0]
+    assert c.forward.__self__ is c and torch.allclose(c(x), want)
+    assert "_residual" not in model[0].self_attn.o_proj.__dict__
