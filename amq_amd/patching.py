@@ -240,6 +240,23 @@ def fuse_llama_layers(model):
     return n
 
 
+def _merge_zeros_with_lora(model):
+    """``allow_merge=True`` (patching.py:210-216, patch_merge_zeros_with_lora :239-275): the reference folds the zero-point term
+    of an HQQLinearLoRA into its LoRA factors -- only for layers quantized WITHOUT groups along axis 1 (":243-245: axis == 0 or a
+    group_size -> 'Skipping zeros lora merging'").  Every AMQ layer has group_size 128, so on AMQ's path the reference skips every
+    layer; this does the same walk, prints the same line for what the reference skips and refuses the one case it would merge
+    (group-less symmetric kernels are not part of this package)."""
+    for name, layer in model.named_modules():
+        if type(layer).__name__ != "HQQLinearLoRA":
+            continue
+        meta = getattr(getattr(layer, "linear_layer", None), "meta", None) or {}
+        if meta.get("axis") == 0 or meta.get("group_size") is not None:
+            print("Skipping zeros lora merging for", getattr(layer, "name", name))
+        else:
+            raise NotImplementedError(f"allow_merge: {name} is quantized without groups; zero/LoRA merging for group-less layers "
+                                      "is outside the AMQ path (group_size 128)")
+
+
 def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False, load_path=None, group_siblings=True, fuse_mlp=True,
                           fuse_norms=True, fuse_layers=True):
     """patching.py:143-223 for the HIP backend.  ``group_siblings`` (default on; not in the reference): q/k/v and gate/up
@@ -249,7 +266,7 @@ def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False
     if backend not in HIP_BACKENDS:
         raise RuntimeError(f"backend '{backend}' is not available in amq_amd (use one of {HIP_BACKENDS})")
     if allow_merge:
-        raise NotImplementedError("allow_merge (LoRA zero merging) is not part of the AMQ speed path")
+        _merge_zeros_with_lora(model)
     if load_path is not None and os.path.exists(load_path) is False:
         patch_linearlayers(model, patch_hqq_to_hip, verbose=verbose)
         print("Saving the model to", load_path)

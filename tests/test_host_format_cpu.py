@@ -176,3 +176,22 @@ def test_fuse_llama_layers_only_touches_known_forwards():
     c = copy.deepcopy(model)[0]
     assert c.forward.__self__ is c and torch.allclose(c(x), want)
     assert "_residual" not in model[0].self_attn.o_proj.__dict__
+
+
+def test_allow_merge_walk_matches_the_reference_skip_rule(capsys):
+    """prepare_for_inference(allow_merge=True): grouped layers are skipped with the reference's message (patching.py:243-245),
+    a group-less HQQLinearLoRA is refused"""
+    import torch.nn as nn
+    from amq_amd import patching
+
+    class HQQLinearLoRA(nn.Module):
+        def __init__(self, group_size):
+            super().__init__()
+            self.linear_layer = nn.Identity()
+            self.linear_layer.meta = {"axis": 1, "group_size": group_size}
+            self.name = "q_proj"
+
+    patching._merge_zeros_with_lora(nn.ModuleList([HQQLinearLoRA(128)]))
+    assert "Skipping zeros lora merging for q_proj" in capsys.readouterr().out
+    with pytest.raises(NotImplementedError, match="without groups"):
+        patching._merge_zeros_with_lora(nn.ModuleList([HQQLinearLoRA(None)]))
