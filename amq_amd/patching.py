@@ -56,17 +56,17 @@ class HQQWeightsModule(torch.nn.Module):
 
 
 def patch_linearlayers(model, fct, patch_param=None, verbose=False):
-    """patching.py:39-49: recursive named_children walk; sets ``layer.name``."""
-
-    def _patch_linear(mod):
-        for name, layer in mod.named_children():
-            if is_hqq_layer(layer):
-                layer.name = name
-                setattr(mod, name, fct(layer, patch_param))
-            else:
-                _patch_linear(layer)
-
-    _patch_linear(model)
+    """The reference's walk (patching.py:39-49): depth first over ``named_children``; every HQQ layer gets its attribute name as
+    ``layer.name`` and is replaced by ``fct(layer, patch_param)``; anything else is descended into."""
+    stack = [model]
+    while stack:
+        parent = stack.pop()
+        for attr, child in list(parent.named_children()):
+            if not is_hqq_layer(child):
+                stack.append(child)
+                continue
+            child.name = attr
+            setattr(parent, attr, fct(child, patch_param))
 
 
 def _inner(layer):
@@ -267,17 +267,18 @@ def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False
         raise RuntimeError(f"backend '{backend}' is not available in amq_amd (use one of {HIP_BACKENDS})")
     if allow_merge:
         _merge_zeros_with_lora(model)
-    if load_path is not None and os.path.exists(load_path) is False:
-        patch_linearlayers(model, patch_hqq_to_hip, verbose=verbose)
-        print("Saving the model to", load_path)
-        torch.save(model.state_dict(), load_path)
-    elif load_path is not None and os.path.exists(load_path) is True:
-        patch_linearlayers(model, patch_hqq_to_hip_load, verbose=verbose)
+    # the cache-file contract of patching.py:178-208: no path -> convert in place; a path that does not exist yet -> convert and
+    # write the patched state_dict there; an existing file -> build empty modules and load it instead of re-packing
+    cached = load_path is not None and os.path.exists(load_path)
+    patch_linearlayers(model, patch_hqq_to_hip_load if cached else patch_hqq_to_hip, verbose=verbose)
+    if cached:
         print("Loading the model from", load_path)
         model.load_state_dict(torch.load(load_path, weights_only=True))
+    elif load_path is not None:
+        print("Saving the model to", load_path)
+        torch.save(model.state_dict(), load_path)
     else:
         print("No load_path provided, using the model as is")
-        patch_linearlayers(model, patch_hqq_to_hip, verbose=verbose)
     _walk_hip(model, patch_add_weight_param)
     if group_siblings:
         group_sibling_linears(model)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""time one GEMM route on the configs[3] shapes (A/B of amq_gemm_ws.hip build variants: python tools/with_variant.py <tag> tools/ws_bench.py [routes])"""
+"""time GEMM routes on the configs[3] shapes at M = 32768 (A/B of build variants: python tools/with_variant.py <tag> tools/ws_bench.py [routes] [NxK,NxK])"""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from amq_amd import ops
@@ -7,7 +7,8 @@ from amq_amd.llama import _synthetic_linear
 routes = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "5").split(",")]
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(0)
-for (n, k) in ((13824, 5120), (5120, 13824)):
+shapes = ((13824, 5120), (5120, 13824)) if len(sys.argv) < 3 else tuple(tuple(int(v) for v in t.split("x")) for t in sys.argv[2].split(","))
+for (n, k) in shapes:
     for bits in (4, 3, 2):
         l = _synthetic_linear(n, k, bits, gen, dev)
         x = (torch.randn(32768, k, device=dev, generator=gen) * 0.5).half()
