@@ -70,11 +70,12 @@ class QuantLlama:
     ENGINE_DEFAULT = False      # what engine=None means (the engine is opt-in until it beats the five-launch step: DESIGN.md 4)
 
     def __init__(self, config, arch_linear=None, device="cuda:0", max_seq=256, seed=0, synthetic=True,
-                 hqq_layers=None, dense=None, batch=1, engine=None):
+                 hqq_layers=None, dense=None, batch=1, engine=None, prebuilt=None):
         """config: an entry of arch.MODEL_CONFIGS (or its name).
         arch_linear: {'self_attn.q_proj': [bits]*n_block, ...}; default uniform 4.
         hqq_layers: {(block, name): HQQWeights} real quantized layers (else synthetic).
         dense: {'embed','lm_head','norm','ln1'[n_block],'ln2'[n_block]} fp16 tensors (else synthetic).
+        prebuilt: {(block, name): _Lin} linears already in the native layout (from_hf: shared with the modules that own them).
         batch: sequences decoded together, 1 .. 8 (same prompt length; one step = the same launches with ``batch`` rows: the
         weights are streamed once per step for all of them).  batch = 1 is the reference's FT configuration."""
         if isinstance(config, str):
@@ -103,6 +104,10 @@ class QuantLlama:
         def lin(block, name):
             n, k = config["linear_shape"][name]
             bits = arch_bits(arch_linear, name, block)
+            if prebuilt is not None:
+                l = prebuilt[(block, name)]
+                assert l.bits == bits and (l.N, l.K) == (n, k) and l.qn.device == dev
+                return l
             if hqq_layers is not None:
                 h: HQQWeights = hqq_layers[(block, name)].to(dev)
                 assert h.nbits == bits and tuple(h.shape) == (n, k)
@@ -164,6 +169,42 @@ class QuantLlama:
                 [dict({n: dict(qn=blk[n].qn, mn=blk[n].mn, bits=blk[n].bits, mode=blk[n].mode, N=blk[n].N) for n in ops.ENGINE_LINEARS},
                       ln1=blk["ln1"], ln2=blk["ln2"], kc=blk["kc"], vc=blk["vc"]) for blk in self.blocks],
                 self.H, self.I, self.nh, self.nkv, max_seq, self.eps, self.x.view(-1), self.rope_cur)
+
+    @classmethod
+    def from_hf(cls, model, max_seq=256, batch=1, engine=None):
+        """The hipGraph runner over a SWAPPED HF ``LlamaForCausalLM`` -- what ``prepare_for_inference(model, backend="hip")`` (or the
+        reference's deepcopy + setattr assembly of a mixed-precision model, amq_speed_benchmark.py:231-256) leaves behind.  The
+        runner shares the modules' native weight buffers, the embedding, lm_head and norm weights (no copies); it is to the swapped
+        model what the reference's ``use_ft`` monkeypatch is to its HF model (kernel/monkeypatch/ftllama_modeling.py): the same weights
+        behind a static-cache, fused token step.  Needs fp16 weights on one GPU, head_dim 128, bias-free projections, SiLU, default RoPE."""
+        from .checkpoint import runner_config
+        from .quant_linear import HIPQuantLinear
+        hf = model.config.to_dict()
+        rp = hf.get("rope_parameters") or {}
+        if (rp.get("rope_type", "default") != "default") or hf.get("rope_scaling") not in (None, {}):
+            raise ValueError("from_hf: only the default RoPE is implemented")
+        if hf.get("hidden_act", "silu") != "silu" or hf.get("attention_bias") or hf.get("mlp_bias"):
+            raise ValueError("from_hf: a SiLU-gated, bias-free Llama is required")
+        hf.setdefault("rope_theta", rp.get("rope_theta", 10000.0))
+        if hf.get("rope_theta") is None:
+            hf["rope_theta"] = rp.get("rope_theta", 10000.0)
+        cfg = runner_config(hf)
+        layers = model.model.layers
+        pre, arch_linear = {}, {name: [] for name in cfg["linear"]}
+        dev = None
+        for b, layer in enumerate(layers):
+            for name in cfg["linear"]:
+                parent, attr = name.split(".")
+                m = getattr(getattr(layer, parent), attr)
+                if not isinstance(m, HIPQuantLinear) or m.bias is not None or not m.qweight.is_cuda:
+                    raise ValueError(f"model.layers.{b}.{name}: expected a bias-free HIPQuantLinear on the GPU (run prepare_for_inference first)")
+                dev = dev or m.qweight.device
+                pre[(b, name)] = _Lin(m.qweight, m.meta, m.bits, m.mode, m.outfeatures, m.infeatures)
+                arch_linear[name].append(m.bits)
+        f16 = lambda t: t.detach() if t.dtype is torch.float16 else t.detach().to(torch.float16)
+        dense = {"embed": f16(model.model.embed_tokens.weight), "lm_head": f16(model.lm_head.weight), "norm": f16(model.model.norm.weight),
+                 "ln1": [f16(l.input_layernorm.weight) for l in layers], "ln2": [f16(l.post_attention_layernorm.weight) for l in layers]}
+        return cls(cfg, arch_linear, device=dev, max_seq=max_seq, dense=dense, batch=batch, engine=engine, prebuilt=pre, synthetic=False)
 
     # ----------------------------------------------------------------- sizes
     def linear_bytes_per_token(self):

@@ -137,12 +137,20 @@ class SyntheticTokenizer:
 
 @torch.inference_mode()
 def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 128, 128), mode="TPS", get_peak_memory=True):
-    """speed.py:131-255.  ``model``: a runner with reset()/prefill()/decode_step()/generate()
-    (QuantLlama or DenseLlama).  ``tokenizer``: used by TTFT mode as in the reference (None: ids are used directly);
-    ``use_ft`` is accepted for signature parity."""
+    """speed.py:131-255.  ``model``: a runner with reset()/prefill()/decode_step()/generate() (QuantLlama or DenseLlama), or --
+    the reference's calling convention (amq_speed_benchmark.py:152, 253) -- a swapped HF ``LlamaForCausalLM`` itself: with
+    ``use_ft`` (default, the reference's fast path) the runner is built over its modules (QuantLlama.from_hf: shared weights,
+    static cache, fused token step), as the reference's FT monkeypatch does to its HF model.  ``tokenizer``: used by TTFT mode as in
+    the reference (None: ids are used directly)."""
     assert mode.lower() in ["tps", "gemv", "gemm", "ttft"], \
         "speed benchmark mode should be one of ['TPS', 'GeMV', 'GeMM', 'TTFT']"
     batch_size, input_seq_len, gen_seq_len = sizes
+    if not hasattr(model, "decode_step") and hasattr(model, "lm_head") and hasattr(getattr(model, "model", None), "layers"):
+        if not use_ft:
+            raise NotImplementedError("benchmark_speed on an HF model drives the fused runner (use_ft=True); HF's own forward over the "
+                                      "swapped modules is what tests/test_gpu_hf.py exercises")
+        from .llama import QuantLlama
+        model = QuantLlama.from_hf(model, max_seq=max(input_seq_len + gen_seq_len, 64), batch=batch_size if batch_size <= 8 else 1)
     if batch_size != getattr(model, "B", 1):
         # a runner built for another batch (the reference's FT path has a batch-1 cache, ftllama_modeling.py:61-68): the
         # batched prompt pass (GeMM mode) needs no cache and is served anyway; token modes need QuantLlama(batch=batch_size)

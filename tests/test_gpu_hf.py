@@ -179,3 +179,58 @@ def test_hf_greedy_loop_with_past_key_values(n_kv_heads):
         else:
             assert (a - c).abs().max() <= 4e-3 * c.abs().max()      # single rows: the norm is formed in the GEMV prologue (another summation order)
         assert (a - b).abs().max() <= 3e-2 * b.abs().max(), step   # HF's fp16 matmuls on the oracle weights; error compounds over the cached steps
+
+
+@pytest.mark.parametrize("n_kv_heads", [2, 1])
+def test_runner_from_swapped_hf_model(n_kv_heads):
+    """QuantLlama.from_hf: the hipGraph token-step runner built over a swapped HF model (sharing its buffers) generates what HF's own
+    forward generates from the same modules, and what the HF model on the oracle's dequantized weights generates -- the counterpart
+    of switching the reference's benchmark to ``use_ft`` (amq_speed_benchmark.py:152; kernel/monkeypatch/ftllama_modeling.py)"""
+    from amq_amd.llama import QuantLlama
+    from amq_amd.patching import prepare_for_inference
+    model, ref = _quantize_linears(_tiny_llama(n_kv_heads))
+    prepare_for_inference(model, backend="hip")
+    r = QuantLlama.from_hf(model, max_seq=64)
+    q0 = model.model.layers[0].self_attn.q_proj
+    assert r.blocks[0]["self_attn.q_proj"].qn.data_ptr() == q0.qweight.data_ptr()         # shared, not copied
+    assert r.embed.data_ptr() == model.model.embed_tokens.weight.data_ptr() and r.nkv == n_kv_heads
+    ids = torch.randint(0, 1000, (1, 7), generator=torch.Generator().manual_seed(5)).to("cuda:0")
+    steps = 6
+    with torch.inference_mode():
+        hf_logits, hf_tokens, cur, past = [], [], ids, None
+        ref_logits, rcur, rpast = [], ids, None
+        for _ in range(steps):
+            o = model(cur, past_key_values=past, use_cache=True)
+            past, cur = o.past_key_values, o.logits[:, -1].max(1)[1].unsqueeze(1)
+            hf_logits.append(o.logits[0, -1].float().clone()); hf_tokens.append(int(cur.item()))
+            o = ref(rcur, past_key_values=rpast, use_cache=True)
+            rpast, rcur = o.past_key_values, o.logits[:, -1].max(1)[1].unsqueeze(1)
+            ref_logits.append(o.logits[0, -1].float().clone())
+    got = [r.prefill(ids[0]).float().clone()]
+    tokens = [int(r.token.item())]
+    for _ in range(steps - 1):
+        r.decode_step()
+        got.append(r.logits.float().clone()); tokens.append(int(r.token.item()))
+    r.check()
+    same = True
+    for i in range(steps):
+        if same:
+            assert (got[i] - hf_logits[i]).abs().max() <= 3e-2 * hf_logits[i].abs().max(), i      # other attention kernels, same weights
+            assert (got[i] - ref_logits[i]).abs().max() <= 3e-2 * ref_logits[i].abs().max(), i
+        same = same and tokens[i] == hf_tokens[i]
+    assert tokens[0] == hf_tokens[0]
+    with pytest.raises(ValueError, match="HIPQuantLinear"):
+        QuantLlama.from_hf(ref)                                         # nn.Linear layers: not a swapped model
+
+
+def test_benchmark_speed_takes_the_swapped_hf_model():
+    """amq_speed_benchmark.py:152 / 253: ``benchmark_speed(model, ...)`` on the assembled HF model itself; same result schema"""
+    from amq_amd.patching import prepare_for_inference
+    from amq_amd.speed import benchmark_speed
+    model, _ = _quantize_linears(_tiny_llama(2))
+    prepare_for_inference(model, backend="hip")
+    for mode in ("TPS", "GeMV", "GeMM", "TTFT"):
+        r = benchmark_speed(model, iteration=2, sizes=(1, 16, 8), mode=mode, get_peak_memory=(mode == "TPS"))
+        assert r[mode.lower()]["1.16.8"] > 0 and (("peak_memory" in r) == (mode == "TPS"))
+    with pytest.raises(NotImplementedError):
+        benchmark_speed(model, use_ft=False, sizes=(1, 16, 8))
