@@ -116,15 +116,21 @@ def _walk_hip(model, fct):
 def group_sibling_linears(model):
     """Install a :class:`LinearGroup` wherever a module holds HIPQuantLinear children named like one of SIBLING_GROUPS with equal
     input sizes: their few-row forwards then run as ONE grouped launch.  Returns the number of groups made.  The modules
-    themselves (buffers, state_dict keys) are not changed."""
+    themselves (buffers, state_dict keys) are not changed.  Siblings that already form exactly this group are left alone; siblings
+    that carry groups from ELSEWHERE -- the reference's driver assembles a mixed-precision model by ``setattr``-ing linears taken
+    from three separately prepared models (amq_speed_benchmark.py:231-251) -- are regrouped with their new neighbours."""
     made = 0
     for parent in model.modules():
         for names in SIBLING_GROUPS:
             mods = [getattr(parent, n, None) for n in names]
-            if all(isinstance(m, HIPQuantLinear) for m in mods) and len({m.infeatures for m in mods}) == 1 \
-                    and not any("_group" in m.__dict__ for m in mods):
-                LinearGroup(mods)
-                made += 1
+            if not all(isinstance(m, HIPQuantLinear) for m in mods) or len({m.infeatures for m in mods}) != 1:
+                continue
+            grps = [m.__dict__.get("_group") for m in mods]
+            if all(g is not None and g[0] is grps[0][0] and g[1] == i for i, g in enumerate(grps)) and len(grps[0][0].members) == len(mods) \
+                    and all(a is b for a, b in zip(grps[0][0].members, mods)):
+                continue
+            LinearGroup(mods)
+            made += 1
     return made
 
 

@@ -234,3 +234,56 @@ def test_benchmark_speed_takes_the_swapped_hf_model():
         assert r[mode.lower()]["1.16.8"] > 0 and (("peak_memory" in r) == (mode == "TPS"))
     with pytest.raises(NotImplementedError):
         benchmark_speed(model, use_ft=False, sizes=(1, 16, 8))
+
+
+def test_reference_driver_assembly_of_a_mixed_model():
+    """amq_speed_benchmark.py:129-256 on tiny models: three uniformly quantized models are prepared one by one and parked on the CPU;
+    a fresh fp16 base model is deep-copied and every linear is ``setattr``-ed from the model of its bit-width; the assembled model goes
+    to the GPU and into ``benchmark_speed``.  Checked: HF's forward over the assembled model against the same assembly of
+    oracle-weight nn.Linear layers; a second ``prepare_for_inference`` regroups the transplanted siblings and fuses the base model's
+    layers without changing a bit for many rows; ``QuantLlama.from_hf`` / ``benchmark_speed`` take the assembled model."""
+    from amq_amd.llama import QuantLlama
+    from amq_amd.patching import prepare_for_inference
+    from amq_amd.quant_linear import HIPLlamaMLP, HIPRMSNorm
+    from amq_amd.speed import benchmark_speed
+    prepared, refs = {}, {}
+    for bits in (2, 3, 4):
+        m, r = _quantize_linears(_tiny_llama(2), bits_cycle=(bits,))
+        prepare_for_inference(m, backend="gptq" if bits < 4 else "ft")           # (the reference's backend names)
+        prepared[bits], refs[bits] = m.to("cpu"), r
+    base = _tiny_llama(2)
+    model, ref = copy.deepcopy(base), copy.deepcopy(base)
+    rng = np.random.default_rng(3)
+    names = [("self_attn", n) for n in ("q_proj", "k_proj", "v_proj", "o_proj")] + [("mlp", n) for n in ("gate_proj", "up_proj", "down_proj")]
+    arch = {n: [int(b) for b in rng.choice([2, 3, 4], size=2)] for n in names}
+    arch[("self_attn", "q_proj")][1] = arch[("self_attn", "k_proj")][1] = arch[("self_attn", "v_proj")][1] = 3    # one trio from ONE model
+    for li in range(2):
+        for (module, linear) in names:
+            b = arch[(module, linear)][li]
+            for dst, src in ((model, prepared[b]), (ref, refs[b])):
+                parent = getattr(dst.model.layers[li], module)
+                delattr(parent, linear)                                           # amq_speed_benchmark.py:246-249
+                setattr(parent, linear, getattr(getattr(src.model.layers[li], module), linear))
+    model = model.eval().to("cuda:0")
+    ids = torch.randint(0, 1000, (1, 12), generator=torch.Generator().manual_seed(2)).to("cuda:0")
+    with torch.inference_mode():
+        y = model(ids).logits.float()
+        y1 = model(ids[:, :1]).logits.float()
+        y_ref = ref(ids).logits.float()
+    assert (y - y_ref).abs().max() <= 2e-2 * y_ref.abs().max()
+    assert not any(isinstance(m, (HIPLlamaMLP, HIPRMSNorm)) for m in model.modules())          # the base model's containers: nothing fused yet
+    prepare_for_inference(model, backend="hip")                                   # no HQQ layer left to convert: regroup + fuse only
+    l1 = model.model.layers[1]
+    g = l1.self_attn.q_proj.__dict__["_group"][0]
+    assert g.members[1] is l1.self_attn.k_proj and g.members[2] is l1.self_attn.v_proj
+    assert isinstance(l1.mlp, HIPLlamaMLP) and isinstance(l1.input_layernorm, HIPRMSNorm) and "forward" in l1.__dict__
+    with torch.inference_mode():
+        assert torch.equal(model(ids).logits.float(), y)                          # 12 rows: same kernels, same bits
+        z1 = model(ids[:, :1]).logits.float()
+    assert (z1 - y1).abs().max() <= 4e-3 * y1.abs().max()                         # 1 row: norms now formed in the GEMV prologues
+    r = QuantLlama.from_hf(model, max_seq=64)
+    assert [r.blocks[1][f"{m}.{n}"].bits for (m, n) in names] == [arch[k][1] for k in names]
+    lg = r.prefill(ids[0]).float()
+    assert (lg - y[0, -1]).abs().max() <= 3e-2 * y[0, -1].abs().max() and int(lg.argmax()) == int(y[0, -1].argmax())
+    out = benchmark_speed(model, iteration=1, sizes=(1, 12, 4), mode="GeMV", get_peak_memory=False)
+    assert out["gemv"]["1.12.4"] > 0
