@@ -665,8 +665,12 @@ class DenseLlama(QuantLlama):
         return self._prefill_finish(x, S, start_pos, b)
 
 
-def get_memory_footprint(model):
-    """bytes of weights + buffers (amq_speed_benchmark.py:87-95 counts parameters and buffers)"""
+def get_memory_footprint(model, return_buffers=True):
+    """bytes of weights + buffers (amq_speed_benchmark.py:88-95 counts parameters and buffers); takes a runner or, as the reference
+    does, a ``torch.nn.Module`` (e.g. the swapped HF model: HIPQuantLinear keeps its weights in buffers)"""
+    if isinstance(model, torch.nn.Module):
+        mem = sum(p.nelement() * p.element_size() for p in model.parameters())
+        return mem + (sum(b.nelement() * b.element_size() for b in model.buffers()) if return_buffers else 0)
     tot = model.embed.numel() * 2 + model.lm_head.numel() * 2 + model.norm.numel() * 2
     for blk in model.blocks:
         for k, v in blk.items():
