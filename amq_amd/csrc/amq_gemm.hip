@@ -562,10 +562,10 @@ static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
     return gemm_launch_cfg<BITS, MODE, 128, 2>(a, st);
 }
 
-// Many-row policy: the ring kernel (amq_gemm_ring.hip) whenever one of its tile shapes fills the chip (gemm_ring_rows),
+// Many-row policy: the ring kernel (amq_gemm_ring.hip) or the wave-specialised kernel (amq_gemm_ws.hip) whenever one of their tile shapes fills the chip (gemm_many_rows_plan),
 // else the kernels of this file (profiles/r02_gemm_routes.txt, 3-bit, TFLOP/s tiled | ring: 13824x5120 M = 1024 822 | 1060,
 // 4096^2 M = 4096 876 | 1086, M = 2048 (128-row tiles) 814 | 910, M = 1024 615 | 531 -> stays tiled).
-bool gemm_takes_ring(int M, int N, int K) { return K >= 256 && gemm_ring_rows(M, N) != 0; }
+bool gemm_takes_ring(int M, int N, int K) { return K >= 256 && gemm_many_rows_plan(M, N) != 0; }
 
 static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route);
 
@@ -590,7 +590,10 @@ static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int rout
     if (route == GEMM_ROUTE_RING && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
     if (route == GEMM_ROUTE_RING128 && gemm_ring_ok(a)) return launch_gemm_ring(a, st, 128);
     if (route == GEMM_ROUTE_WS && gemm_ring_ok(a)) return launch_gemm_ws(a, st);
-    if (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K) && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
+    if (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K) && gemm_ring_ok(a)) {
+        const int plan = gemm_many_rows_plan(a.M, a.N);          // 256 / 128-row ring tiles, or the 256 x 128 wave-specialised tile
+        return plan < 0 ? launch_gemm_ws(a, st) : launch_gemm_ring(a, st, plan);
+    }
     if (gemm_is_skinny(a.M, a.N, a.K, route)) {
         if (a.mode == MODE_HQQ) {
             if (a.bits == 4) return skinny_launch<4, MODE_HQQ>(a, st);

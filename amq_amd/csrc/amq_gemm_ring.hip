@@ -417,10 +417,31 @@ bool gemm_ring_ok(const GemmArgs& a) {
     return (a.y_stride & 3) == 0 && a.splits <= 1 && a.K >= 128 && a.M >= 1 && xspan < lim && wspan < lim;
 }
 
-// Rows per tile (0: the launch is too small for this kernel).  All tiles of a launch cost the same, so a launch runs in
-// rounds of 256 workgroups: a tile shape is scored by its last-round fill, t / (256 ceil(t / 256)), times 0.85 for 128-row
-// tiles (twice the unpack work per MFMA); a shape needs >= 150 tiles to be considered (profiles/r02_gemm_routes.txt:
-// 128 tiles lose to the round-1 kernel, 160+ win; 11008x4096 at 2048 rows: 344 big tiles 0.89 PFLOP/s, 688 small ones 0.96).
+// Which many-row kernel serves a launch: 256 / 128 = this kernel with that many rows per tile, -1 = the wave-specialised kernel
+// (amq_gemm_ws.hip, 256 x 128 tiles), 0 = the launch is too small for any of them.  All tiles of a launch cost the same, so a launch
+// runs in rounds of 256 workgroups: a tile shape is scored by its last-round fill, t / (256 ceil(t / 256)), times its measured efficiency
+// at full fill relative to the 256 x 256 ring tile -- 0.93 for the wave-specialised 256 x 128 tile, 0.85 for 128-row ring tiles (twice
+// the unpack work per MFMA) -- and needs >= 150 tiles to be considered (profiles/r02_gemm_routes.txt: 128 tiles lose to the round-1
+// kernel, 160+ win).  The three kernels accumulate every output in the same order, so the choice never changes a bit.  Round 3
+// (profiles/r03_gemm_mid_sweep.txt, 3-bit TFLOP/s ring | wave-specialised): wherever the ring kernel would fall back to 128-row tiles,
+// or its 256-row tiles leave the last round mostly empty, the 256 x 128 tile wins by 4-9 % (4096x11008 M = 2048: 1099 | 1169;
+// 5120x13824 M = 4096: 1070 | 1135; 13824x5120 M = 512: 927 | 966); at equal fill the ring kernel wins by 5-15 %.
+int gemm_many_rows_plan(int M, int N) {
+    const long nt = (N + RG_BN - 1) / RG_BN, ntw = (N + 127) / 128;
+    const long t256 = (long)((M + 255) / 256) * nt, t128 = (long)((M + 127) / 128) * nt, tws = (long)((M + 255) / 256) * ntw;
+    auto fill = [](long t) { return (double)t / (256.0 * (double)((t + 255) / 256)); };
+    const double s256 = t256 >= 150 ? fill(t256) : 0.0, s128 = t128 >= 150 ? 0.85 * fill(t128) : 0.0;
+#ifdef AMQ_PLAN_NO_WS               /* A/B build: the round-2 policy (ring tiles only) */
+    const double sws = 0.0;
+#else
+    const double sws = tws >= 150 ? 0.93 * fill(tws) : 0.0;
+#endif
+    if (s256 == 0.0 && s128 == 0.0 && sws == 0.0) return 0;
+    if (s256 >= s128 && s256 >= sws) return 256;
+    return sws >= s128 ? -1 : 128;
+}
+
+// the ring kernel's own choice of tile rows (forced routes, tools)
 int gemm_ring_rows(int M, int N) {
     const long nt = (N + RG_BN - 1) / RG_BN;
     const long t256 = (long)((M + 255) / 256) * nt, t128 = (long)((M + 127) / 128) * nt;

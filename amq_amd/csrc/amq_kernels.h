@@ -78,6 +78,7 @@ hipError_t launch_gemm_ring(const GemmArgs& a, hipStream_t st, int bm = 0);     
 bool gemm_ring_ok(const GemmArgs& a);
 hipError_t launch_gemm_ws(const GemmArgs& a, hipStream_t st);                  // amq_gemm_ws.hip: 256 x 128 tiles, 4 MFMA waves + 4 DMA / unpack waves (same shape conditions: gemm_ring_ok)
 int gemm_ring_rows(int M, int N);                                   // 256 / 128 rows per ring tile, 0: launch too small
+int gemm_many_rows_plan(int M, int N);                              // GEMM_ROUTE_AUTO: 256 / 128 ring tile rows, -1 the wave-specialised kernel, 0 none
 bool gemm_takes_ring(int M, int N, int K);                          // GEMM_ROUTE_AUTO's choice for the shape
 hipError_t launch_gemm_xfrag(const GemmArgs& a, hipStream_t st);     // a.x in fragment order (launch_xfrag)
 hipError_t launch_xfrag(const void* src, void* xf, int M, int K, long stride_m, long stride_kt, hipStream_t st);

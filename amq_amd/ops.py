@@ -217,7 +217,7 @@ def gemm_route_name(M):
     """what :func:`gemm` runs for M rows under the current settings (for result files)"""
     if LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
         return "amq::dequant_kernel + library GEMM (torch.matmul -> hipBLASLt)"
-    return "amq::gemm_ring_kernel / amq::gemm_kernel (fused unpack + MFMA, hand-written; 256x256 ring tiles when they fill the chip)"
+    return "amq::gemm_ring_kernel / amq::gemm_ws_kernel / amq::gemm_kernel (fused unpack + MFMA, hand-written; 256x256 ring tiles when they fill the chip, 256x128 wave-specialised tiles where those fill it better)"
 
 
 def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=GEMM_AUTO, gate=None):
