@@ -1,4 +1,6 @@
 // amq_gemm_ws.hip -- the many-row GEMM with WAVE SPECIALISATION (round 3), gfx950.
+// Slower than the ring kernel at equal fill (profiles/r03_gemm_ws_negative.txt), faster where its half-size tile fills the chip better:
+// launch_gemm takes it for those launches (gemm_many_rows_plan, amq_gemm_ring.hip).
 //
 // Same job as amq_gemm_ring.hip (y[M,N] = x[M,K] . W^T, 2/3/4-bit AMQ-T16 weights, replaces gemm_w4a16_T2,
 // amq/kernel/ft/quantization_new/gemm/gemm_cuda.cu:746-927), different division of labour.  In the ring kernel all 8 waves

@@ -83,7 +83,7 @@ typedef struct amq_gemv_opts {
 #define AMQ_GEMM_SKINNY 2          /* barrier-free K-split-by-wave kernel, M <= 64 */
 #define AMQ_GEMM_RING   3          /* 256 x 256 tiles (128 x 256 when those would not fill the chip), LDS rings for x and packed W, counted waits */
 #define AMQ_GEMM_RING128 4         /* the same kernel forced to 128-row tiles */
-#define AMQ_GEMM_WS 5              /* amq_gemm_ws.hip: 256 x 128 tiles, 4 MFMA waves + 4 DMA / unpack waves per workgroup (A/B tools, tests) */
+#define AMQ_GEMM_WS 5              /* amq_gemm_ws.hip: 256 x 128 tiles, 4 MFMA waves + 4 DMA / unpack waves per workgroup (AUTO takes it where that tile fills the chip better) */
 
 /* capabilities: writes up to `cap` ints {max_gemv_rows_for_K, lds_bytes, ...}; returns the count */
 int amq_query(int K, int* out, int cap);
