@@ -177,8 +177,14 @@ int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qn, const
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream), "gemm_splitk");
 }
 
+// the workspace of a route call holds the dequantized fp16 weights (dequantize-once route) or the split-K partials, never both
+static bool route_is_deq(int route, int M, int N, int K) {
+    return route == AMQ_GEMM_DEQ || (route == AMQ_GEMM_AUTO && amq::gemm_takes_deq(M, N, K));
+}
+
 size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K) {
-    if (M < 1 || N < 1 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_WS) return 0;
+    if (M < 1 || N < 1 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_DEQ) return 0;
+    if (route_is_deq(route, M, N, K)) return (size_t)N * (size_t)K * 2;       // the dequantized fp16 weights
     const int s = amq::gemm_pick_splits(M, N, K, route);
     return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -186,32 +192,40 @@ size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K) {
 int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
                        const void* residual, void* y, int M, int N, int K, int group, int x_stride, int y_stride,
                        void* workspace, size_t workspace_bytes, void* stream) {
-    if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_WS) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
+    if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_DEQ) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     if (route == AMQ_GEMM_SKINNY && M > 64) return fail(AMQ_ESHAPE, "the few-row kernel takes at most 64 rows (got %d)", M);
     const size_t need = amq_gemm_route_workspace_bytes(route, M, N, K);
-    const bool split = need != 0 && workspace != nullptr;          // no workspace: single pass
-    if (split && workspace_bytes < need)
-        return fail(AMQ_EINVAL, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    const bool deq = route_is_deq(route, M, N, K);
+    if (route == AMQ_GEMM_DEQ && !workspace) return fail(AMQ_EINVAL, "AMQ_GEMM_DEQ needs a workspace of N * K * 2 bytes for the fp16 weights");
+    const bool use_ws = need != 0 && workspace != nullptr;         // no workspace: single pass through a fused kernel
+    if (use_ws && workspace_bytes < need)
+        return fail(AMQ_EINVAL, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    const bool split = use_ws && !deq;
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N,
-                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, route) : 1, residual};
+                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, route) : 1, residual, nullptr,
+                    use_ws && deq ? workspace : nullptr};
+    if (route == AMQ_GEMM_DEQ && !amq::gemm_f16w_ok(M, N, K, a.x_stride, a.y_stride))
+        return fail(AMQ_ESHAPE, "AMQ_GEMM_DEQ: strides must be multiples of 8 (x) / 4 (y) halves and x, W must each span < 4 GiB");
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream, route), "gemm");
 }
 
 int amq_gemm_gated_fused(int route, int M, int N, int K, int use_workspace) {
-    if (M < 1 || N < 16 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_WS) return 0;
+    if (M < 1 || N < 16 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_DEQ) return 0;
+    const bool deq = route_is_deq(route, M, N, K);
     amq::GemmArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, M, N, K, 4, AMQ_MODE_HQQ, K, N, nullptr,
-                    use_workspace ? amq::gemm_pick_splits(M, N, K, route) : 1};
+                    use_workspace && !deq ? amq::gemm_pick_splits(M, N, K, route) : 1, nullptr, nullptr,
+                    use_workspace && deq ? (void*)&a : nullptr};      // (any non-null value: only tested for presence)
     return amq::gemm_gate_fused(a, route) ? 1 : 0;
 }
 
 int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
                        const void* gate, void* y, int M, int N, int K, int group, int x_stride, void* workspace,
                        size_t workspace_bytes, void* stream) {
-    if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_WS) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
+    if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_DEQ) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!x || !qn || !mn || !y || !gate) return fail(AMQ_EINVAL, "null pointer");
@@ -219,14 +233,28 @@ int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void*
     if (N % 8) return fail(AMQ_ESHAPE, "the gated product needs N %% 8 == 0 (got %d)", N);
     if (route == AMQ_GEMM_SKINNY && M > 64) return fail(AMQ_ESHAPE, "the few-row kernel takes at most 64 rows (got %d)", M);
     const size_t need = amq_gemm_route_workspace_bytes(route, M, N, K);
-    const bool split = need != 0 && workspace != nullptr;
-    if (split && workspace_bytes < need)
-        return fail(AMQ_EINVAL, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    const bool deq = route_is_deq(route, M, N, K);
+    if (route == AMQ_GEMM_DEQ && !workspace) return fail(AMQ_EINVAL, "AMQ_GEMM_DEQ needs a workspace of N * K * 2 bytes for the fp16 weights");
+    const bool use_ws = need != 0 && workspace != nullptr;
+    if (use_ws && workspace_bytes < need)
+        return fail(AMQ_EINVAL, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    const bool split = use_ws && !deq;
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, N,
-                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, route) : 1, nullptr, gate};
+                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, route) : 1, nullptr, gate,
+                    use_ws && deq ? workspace : nullptr};
     if (gate == y && !amq::gemm_gate_fused(a, route))
         return fail(AMQ_EINVAL, "gate may alias y only where the kernel applies it in its epilogue (amq_gemm_gated_fused)");
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream, route), "gemm_gated");
+}
+
+int amq_gemm_f16w_f16(const void* x, const void* w, const void* bias, const void* residual, const void* gate, void* y,
+                      int M, int N, int K, int x_stride, int y_stride, void* stream) {
+    if (!x || !w || !y) return fail(AMQ_EINVAL, "null pointer");
+    if (residual && gate) return fail(AMQ_EINVAL, "residual and gate are exclusive");
+    const int xs = x_stride ? x_stride : K, ys = y_stride ? y_stride : N;
+    if (!amq::gemm_f16w_ok(M, N, K, xs, ys))
+        return fail(AMQ_ESHAPE, "need M >= 1, N %% 16 == 0, K %% 128 == 0, x_stride %% 8 == 0, y_stride %% 4 == 0, x and W < 4 GiB each (got M=%d N=%d K=%d)", M, N, K);
+    return check_hip(amq::launch_gemm_f16w(x, w, bias, residual, gate, y, M, N, K, xs, ys, (hipStream_t)stream), "gemm_f16w");
 }
 
 int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, const void* residual,

@@ -569,12 +569,30 @@ bool gemm_takes_ring(int M, int N, int K) { return K >= 256 && gemm_many_rows_pl
 
 static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route);
 
+// GEMM_ROUTE_AUTO takes the dequantize-once route (amq_gemm_f16.hip behind the dequantize kernel) where the launch is MFMA-bound:
+// at least DEQ_MIN_ROWS rows and at least one full round of 256 x 256 tiles.  Below, the fused kernels win: they read 2-4 bit
+// weights instead of writing and re-reading 16-bit ones (profiles/r04_gemm_f16pp.txt).
+#ifndef AMQ_DEQ_MIN_ROWS
+#define AMQ_DEQ_MIN_ROWS 2048
+#endif
+bool gemm_takes_deq(int M, int N, int K) {
+    const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+    return M >= AMQ_DEQ_MIN_ROWS && tiles >= 256 && K >= 256;
+}
+
+// the dequantize-once route: forced, or AUTO's choice -- either way only with a scratch for the fp16 weights and without split-K
+static bool gemm_runs_deq(const GemmArgs& a, int route) {
+    if (!a.w16 || a.splits > 1 || !gemm_f16w_ok(a.M, a.N, a.K, a.x_stride, a.y_stride)) return false;
+    return route == GEMM_ROUTE_DEQ || (route == GEMM_ROUTE_AUTO && gemm_takes_deq(a.M, a.N, a.K));
+}
+
+
 // a.gate (y = fp16(silu(gate)) * fp16(x . W^T (+ bias)), no residual): formed in the epilogue by the ring and the few-row
 // kernels; the tiled kernel (with or without split-K) is followed by the element-wise launch instead -- same expression, same bits.
 bool gemm_gate_fused(const GemmArgs& a, int route) {
     const bool ring = (route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128 || route == GEMM_ROUTE_WS ||
                        (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K))) && gemm_ring_ok(a);
-    return ring || gemm_is_skinny(a.M, a.N, a.K, route);
+    return ring || gemm_is_skinny(a.M, a.N, a.K, route) || gemm_runs_deq(a, route);
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route) {
@@ -587,6 +605,11 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route) {
 }
 
 static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route) {
+    if (gemm_runs_deq(a, route)) {
+        // MFMA-bound launches: the exact fp16 weights once (amq_dequantize_f16's kernel), then a GEMM with no unpack in its loop
+        if (hipError_t e = launch_dequantize(a.bits, a.mode, a.qweight, a.meta, a.N, a.K, a.w16, st)) return e;
+        return launch_gemm_f16w(a.x, a.w16, a.bias, a.residual, a.gate, a.y, a.M, a.N, a.K, a.x_stride, a.y_stride, st);
+    }
     if (route == GEMM_ROUTE_RING && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
     if (route == GEMM_ROUTE_RING128 && gemm_ring_ok(a)) return launch_gemm_ring(a, st, 128);
     if (route == GEMM_ROUTE_WS && gemm_ring_ok(a)) return launch_gemm_ws(a, st);

@@ -69,9 +69,11 @@ struct GemmArgs {
     int splits;     // >= 1
     const void* residual;   // fp16 [M, y_stride] added to the rounded result (y = residual + fp16(acc (+ bias))), or null
     const void* gate;       // few-row kernel only: fp16 [M, y_stride]; y = fp16(silu(gate)) * fp16(acc (+ bias)) (LlamaMLP), or null
+    void* w16;              // GEMM_ROUTE_DEQ: caller-owned scratch for the dequantized fp16 weights [N, K] (else null)
 };
 // route: which kernel family serves the launch (AUTO: by shape; the others force one for tests / A-B tools)
-enum { GEMM_ROUTE_AUTO = 0, GEMM_ROUTE_TILED = 1, GEMM_ROUTE_SKINNY = 2, GEMM_ROUTE_RING = 3, GEMM_ROUTE_RING128 = 4, GEMM_ROUTE_WS = 5 };
+enum { GEMM_ROUTE_AUTO = 0, GEMM_ROUTE_TILED = 1, GEMM_ROUTE_SKINNY = 2, GEMM_ROUTE_RING = 3, GEMM_ROUTE_RING128 = 4, GEMM_ROUTE_WS = 5,
+       GEMM_ROUTE_DEQ = 6 /* launch_dequantize into a.w16, then launch_gemm_f16w */ };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route = GEMM_ROUTE_AUTO);
 bool gemm_gate_fused(const GemmArgs& a, int route);                 // a.gate applied in the kernel's epilogue (else: element-wise launch behind it)
 hipError_t launch_gemm_ring(const GemmArgs& a, hipStream_t st, int bm = 0);      // amq_gemm_ring.hip: 256 (or 128) x 256 tiles, LDS rings, counted waits; bm 0 = by shape
@@ -85,6 +87,12 @@ hipError_t launch_xfrag(const void* src, void* xf, int M, int K, long stride_m, 
 // several linears over the same fragment-ordered x as segments of one few-row launch (uses qweight / meta / bias / residual / y / N / bits / mode / y_stride)
 hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg* segs, int nseg, hipStream_t st);
 int gemm_pick_splits(int M, int N, int K, int route = GEMM_ROUTE_AUTO);
+// amq_gemm_f16.hip: y = x . W^T with W as fp16 [N, K] (the dequantized weights, or any dense fp16 matrix): 256 x 256 tiles, two wave
+// groups in ping-pong, no VALU in the K loop; bias / residual / gate epilogues as GemmArgs
+bool gemm_f16w_ok(int M, int N, int K, int x_stride, int y_stride);
+bool gemm_takes_deq(int M, int N, int K);                           // GEMM_ROUTE_AUTO: dequantize once + fp16 GEMM (given a scratch) beats the fused kernels
+hipError_t launch_gemm_f16w(const void* x, const void* w, const void* bias, const void* residual, const void* gate, void* y,
+                            int M, int N, int K, int x_stride, int y_stride, hipStream_t st);
 
 // decode-step surroundings (amq_decode.hip)
 struct AttnArgs {

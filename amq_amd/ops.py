@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (MODE_HQQ, MODE_FMA, PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL, Segment, GemvOpts, EngineBlock, EngineLinear,  # noqa: F401
-                   GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, GEMM_WS, MATH_EXACT, MATH_LINEAR)
+                   GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, GEMM_WS, GEMM_DEQ, MATH_EXACT, MATH_LINEAR)
 
 GROUP = 128
 
@@ -213,6 +213,18 @@ def _dequant_scratch(device, numel):
     return _DEQ_SCRATCH.get(device, numel)[:numel]
 
 
+def _route_workspace(lib, device, route, M, N, K):
+    """(tensor or None, bytes) for ``amq_gemm_route_f16`` / ``amq_gemm_gated_f16``: split-K partials for few rows, the dequantized
+    fp16 weights for the dequantize-once route (GEMM_DEQ, and GEMM_AUTO on MFMA-bound launches)."""
+    need = lib.amq_gemm_route_workspace_bytes(route, M, N, K)
+    if not need:
+        return None, 0
+    if need == N * K * 2 and (route == GEMM_DEQ or route == GEMM_AUTO):
+        return _dequant_scratch(device, N * K), need
+    ws = _splitk_workspace(device, need)
+    return ws, ws.numel() * 4
+
+
 def gemm_route_name(M):
     """what :func:`gemm` runs for M rows under the current settings (for result files)"""
     if LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
@@ -243,16 +255,15 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=
     _need(y, torch.float16, "y", M * N)
     lib = _lib.load()
     if gate is not None:
-        need = lib.amq_gemm_route_workspace_bytes(route, M, N, K)
-        if y.data_ptr() == gate.data_ptr() and not lib.amq_gemm_gated_fused(route, M, N, K, 1 if need else 0):
+        ws, ws_bytes = _route_workspace(lib, x.device, route, M, N, K)
+        if y.data_ptr() == gate.data_ptr() and not lib.amq_gemm_gated_fused(route, M, N, K, 1 if ws_bytes else 0):
             # the tiled kernel cannot apply the gate itself: in place on the gate needs the projection somewhere else first
             up = gemm(x, qn, mn, bits, mode, N, K, bias=bias, route=route)
             silu_mul(gate, up.view(-1), out=y)
             return y.reshape(*x.shape[:-1], N)
-        ws = _splitk_workspace(x.device, need) if need else None
         _lib.check(lib.amq_gemm_gated_f16(route, bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
                                           _lib.ptr(gate), _lib.ptr(y), M, N, K, GROUP, 0, _lib.ptr(ws),
-                                          ws.numel() * 4 if need else 0, _lib.current_stream()))
+                                          ws_bytes, _lib.current_stream()))
         return y.reshape(*x.shape[:-1], N)
     if route == GEMM_AUTO and LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
         w = dequantize(qn, mn, bits, mode, N, K, out=_dequant_scratch(x.device, N * K).view(N, K))
@@ -270,11 +281,27 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=
         else:
             torch.matmul(x2, w.t(), out=y2)
         return y.reshape(*x.shape[:-1], N)
-    need = lib.amq_gemm_route_workspace_bytes(route, M, N, K)
-    ws = _splitk_workspace(x.device, need) if need else None
+    ws, ws_bytes = _route_workspace(lib, x.device, route, M, N, K)
     _lib.check(lib.amq_gemm_route_f16(route, bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
                                       _lib.ptr(residual), _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.ptr(ws),
-                                      ws.numel() * 4 if need else 0, _lib.current_stream()))
+                                      ws_bytes, _lib.current_stream()))
+    return y.reshape(*x.shape[:-1], N)
+
+
+def gemm_f16w(x, w, bias=None, out=None, residual=None, gate=None):
+    """y = x . w^T for DENSE fp16 weights w [N, K] (hand-written ping-pong MFMA kernel, amq_gemm_f16.hip): what GEMM_DEQ runs behind
+    :func:`dequantize`; ``residual`` / ``gate`` as in :func:`gemm`."""
+    _need(w, torch.float16, "w")
+    N, K = w.shape
+    x2 = _prep_x(x, K)
+    M = x2.shape[0]
+    y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=x.device)
+    _need(y, torch.float16, "y", M * N)
+    for t, nm, n in ((bias, "bias", N), (residual, "residual", M * N), (gate, "gate", M * N)):
+        if t is not None:
+            _need(t, torch.float16, nm, n)
+    _lib.check(_lib.load().amq_gemm_f16w_f16(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(gate),
+                                             _lib.ptr(y), M, N, K, 0, 0, _lib.current_stream()))
     return y.reshape(*x.shape[:-1], N)
 
 

@@ -84,6 +84,9 @@ typedef struct amq_gemv_opts {
 #define AMQ_GEMM_RING   3          /* 256 x 256 tiles (128 x 256 when those would not fill the chip), LDS rings for x and packed W, counted waits */
 #define AMQ_GEMM_RING128 4         /* the same kernel forced to 128-row tiles */
 #define AMQ_GEMM_WS 5              /* amq_gemm_ws.hip: 256 x 128 tiles, 4 MFMA waves + 4 DMA / unpack waves per workgroup (AUTO takes it where that tile fills the chip better) */
+#define AMQ_GEMM_DEQ 6             /* dequantize once into the caller's workspace (N * K * 2 bytes), then amq_gemm_f16.hip: a plain fp16 GEMM with no
+                                      unpack in its loop -- GPTQLinear.forward's own split from 128 rows on (hqq/backends/autogptq.py:245-283), hand-written.
+                                      AUTO takes it for MFMA-bound launches when the workspace is passed. */
 
 /* capabilities: writes up to `cap` ints {max_gemv_rows_for_K, lds_bytes, ...}; returns the count */
 int amq_query(int K, int* out, int cap);
@@ -256,11 +259,18 @@ int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qweight_nati
                      const void* bias, const void* residual, void* y, int M, int N, int K, int group, int x_stride,
                      int y_stride, void* workspace, size_t workspace_bytes, void* stream);
 /* The same with the kernel family chosen by the caller (tests, A/B tools); amq_gemm_route_workspace_bytes is the
- * matching workspace query (0: no workspace needed). */
+ * matching workspace query (0: no workspace needed).  The workspace holds split-K partials (few rows) or the dequantized
+ * fp16 weights (AMQ_GEMM_DEQ, and AUTO on MFMA-bound launches) -- never both; without it AUTO runs a fused kernel. */
 size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K);
 int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
                        const void* bias, const void* residual, void* y, int M, int N, int K, int group, int x_stride,
                        int y_stride, void* workspace, size_t workspace_bytes, void* stream);
+/* y = x . W^T (+ bias) (+ residual | silu-gated) with W as DENSE fp16 [N, K] (row-major): the matmul of GPTQLinear.forward's
+ * many-row branch (hqq/backends/autogptq.py:283: torch.matmul(x, weights)) as a hand-written kernel -- what AMQ_GEMM_DEQ runs
+ * behind amq_dequantize_f16, exported for callers that keep fp16 weights (lm_head, an fp16 base model).  N % 16 == 0,
+ * K % 128 == 0, x_stride % 8 == 0, y_stride % 4 == 0 (0 = dense); epilogue operands as amq_gemm_res_f16 / amq_gemm_gated_f16. */
+int amq_gemm_f16w_f16(const void* x, const void* w_f16, const void* bias, const void* residual, const void* gate, void* y,
+                      int M, int N, int K, int x_stride, int y_stride, void* stream);
 /* The LlamaMLP product act_fn(gate_proj(x)) * up_proj(x) with up_proj as this GEMM:
  *     y = fp16(silu(gate)) * fp16(x . W^T (+ bias)),   gate fp16 [M, N] contiguous, y [M, N] contiguous,
  * formed in the epilogue of the kernel that serves the shape (256-row ring and few-row kernels) or by the element-wise
