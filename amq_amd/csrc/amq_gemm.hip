@@ -571,9 +571,11 @@ static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int rout
 
 // GEMM_ROUTE_AUTO takes the dequantize-once route (amq_gemm_f16.hip behind the dequantize kernel) where the launch is MFMA-bound:
 // at least DEQ_MIN_ROWS rows and at least one full round of 256 x 256 tiles.  Below, the fused kernels win: they read 2-4 bit
-// weights instead of writing and re-reading 16-bit ones (profiles/r04_gemm_f16pp.txt).
+// weights instead of writing and re-reading 16-bit ones, and they have smaller tiles for launches that do not fill the chip
+// (profiles/r04_gemm_f16pp.txt, 7B / 13B shapes, dequantize-once over the best fused kernel: 0.63-0.91 at 1024 rows, 0.69-1.03 at 2048,
+// 0.90-1.06 at 4096, 1.02-1.06 at 8192, 1.05-1.10 at 32768).
 #ifndef AMQ_DEQ_MIN_ROWS
-#define AMQ_DEQ_MIN_ROWS 2048
+#define AMQ_DEQ_MIN_ROWS 6144
 #endif
 bool gemm_takes_deq(int M, int N, int K) {
     const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);

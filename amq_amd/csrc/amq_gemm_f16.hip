@@ -36,7 +36,8 @@
 //
 // Measured and NOT adopted (profiles/r04_gemm_f16pp.txt): four phases of 16 MFMAs (the same speed), the operand wait behind the barrier
 // instead of in front of it (same), accumulators pinned to AGPRs by inline-asm MFMAs (same), s_setprio 0 / 3 for the MFMA burst (same),
-// one phase of 64 MFMAs per K-tile (needs a third LDS set: a refilled set would be overwritten under the other wave group's reads).
+// one phase of 64 MFMAs per K-tile (needs a third LDS set: a refilled set would be overwritten under the other wave group's reads),
+// half of the waves issuing their pieces BEFORE their operand reads (hand-over gap 59 -> 80-98 cycles: slower).
 #include "amq_common.cuh"
 #include "amq_kernels.h"
 

@@ -198,12 +198,13 @@ def _splitk_workspace(device, nbytes):
     return _SPLITK_WS.get(device, (nbytes + 3) // 4)
 
 
-# OPT-IN alternative for many rows: from LIB_GEMM_ROWS rows on (0 = never, the default) `gemm` runs the bit-exact dequantize
+# OPT-IN comparison leg for many rows: from LIB_GEMM_ROWS rows on (0 = never, the default) `gemm` runs the bit-exact dequantize
 # kernel into a scratch and hands the plain fp16 GEMM to the library (torch.matmul -> hipBLASLt) -- what the reference itself
 # does from 128 rows on (GPTQLinear.forward: torch unpack + matmul, hqq/backends/autogptq.py:245-283).  The product path is
-# the hand-written kernels at every size (profiles/r02_gemm_routes.txt: the fused ring kernel reaches 1.15-1.3 PFLOP/s at
-# BASELINE configs[3] sizes against 1.43-1.52 for dequantize + hipBLASLt, and beats it on several mid-size shapes);
-# bench.py --config 4 reports the library route next to it.
+# hand-written at every size: the fused kernels below ~6k rows, and from there the same split as the reference's with BOTH halves
+# hand-written (GEMM_DEQ: dequantize kernel + amq_gemm_f16.hip; profiles/r04_gemm_f16pp.txt: 1.33-1.45 PFLOP/s at BASELINE configs[3]
+# sizes against 1.27-1.32 for the fused ring kernel and 1.42-1.52 for dequantize + hipBLASLt, faster than the library up to 8192 rows);
+# bench.py reports the library route next to it.
 LIB_GEMM_ROWS = 0
 _DEQ_SCRATCH = _ScratchPool(torch.float16)
 
@@ -225,11 +226,15 @@ def _route_workspace(lib, device, route, M, N, K):
     return ws, ws.numel() * 4
 
 
-def gemm_route_name(M):
-    """what :func:`gemm` runs for M rows under the current settings (for result files)"""
+def gemm_route_name(M, N=13824, K=5120):
+    """what :func:`gemm` runs for an M-row launch under the current settings (for result files)"""
     if LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
         return "amq::dequant_kernel + library GEMM (torch.matmul -> hipBLASLt)"
-    return "amq::gemm_ring_kernel / amq::gemm_ws_kernel / amq::gemm_kernel (fused unpack + MFMA, hand-written; 256x256 ring tiles when they fill the chip, 256x128 wave-specialised tiles where those fill it better)"
+    if _lib.load().amq_gemm_route_workspace_bytes(GEMM_AUTO, M, N, K) == N * K * 2:
+        return ("amq::dequant_native_kernel + amq::gemm_f16_pp_kernel (dequantize once into a scratch, then a hand-written fp16 MFMA GEMM: "
+                "256x256 tiles, two wave groups in ping-pong, persistent tiles, no unpack in the K loop)")
+    return ("amq::gemm_ring_kernel / amq::gemm_ws_kernel / amq::gemm_kernel (fused unpack + MFMA, hand-written; 256x256 ring tiles when they "
+            "fill the chip, 256x128 wave-specialised tiles where those fill it better)")
 
 
 def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=GEMM_AUTO, gate=None):

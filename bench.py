@@ -213,15 +213,19 @@ def mfma_roofline(dev, seed=0):
         for l in lins:
             ops.gemm(xs[l.K], l.qn, l.mn, l.bits, l.mode, l.N, l.K, out=ys[l.N])
 
-    def timed():
-        linears()
+    def timed(fn=linears):
+        fn()
         torch.cuda.synchronize(dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        linears()
+        fn()
         e1.record()
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) * 1e-3
+
+    def linears_fused():                               # comparison: the fused unpack + MFMA ring kernel on the same launches
+        for l in lins:
+            ops.gemm(xs[l.K], l.qn, l.mn, l.bits, l.mode, l.N, l.K, out=ys[l.N], route=ops.GEMM_RING)
 
     with torch.inference_mode():
         t = timed()
@@ -230,9 +234,11 @@ def mfma_roofline(dev, seed=0):
             t_lib = timed()
         finally:
             ops.LIB_GEMM_ROWS = 0
+        t_fused = timed(linears_fused)
     tf = flops / t / 1e12
     return {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
             "traffic": None, "kernel": ops.gemm_route_name(M), "launches": len(lins), "ms": t * 1e3, "rows": M,
+            "comparison_fused_ring_kernel_tflops": flops / t_fused / 1e12,
             "workload": "the 28 linears of 4 Llama-2-13B blocks, avg-3-bit arch (bits_usage %.3f), M = 16 x 2048 rows "
                         "(BASELINE.json configs[3]); HIP events on the launch stream" % usage,
             "comparison_library_route_tflops": flops / t_lib / 1e12}

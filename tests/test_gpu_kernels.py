@@ -564,12 +564,15 @@ def _sampled_rows_check(y, x, w_dev, rows, what):
 @pytest.mark.parametrize("m,n,k,route", [(640, 12288, 512, 1), (2048, 3072, 256, 1), (517, 6144, 384, 1),
                                          (640, 12288, 512, 3), (2048, 3072, 256, 3), (517, 6144, 384, 3), (300, 1040, 1152, 3),
                                          (640, 12288, 512, 4), (517, 6144, 384, 4), (300, 1040, 1152, 4), (129, 2048, 256, 4),
-                                         (640, 12288, 512, 5), (517, 6144, 384, 5), (300, 1040, 1152, 5), (129, 2048, 256, 5), (2048, 3072, 128, 5)])
+                                         (640, 12288, 512, 5), (517, 6144, 384, 5), (300, 1040, 1152, 5), (129, 2048, 256, 5), (2048, 3072, 128, 5),
+                                         (640, 12288, 512, 6), (517, 6144, 384, 6), (300, 1040, 1152, 6), (129, 2048, 256, 6), (2048, 3072, 128, 6),
+                                         (2600, 6144, 256, 6)])
 def test_gemm_big_tiles(bits, m, n, k, route):
     """the many-row MFMA kernels on shapes that select their LARGE tiles (route 1: gemm_kernel<.,.,128,2> needs
     ceil(M/128) * ceil(N/128) >= 384 workgroups; route 3: the ring kernel, 256-row tiles when they fill the chip; route 4: the
     ring kernel forced to 128-row tiles; route 5: the wave-specialised kernel, amq_gemm_ws.hip, 256 x 128 tiles -- N = 1040 leaves a
-    ragged last column tile, K = 128 a single group), ragged M tails, bias and an in-place
+    ragged last column tile, K = 128 a single group; route 6: dequantize once + the ping-pong fp16 kernel, amq_gemm_f16.hip, whose
+    persistent workgroups walk two tiles each at 2600 x 6144), ragged M tails, bias and an in-place
     residual, against the CPU oracle linear on the reference's dequantized weights."""
     from amq_amd import ops
     h, qn, mn, w_ref = _random_case(bits, n, k, seed=31 * bits + m, bias=True)
@@ -620,7 +623,8 @@ def test_gemm_xfrag_grouped_equals_single_launches(m, k, specs):
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("m,n,k,route", [(20, 1024, 512, 0), (64, 2048, 256, 2), (300, 1040, 1152, 0), (300, 1040, 1152, 1),
                                          (200, 2048, 4096, 0),                       # tiled kernel + split-K, then the element-wise launch
-                                         (2048, 3072, 256, 3), (517, 6144, 384, 4), (2500, 4096, 512, 0), (517, 1040, 384, 5)])
+                                         (2048, 3072, 256, 3), (517, 6144, 384, 4), (2500, 4096, 512, 0), (517, 1040, 384, 5),
+                                         (2048, 3072, 256, 6), (517, 1040, 384, 6)])
 def test_gemm_gated_equals_separate_silu_mul(bits, m, n, k, route):
     """y = fp16(silu(gate)) * fp16(x . W^T + bias) formed by the GEMM (ring / few-row epilogue, or the element-wise launch
     behind the tiled kernel) == amq_silu_mul_f16 on the separately computed projection, bit for bit; in place on the gate."""
@@ -660,7 +664,7 @@ def test_gemm_13b_shapes_at_size(bits, n, k, m):
     rms = ref.pow(2).mean().sqrt()
     rows = torch.tensor(sorted({0, 1, m // 3, m // 2, m - 2, m - 1}), device=dev)
     outs = {}
-    for route in (ops.GEMM_TILED, ops.GEMM_RING, ops.GEMM_RING128, ops.GEMM_WS):
+    for route in (ops.GEMM_TILED, ops.GEMM_RING, ops.GEMM_RING128, ops.GEMM_WS, ops.GEMM_DEQ):
         y = ops.gemm(x, l.qn, l.mn, bits, l.mode, n, k, route=route)
         assert torch.all((y.float() - ref).abs() <= 1e-3 * ref.abs() + 1e-3 * rms), route
         _sampled_rows_check(y, x, w, rows, f"13B {n}x{k} {bits}b M={m} route {route}")
@@ -669,6 +673,52 @@ def test_gemm_13b_shapes_at_size(bits, n, k, m):
     assert torch.all(d <= 2.0 ** -9 * ref.abs() + 1e-3 * rms)
     # the wave-specialised kernel accumulates every output over k in the ring kernel's order (same MFMA chain): same bits
     assert torch.equal(outs[ops.GEMM_WS], outs[ops.GEMM_RING])
+    # the dequantize-once route = the dense fp16 kernel on amq_dequantize_f16's weights, bit for bit; and the ring kernel's bits too
+    # (same MFMA chain over k, and the in-loop unpack forms the same fp16 weights as the dequantize kernel on these layers)
+    assert torch.equal(outs[ops.GEMM_DEQ], ops.gemm_f16w(x, w))
+    assert torch.equal(outs[ops.GEMM_DEQ], outs[ops.GEMM_RING])
+    # what GEMM_AUTO runs: the dequantize-once route from AMQ_DEQ_MIN_ROWS rows on (a workspace of N * K * 2 bytes), a fused kernel below
+    from amq_amd import _lib as _lib_mod
+    need = _lib_mod.load().amq_gemm_route_workspace_bytes(ops.GEMM_AUTO, m, n, k)
+    assert need == (n * k * 2 if m >= 6144 else 0)
+    auto = ops.gemm(x, l.qn, l.mn, bits, l.mode, n, k)
+    if m >= 6144:
+        assert torch.equal(auto, outs[ops.GEMM_DEQ])
+    else:
+        assert any(torch.equal(auto, outs[r]) for r in (ops.GEMM_TILED, ops.GEMM_RING, ops.GEMM_RING128, ops.GEMM_WS))
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (300, 272, 384), (1000, 1040, 1152), (257, 16, 128), (4096, 5120, 1024), (70000, 256, 128)])
+def test_gemm_f16w_dense(m, n, k):
+    """amq_gemm_f16w_f16 (amq_gemm_f16.hip: the matmul of GPTQLinear.forward's many-row branch, hqq/backends/autogptq.py:283, on dense
+    fp16 weights): every output against an fp32 product within 2 fp16 ulps + 2e-3 rms, ragged M / N tiles, one to several tiles
+    per persistent workgroup, bias / residual / SiLU-gate epilogues (the separate fp16 expressions, bit for bit), in place, repeatable."""
+    from amq_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(m + n + k)
+    x = (torch.randn(m, k, device=dev, generator=g) * 0.5).half()
+    w = (torch.randn(n, k, device=dev, generator=g) * 0.05).half()
+    bias = (torch.randn(n, device=dev, generator=g) * 0.1).half()
+    res = torch.randn(m, n, device=dev, generator=g).half()
+    gate = torch.randn(m, n, device=dev, generator=g).half()
+    ref = x.float() @ w.float().t()
+    y = ops.gemm_f16w(x, w)
+    bar = ref.abs() * 2.0 ** -9 + 2e-3 * ref.pow(2).mean().sqrt()
+    assert torch.all((y.float() - ref).abs() <= bar)
+    assert torch.equal(ops.gemm_f16w(x, w), y)
+    assert torch.equal(ops.gemm_f16w(x, w, bias=bias), y + bias)
+    assert torch.equal(ops.gemm_f16w(x, w, bias=bias, residual=res), res + (y + bias))
+    assert torch.equal(ops.gemm_f16w(x, w, gate=gate), ops.silu_mul(gate.view(-1), y.view(-1)).view(m, n))
+    r2 = res.clone()
+    ops.gemm_f16w(x, w, residual=r2, out=r2)
+    assert torch.equal(r2, res + y)
+    g2 = gate.clone()
+    ops.gemm_f16w(x, w, gate=g2, out=g2)
+    assert torch.equal(g2, ops.silu_mul(gate.view(-1), y.view(-1)).view(m, n))
+    with pytest.raises(Exception):
+        ops.gemm_f16w(x, w, residual=res, gate=gate)
+    with pytest.raises(Exception):
+        ops.gemm_f16w(x[:, :k - 64].contiguous(), w[:, :k - 64].contiguous())        # K % 128 != 0
 
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
