@@ -31,6 +31,10 @@ spawns N fresh children, one rank per GPU, BEFORE touching the GPU itself; under
 Ranks are independent replicas (one decode stream per GPU, no data-path collective);
 RCCL is used for the start/stop barrier, the max-over-ranks time and the per-rank rates.
 
+--config 5: BASELINE.json configs[4] -- Llama-2-70B shapes, avg-3-bit arch, one independent decode stream per rank (N = 1: one
+replica on one GPU, the case the driver can record on a one-GPU box; N = 8 is configs[4] itself): same line schema, roofline on the
+70B GEMV launches.  The 7B-specific extras of the default line (per-layer table, MFMA roofline, CPU baseline) are not repeated.
+
 --config 4: BASELINE.json configs[3] instead -- Llama-2-13B avg-3-bit, 16 x 2048 prompt
 rows in one batched prompt pass (the harness' GeMM mode, amq/utils/speed.py:61-71); a step
 is one pass, the roofline object is the MFMA one (linears' flop / time of the linears).
@@ -41,6 +45,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -269,6 +274,69 @@ def cpu_baseline(seed=0):
     return cb.time_decode_linears(layers, cfg["n_block"], tokens=3, extra_dense=lm_head, sample_blocks=4)
 
 
+def host_cpu_info():
+    """model string and PHYSICAL core count of the host the CPU baseline ran on ("core count + CPU model string")"""
+    model, cores = None, set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or None)
+
+
+def parity_gate(dev, seed=7):
+    """The same-run parity gate (north_star: "outputs match the reference CPU nn.Linear-on-dequantized-weights path
+    within 1e-3 relative fp16 tolerance ... in the same run"): for one 4096 x 4096 group-128 layer per bit-width (configs[0]'s shape),
+    y_cpu = F.linear(x, W_deq) on the host with the ORACLE's dequantized weights (hqq/utils/patching.py:95-100 semantics) against
+    y_gpu = the product GEMV / GEMM on the repacked payload of the very same layer, 1 and 5 rows through amq::gemv_kernel and 64 rows
+    through the few-row MFMA kernel.  The bar is the tests' bar; the run FAILS (non-zero exit) outside it."""
+    from amq_amd import ops
+    from amq_amd.hqq_format import random_hqq
+    from oracle import cpu_baseline as cb, hqq_ref
+    n = k = 4096
+    worst_bar, worst_rel, worst_rms, cases = 0.0, 0.0, 0.0, 0
+    for bits in (2, 3, 4):
+        h = random_hqq(n, k, bits, seed=seed + bits)
+        w_deq = cb.dequantize_torch(h.W_q, h.scale, h.zero, bits, (n, k))                 # the oracle port (checked against the numpy
+        w_np = hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (n, k))   # restatement right here)
+        assert np.array_equal(w_deq.numpy().view(np.uint16), w_np.view(np.uint16))
+        hd = h.to(dev)
+        qn, mn = ops.repack_from_hqq(hd.W_q, hd.scale.reshape(-1), hd.zero.reshape(-1), bits, n, k)
+        assert torch.equal(ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).cpu(), w_deq)          # weights: bit for bit
+        for rows in (1, 5, 64):
+            x = torch.randn(rows, k, generator=torch.Generator().manual_seed(seed + rows)).to(torch.float16)
+            with torch.inference_mode():
+                y_cpu = torch.nn.functional.linear(x.float(), w_deq.float()).to(torch.float16).float()   # fp32 accumulate, one fp16 rounding
+                xg = x.to(dev)
+                y_gpu = (ops.gemv(xg, qn, mn, bits, ops.MODE_HQQ, n, k) if rows <= 16 else
+                         ops.gemm(xg, qn, mn, bits, ops.MODE_HQQ, n, k)).float().cpu()
+            rms = float(y_cpu.pow(2).mean().sqrt())
+            err = (y_gpu - y_cpu).abs()
+            worst_bar = max(worst_bar, float((err / (1e-3 * y_cpu.abs() + 1e-3 * rms)).max()))
+            big = y_cpu.abs() >= rms                                                       # relative error where "relative" means something
+            worst_rel = max(worst_rel, float((err[big] / y_cpu.abs()[big]).max()))
+            worst_rms = max(worst_rms, float(err.max()) / rms)
+            cases += 1
+    return {"ok": worst_bar <= 1.0, "max_err_over_bar": worst_bar, "max_rel_err": worst_rel, "max_err_over_rms": worst_rms,
+            "bits": [2, 3, 4], "rows": [1, 5, 64], "shape": [n, k], "cases": cases, "weights_bit_exact": True,
+            "bar": "|y_gpu - y_cpu| <= 1e-3*|y_cpu| + 1e-3*rms(y_cpu); max_rel_err over outputs with |y_cpu| >= rms",
+            "cpu_side": "torch CPU F.linear (fp32 accumulate, one fp16 rounding) on the oracle's dequantized fp16 weights"}
+
+
 def load_traffic():
     """HBM bytes per GEMV launch from this round's committed rocprofv3 PMC pass over the CURRENT kernels
     (profiles/r03_gemv_pmc.json, tools/collect_round.sh r03), or None -- never a stale constant."""
@@ -284,7 +352,10 @@ def load_traffic():
 def run_decode(args, rep, dev):
     rank, n_gpus = rep.rank, rep.world
     max_seq = PROMPT + args.warmup + args.steps + 8
-    m, a, usage = build_model(dev, seed=rank, max_seq=max_seq, engine=False if args.five_launch else (True if args.engine else None))
+    big = args.config == 5                      # BASELINE.json configs[4]: Llama-2-70B, one decode stream per GPU
+    model = "Llama-2-70b-hf" if big else MODEL
+    m, a, usage = build_model(dev, seed=rank, max_seq=max_seq, model=model, pinned=() if big else None,
+                              engine=False if args.five_launch else (True if args.engine else None))
     if args.fuse_qkv_attn:
         m.fuse_qkv_attn = True
     ids = torch.randint(0, m.vocab - 1, (PROMPT,), generator=torch.Generator().manual_seed(rank)).to(dev)
@@ -300,7 +371,8 @@ def run_decode(args, rep, dev):
         return
     roof = gemv_roofline(m)
     out = {
-        "metric": "decode tokens/s, Llama-2-7B AMQ mixed 2/3/4-bit avg-3-bit, batch 1",
+        "metric": "decode tokens/s, Llama-2-%s AMQ mixed 2/3/4-bit avg-3-bit, batch 1%s" % (
+            "70B" if big else "7B", ", %d independent streams" % n_gpus if big else ""),
         "value": n_gpus * args.steps / elapsed,
         "unit": "tokens/s",
         "n_gpus": n_gpus,
@@ -312,11 +384,12 @@ def run_decode(args, rep, dev):
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
-        "config": {"workload": "Llama-2-7B shapes, synthesized avg-3.0-bit per-layer arch (bits_usage %.3f), "
-                               "batch 1 decode after a 64-token prefill, one stream per GPU" % usage,
+        "config": {"workload": "Llama-2-%s shapes, synthesized avg-3.0-bit per-layer arch (bits_usage %.3f), "
+                               "batch 1 decode after a 64-token prefill, one stream per GPU%s" % (
+                                   "70B" if big else "7B", usage, " (BASELINE.json configs[4])" if big else ""),
                    "parallelism": "replicas x%d" % n_gpus, "prompt": PROMPT, "group_size": 128},
         "roofline": {"bound": "hbm", "achieved": roof["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": roof["gbps"] / HBM_PEAK_GBPS, "traffic": load_traffic(),
+                     "frac": roof["gbps"] / HBM_PEAK_GBPS, "traffic": None if big else load_traffic(),
                      "kernel": "amq::gemv_kernel (grouped 2/3/4-bit weight-streaming GEMV)",
                      "bytes_per_launch": roof["bytes_per_launch"], "us_per_launch": roof["us_per_launch"],
                      "launches_per_token": roof["launches_per_token"]},
@@ -332,6 +405,8 @@ def run_decode(args, rep, dev):
         "linear_gb_per_token": m.linear_bytes_per_token() / 1e9,
         "model_gbps": m.total_bytes_per_token(PROMPT + args.warmup + args.steps // 2) / (elapsed / args.steps) / 1e9,
     }
+    if big:
+        args.no_layer_table = args.no_mfma = args.no_cpu_baseline = True      # 7B / 13B-specific extras of the default line
     if n_gpus == 1 and not args.no_layer_table:
         del m
         torch.cuda.empty_cache()
@@ -348,13 +423,20 @@ def run_decode(args, rep, dev):
         except Exception as e:      # noqa: BLE001
             out["dequant_hqq"] = {"error": repr(e)}
         torch.cuda.empty_cache()
+    gate_ok = True
     if n_gpus == 1 and not args.no_cpu_baseline:
+        out["parity"] = parity_gate(dev)
+        gate_ok = out["parity"]["ok"]
         cb = cpu_baseline()
+        cpu_model, physical = host_cpu_info()
         out["cpu_baseline"] = {"value": cb["tokens_per_s_predequantized"], "unit": "tokens/s", "cores": cb["cores"],
+                               "best_threads": cb["cores"], "physical_cores": physical, "cpu_model": cpu_model,
                                "kind": "port", "sample": cb["sample"], "host_threads": cb["host_threads"],
                                "thread_sweep_tokens_per_s": cb["thread_sweep"],
                                "dequant_every_call_tokens_per_s": cb["tokens_per_s_dequant_every_call"]}
     print(json.dumps(out), flush=True)
+    if not gate_ok:
+        raise SystemExit("parity gate failed: GPU output outside the bar against the CPU reference path (see \"parity\" in the line above)")
 
 
 def run_gemm_mode(args, rep, dev):
@@ -431,8 +513,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=3, choices=(3, 4),
-                    help="3 (default): BASELINE.json configs[2], the headline decode metric; 4: configs[3], GeMM mode")
+    ap.add_argument("--config", type=int, default=3, choices=(3, 4, 5),
+                    help="3 (default): BASELINE.json configs[2], the headline decode metric; 4: configs[3], GeMM mode; "
+                         "5: configs[4], Llama-2-70B decode streams (one per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer-table", action="store_true")
     ap.add_argument("--engine", action="store_true", help="A/B: decode steps through the one-launch-per-token engine")
@@ -442,9 +525,9 @@ def main():
     ap.add_argument("--no-mfma", action="store_true", help="skip the batched-path (MFMA) roofline and the dequantize rows")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 256 if args.config == 3 else 3
+        args.steps = {3: 256, 5: 64}.get(args.config, 3)
     if args.warmup is None:
-        args.warmup = 16 if args.config == 3 else 1
+        args.warmup = {3: 16, 5: 8}.get(args.config, 1)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: become one.  Nothing above has touched the GPU (`import torch` does not), and the children are

@@ -88,6 +88,11 @@ def test_bench_gpus_flag_spawns_ranks():
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0
     assert out.stderr.count("needs a GPU") >= 1          # (the second rank may be terminated before it prints)
+    # BASELINE.json configs[4] (one 70B decode stream per rank) takes the same launch path
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "5", "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert out.stderr.count("needs a GPU") >= 1
     # a launcher that started a different number of ranks is an error, not a silent 1-GPU run
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
