@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
 }
 
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
+    StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     const int lds = 2 * 2 * AP_TILE;                    // 64 KiB
     static unsigned long long attr1_done = 0, attr2_done = 0;
     const hipError_t attr1 = ensure_dyn_lds(attr1_done, (const void*)attn_prefill_kernel<1>, lds);

@@ -396,6 +396,7 @@ int amq_decode_engine_f16(const void* blocks_dev, int n_block, int hidden, int i
     amq::EngineDesc d{};
     d.blocks_dev = blocks_dev; d.n_block = n_block; d.H = hidden; d.I = inter; d.n_heads = n_heads; d.n_kv_heads = n_kv_heads;
     d.max_seq = max_seq; d.eps = eps; d.x = x; d.scratch = scratch; d.state = step_state; d.sync = sync; d.grid = grid;
+    amq::StreamDevice sd_((hipStream_t)stream);
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return fail(AMQ_ELAUNCH, "no HIP device");

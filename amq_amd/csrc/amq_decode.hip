@@ -199,6 +199,7 @@ static hipError_t launch_gemv_f16w_n(const void* x, const void* W, const void* b
 // x: fp16 [M, K] contiguous, y: fp16 [M, N] contiguous, 1 <= M <= 8
 hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                             int N, int K, hipStream_t st, int M) {
+    StreamDevice sd_(st);                                  // kernel attributes are per device: the stream's, not the current one
     if (gamma) return launch_gemv_f16w_n<true>(x, W, bias, y, gamma, eps, M, N, K, st);
     return launch_gemv_f16w_n<false>(x, W, bias, y, nullptr, eps, M, N, K, st);
 }
@@ -911,6 +912,7 @@ static int att_chunk_max(int max_seq, int n_splits) {
 }
 
 hipError_t launch_attn_decode_split(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, hipStream_t st) {
+    StreamDevice sd_(st);                                  // kernel attributes are per device: the stream's, not the current one
     const size_t lds = 6 * ATT_D + (size_t)att_chunk_max(a.max_seq, n_splits) * 4;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_decode_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -929,6 +931,7 @@ hipError_t launch_attn_decode_split(const AttnArgs& a, int batch, int n_splits, 
 }
 
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st) {
+    StreamDevice sd_(st);                                  // kernel attributes are per device: the stream's, not the current one
     const size_t lds = 6 * ATT_D + (size_t)a.max_seq * 4;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -450,7 +450,7 @@ __device__ __forceinline__ void eng_run(const EngArgs& a, Issue& is, int& cslot,
             const unsigned long long t2_ = ENG_T();
             eng_issue<U>(a, is, lds0 + ring_off, img, rinfo, wave, lane);
             ENG_ACC(c_issue, t2_);
-            const unsigned long long t3_ = ENG_T();
+            [[maybe_unused]] const unsigned long long t3_ = ENG_T();      // (read by the -DAMQ_ENG_CYCLES build only)
             cslot = cslot + ENG_SLOT == ring_off + U * ENG_SLOT ? ring_off : cslot + ENG_SLOT;
             h2 wv[16];
             dequant_lane_sd<BITS, MODE>(wr, meta, wv);
@@ -863,6 +863,7 @@ size_t engine_lds_bytes(const EngineDesc& d, int P) {
 }
 
 hipError_t launch_decode_engine(const EngineDesc& d, hipStream_t st) {
+    StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

@@ -386,6 +386,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_grouped_kernel(const void* xf
 
 template <int NSUB>
 static hipError_t skinny_grouped_launch(const void* xf, int M, int K, SkinnySegs& sg, int total_wg, hipStream_t st) {
+    StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     auto k = gemm_skinny_grouped_kernel<NSUB>;
     constexpr int LDS = 8 * NSUB * 4096;
     if (LDS > 64 * 1024) {
@@ -419,6 +420,7 @@ hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg
 
 template <int BITS, int MODE, int MB>
 static hipError_t skinny_launch_mb(const GemmArgs& a, hipStream_t st) {
+    StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     // 8 waves split K (two per SIMD overlap each other's fetch / transpose / unpack / MFMA phases: 16.2 -> 12.8 us at
     // 64 x 4096 x 4096 against 4 waves with a 3-deep ring); one 16-column block per workgroup
     constexpr int NWV = 8;
@@ -443,6 +445,7 @@ static hipError_t skinny_launch_mb(const GemmArgs& a, hipStream_t st) {
 // 20.4 / 28.1 / 51.4.
 template <int BITS, int MODE>
 static hipError_t skinny_launch_xf(const GemmArgs& a, hipStream_t st) {
+    StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     const int nblk = a.N >> 4;
     const int ny = (a.M + 63) / 64;
     const long blocks = (long)nblk * ny;

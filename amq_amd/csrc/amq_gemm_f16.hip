@@ -389,6 +389,7 @@ static int pp_grid_limit() {
 
 hipError_t launch_gemm_f16w(const void* x, const void* w, const void* bias, const void* residual, const void* gate, void* y,
                             int M, int N, int K, int x_stride, int y_stride, hipStream_t st) {
+    StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     static unsigned long long attr_done = 0;
     const hipError_t attr = ensure_dyn_lds(attr_done, (const void*)gemm_f16_pp_kernel, PP_LDS_ALLOC);
     if (attr != hipSuccess) return attr;

@@ -393,6 +393,7 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
 
 template <int BITS, int MODE, int BM>
 static hipError_t ring_launch_bm(const GemmArgs& a, hipStream_t st) {
+    StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     auto k = gemm_ring_kernel<BITS, MODE, BM>;
     static unsigned long long attr_done = 0;
     const hipError_t attr = ensure_dyn_lds(attr_done, (const void*)k, rg_lds(BM));

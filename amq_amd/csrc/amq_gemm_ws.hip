@@ -424,6 +424,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(GemmArgs a, int ntm
 
 template <int BITS, int MODE>
 hipError_t ws_launch(const GemmArgs& a, hipStream_t st) {
+    StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     auto k = gemm_ws_kernel<BITS, MODE>;
     static unsigned long long attr_done = 0;
     const hipError_t attr = ensure_dyn_lds(attr_done, (const void*)k, WS_LDS);

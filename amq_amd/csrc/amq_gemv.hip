@@ -997,6 +997,7 @@ size_t gemv_qkv_attn_lds_bytes(int K, int max_seq) {
 
 // q / k / v GEMV (segments 0 .. 2 of `a`: fused RMSNorm prologue, M = 1, no bias / residual) + attention.  tickets: int32 [n_heads], zero.
 hipError_t launch_gemv_qkv_attn(GemvArgs& a, const AttnArgs& t, int* tickets, hipStream_t st) {
+    StreamDevice sd_(st);                                  // kernel attributes are per device: the stream's, not the current one
     int total_rt = 0;
     for (int i = 0; i < 3; ++i) { a.seg[i].n_rt = a.seg[i].N / 16; total_rt += a.seg[i].n_rt; }
     const int chunks = a.K >> 3;
@@ -1104,6 +1105,7 @@ static hipError_t launch_pro(const GemvKArgs& a, int flags, int depth, int nw, i
 
 // Fills the per-segment workgroup ranges and launches.  rpt = row-tiles per workgroup.
 hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
+    StreamDevice sd_(st);                                  // kernel attributes are per device: the stream's, not the current one
     int total_rt = 0;
     for (int i = 0; i < a.nseg; ++i) { a.seg[i].n_rt = a.seg[i].N / 16; total_rt += a.seg[i].n_rt; }
     int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_rt, a.K);

@@ -21,6 +21,23 @@ inline hipError_t ensure_dyn_lds(unsigned long long& done_mask, const void* fn, 
     return e;
 }
 
+// Launchers that set a per-device kernel attribute or size a grid by the CU count must do so for the device the STREAM belongs to, not for
+// whatever device happens to be current: a process that holds weights on cuda:1 while cuda:0 is current (HF device_map, no
+// set_device) launches on cuda:1's stream.  Makes the stream's device current for the scope; the null stream means
+// "the current device" and changes nothing.
+struct StreamDevice {
+    int prev = -1;
+    bool switched = false;
+    explicit StreamDevice(hipStream_t st) {
+        hipDevice_t dev = 0;
+        if (st == nullptr || hipGetDevice(&prev) != hipSuccess || hipStreamGetDevice(st, &dev) != hipSuccess) return;
+        if ((int)dev != prev && hipSetDevice((int)dev) == hipSuccess) switched = true;
+    }
+    ~StreamDevice() { if (switched) (void)hipSetDevice(prev); }
+    StreamDevice(const StreamDevice&) = delete;
+    StreamDevice& operator=(const StreamDevice&) = delete;
+};
+
 enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILU_MUL = 2 };
 enum { FMT_HQQ = 0, FMT_GPTQ = 1, FMT_AWQ = 2 };
 constexpr int GEMV_MAX_SEG = 4;

@@ -173,9 +173,19 @@ def fuse_llama_norms(model):
         for name, consumer in (("input_layernorm", grp[0] if grp is not None else None),
                                ("post_attention_layernorm", mlp if isinstance(mlp, HIPLlamaMLP) else None)):
             norm = getattr(layer, name, None)
+            slot = "qkv" if name == "input_layernorm" else "mlp"
+            if isinstance(norm, HIPRMSNorm):
+                # a second prepare_for_inference (or a sibling transplanted since): the wrapper exists but may point at a group that no
+                # longer owns q/k/v -- re-target it, or un-fuse it when its launch is gone
+                if consumer is None:
+                    setattr(layer, name, norm.__dict__["_inner"])
+                elif norm.__dict__.get("_consumer") is not consumer or norm.__dict__.get("_owner") is not layer:
+                    norm.retarget(consumer, layer, slot)
+                    n += 1
+                continue
             if consumer is None or norm is None or type(norm).__name__ not in RMSNORM_CLASSES or getattr(norm, "weight", None) is None:
                 continue
-            setattr(layer, name, HIPRMSNorm(norm, consumer))
+            setattr(layer, name, HIPRMSNorm(norm, consumer, layer, slot))
             n += 1
     return n
 
@@ -294,7 +304,36 @@ def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False
         fuse_llama_norms(model)
     if fuse_layers:                   # the decoder layers' residual adds into the o_proj / down_proj epilogues
         fuse_llama_layers(model)
+    _warn_unfused(model, group_siblings, fuse_mlp, fuse_norms and group_siblings, fuse_layers)
     return model
+
+
+def _warn_unfused(model, group_siblings, fuse_mlp, fuse_norms, fuse_layers):
+    """One warning per fusion step that was asked for and found NOTHING to fuse on a model that does hold HIPQuantLinear projections
+    with the Llama names: the steps recognise HF's module structure by shape (child names, SiLU, LlamaRMSNorm, the 5.x decoder-layer
+    signature), so a transformers refactor would otherwise fall back to 13 launches per block without a word.  Correctness is not
+    affected either way."""
+    import warnings
+    lins = [(n.rsplit(".", 1)[-1], m) for n, m in model.named_modules() if isinstance(m, HIPQuantLinear)]
+    names = {n for n, _ in lins}
+    if not lins:
+        return
+    sib = {n for g in SIBLING_GROUPS for n in g}
+    if group_siblings and names & sib and not any("_group" in m.__dict__ for n, m in lins if n in sib):
+        warnings.warn("prepare_for_inference: q/k/v / gate/up siblings found but none could be grouped (group_sibling_linears matched "
+                      "nothing): every projection runs as its own launch", RuntimeWarning, stacklevel=3)
+    if fuse_mlp and {"gate_proj", "up_proj", "down_proj"} <= names and not any(isinstance(m, HIPLlamaMLP) for m in model.modules()):
+        warnings.warn("prepare_for_inference: gate/up/down projections found but no MLP was fused (fuse_llama_mlps matched nothing: "
+                      "no SiLU-gated, bias-free MLP of three HIPQuantLinear children)", RuntimeWarning, stacklevel=3)
+    layers = [m for m in model.modules() if all(hasattr(m, k) for k in ("input_layernorm", "self_attn", "post_attention_layernorm", "mlp"))
+              and any(isinstance(c, HIPQuantLinear) for c in m.modules())]
+    if fuse_norms and layers and not any(isinstance(m, HIPRMSNorm) for m in model.modules()):
+        warnings.warn("prepare_for_inference: decoder layers found but no RMSNorm was fused into its consumer (fuse_llama_norms matched "
+                      "nothing: needs a grouped q/k/v, a fused MLP and a LlamaRMSNorm-class norm)", RuntimeWarning, stacklevel=3)
+    if fuse_layers and layers and not any("forward" in m.__dict__ for m in layers):
+        warnings.warn("prepare_for_inference: decoder layers found but none took the fused forward (fuse_llama_layers matched nothing: "
+                      "the layer class is not transformers' LlamaDecoderLayer with the known forward signature); residual adds stay "
+                      "separate launches", RuntimeWarning, stacklevel=3)
 
 
 def load_reference_cache(state_dict, device="cuda"):

@@ -126,6 +126,7 @@ def _defer(consumer, norm, x):
     """record that ``x`` is the RAW input of ``norm`` and that ``consumer``'s next launch has to normalise it"""
     p = consumer.__dict__.get("_norm")
     if p is not None:
+        consumer.__dict__["_norm"] = None       # (reported once: a forward that died between the norm and its consumer must not brick the model)
         raise RuntimeError("a deferred RMSNorm output was never consumed by the grouped linears it was fused into "
                            "(the module that follows the norm does not read it through q/k/v or gate/up): "
                            "call prepare_for_inference(..., fuse_norms=False) for this model")
@@ -154,18 +155,45 @@ class HIPRMSNorm(nn.Module):
     else (more rows, other dtypes) runs the wrapped module.  ``weight`` is the wrapped module's own Parameter, so state_dict
     keys are unchanged."""
 
-    def __init__(self, inner, consumer):
+    def __init__(self, inner, consumer, owner=None, slot=None):
         super().__init__()
         self.weight = inner.weight
         self.variance_epsilon = float(getattr(inner, "variance_epsilon", getattr(inner, "eps", 0.0)))
         self.__dict__["_inner"] = inner          # not registered: the state_dict keeps ``<norm>.weight`` only
+        self.retarget(consumer, owner, slot)
+
+    def retarget(self, consumer, owner=None, slot=None):
+        """(re)bind the launch this norm is fused into.  ``owner`` (the decoder layer; kept in __dict__, not as a sub-module, so that
+        deepcopy / pickling of the model carry it along) and ``slot`` ("qkv" | "mlp") let
+        every forward verify that the consumer is STILL what follows the norm -- a sibling replaced after prepare_for_inference, or a
+        second prepare_for_inference that regrouped q/k/v, leaves a stale group behind that would otherwise get the un-normalised x."""
         self.__dict__["_consumer"] = consumer
+        self.__dict__["_owner"] = owner
+        self.__dict__["_slot"] = slot
+
+    def _consumer_is_current(self, c):
+        owner = self.__dict__.get("_owner")
+        if owner is None:
+            return True                          # (bound by hand, no layer to check against)
+        if self.__dict__.get("_slot") == "mlp":
+            return getattr(owner, "mlp", None) is c
+        attn = getattr(owner, "self_attn", None)
+        ms = getattr(c, "members", None)
+        if attn is None or ms is None or len(ms) != 3:
+            return False
+        for i, name in enumerate(("q_proj", "k_proj", "v_proj")):
+            m = getattr(attn, name, None)
+            g = m.__dict__.get("_group") if m is not None else None
+            if m is not ms[i] or g is None or g[0] is not c:
+                return False
+        return True
 
     def forward(self, x):
         c = self.__dict__["_consumer"]
         K = self.weight.numel()
         if (x.dtype is torch.float16 and x.is_cuda and x.is_contiguous() and x.shape[-1] == K and 0 < x.numel() // K <= GROUP_MAX_ROWS
-                and self.weight.dtype is torch.float16 and self.weight.device == x.device and c.accepts_norm(x)):
+                and self.weight.dtype is torch.float16 and self.weight.device == x.device and self._consumer_is_current(c)
+                and c.accepts_norm(x)):
             c.defer_norm(self, x)
             return x
         return self.__dict__["_inner"](x)
@@ -320,7 +348,9 @@ class HIPQuantLinear(nn.Module):
                 hold[0] = None                        # consumed: the caller does not add it again
                 return y
         grp = self.__dict__.get("_group")
-        if grp is not None and M <= GROUP_MAX_ROWS:  # q/k/v, gate/up: one grouped launch for all siblings (LinearGroup)
+        # q/k/v, gate/up: one grouped launch for all siblings (LinearGroup) -- fp16 callers only: a cast input is a fresh tensor per sibling
+        # call, the group would never recognise it and every sibling would launch the whole group
+        if grp is not None and M <= GROUP_MAX_ROWS and x_dtype == torch.float16:
             y = grp[0].take(grp[1], x)
             if y is not None:
                 return y if x_dtype == torch.float16 else y.to(x_dtype)

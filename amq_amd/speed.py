@@ -135,22 +135,62 @@ class SyntheticTokenizer:
         return self.tk.decode(list(ids))
 
 
+class HFForwardRunner:
+    """``use_ft=False``: a (swapped) HF causal LM driven through ITS OWN forward, with the runner surface this harness times.  The
+    reference's non-FT branches restated: TPS = ``model.generate(ids, min_new_tokens=G, max_new_tokens=G, do_sample=False, num_beams=1,
+    attention_mask=...)`` (amq/utils/speed.py:31-36), GeMV / GeMM = the ``past_key_values`` loop with the arg-max token fed back
+    (speed.py:93-125).  Nothing is captured or fused here beyond what ``prepare_for_inference`` left in the modules."""
+
+    def __init__(self, model, batch=1, max_seq=None):
+        self.model = model
+        self.dev = next(model.parameters()).device
+        self.vocab = int(model.config.vocab_size)
+        self.max_seq = int(max_seq or getattr(model.config, "max_position_embeddings", 1 << 30))
+        self.B = int(batch)
+        self.reset()
+
+    def reset(self):
+        self.past, self.token, self.logits = None, None, None
+
+    def capture(self):          # (the runner's hipGraph hook: HF's forward is timed eagerly, as the reference does)
+        pass
+
+    def _step(self, ids):
+        out = self.model(ids, past_key_values=self.past, use_cache=True)
+        self.past, self.logits = out.past_key_values, out.logits[:, -1]
+        self.token = self.logits.max(1)[1].unsqueeze(1)             # speed.py:107 / 121
+        return self.logits
+
+    def prefill(self, ids):
+        self.past = None
+        return self._step(ids.view(1, -1) if ids.dim() == 1 else ids)
+
+    def decode_step(self):
+        return self._step(self.token)
+
+    def generate(self, ids, n):
+        ids = ids.view(1, -1) if ids.dim() == 1 else ids
+        return self.model.generate(ids, min_new_tokens=n, max_new_tokens=n, do_sample=False, num_beams=1,
+                                   attention_mask=torch.ones_like(ids))
+
+
 @torch.inference_mode()
 def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 128, 128), mode="TPS", get_peak_memory=True):
     """speed.py:131-255.  ``model``: a runner with reset()/prefill()/decode_step()/generate() (QuantLlama or DenseLlama), or --
     the reference's calling convention (amq_speed_benchmark.py:152, 253) -- a swapped HF ``LlamaForCausalLM`` itself: with
     ``use_ft`` (default, the reference's fast path) the runner is built over its modules (QuantLlama.from_hf: shared weights,
-    static cache, fused token step), as the reference's FT monkeypatch does to its HF model.  ``tokenizer``: used by TTFT mode as in
+    static cache, fused token step), as the reference's FT monkeypatch does to its HF model; with ``use_ft=False`` HF's own forward /
+    ``generate`` is timed (HFForwardRunner: the reference's non-FT loops).  ``tokenizer``: used by TTFT mode as in
     the reference (None: ids are used directly)."""
     assert mode.lower() in ["tps", "gemv", "gemm", "ttft"], \
         "speed benchmark mode should be one of ['TPS', 'GeMV', 'GeMM', 'TTFT']"
     batch_size, input_seq_len, gen_seq_len = sizes
     if not hasattr(model, "decode_step") and hasattr(model, "lm_head") and hasattr(getattr(model, "model", None), "layers"):
-        if not use_ft:
-            raise NotImplementedError("benchmark_speed on an HF model drives the fused runner (use_ft=True); HF's own forward over the "
-                                      "swapped modules is what tests/test_gpu_hf.py exercises")
-        from .llama import QuantLlama
-        model = QuantLlama.from_hf(model, max_seq=max(input_seq_len + gen_seq_len, 64), batch=batch_size if batch_size <= 8 else 1)
+        if use_ft:
+            from .llama import QuantLlama
+            model = QuantLlama.from_hf(model, max_seq=max(input_seq_len + gen_seq_len, 64), batch=batch_size if batch_size <= 8 else 1)
+        else:
+            model = HFForwardRunner(model, batch=batch_size)
     if batch_size != getattr(model, "B", 1):
         # a runner built for another batch (the reference's FT path has a batch-1 cache, ftllama_modeling.py:61-68): the
         # batched prompt pass (GeMM mode) needs no cache and is served anyway; token modes need QuantLlama(batch=batch_size)
@@ -195,7 +235,7 @@ def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 1
             else:
                 ids = input_ids
             model.prefill(ids)
-            first = int(model.token.item())       # argmax token back on the host
+            first = int(model.token.reshape(-1)[0].item())       # argmax token back on the host
             if tokenizer is not None:
                 _ = tokenizer.decode([first])
             torch.cuda.synchronize()
@@ -210,4 +250,4 @@ def benchmark_speed(model, tokenizer=None, use_ft=True, iteration=1, sizes=(1, 1
     return data
 
 
-__all__ = ["benchmark_speed", "SyntheticTokenizer"]
+__all__ = ["benchmark_speed", "SyntheticTokenizer", "HFForwardRunner"]

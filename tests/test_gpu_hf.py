@@ -232,8 +232,113 @@ def test_benchmark_speed_takes_the_swapped_hf_model():
     for mode in ("TPS", "GeMV", "GeMM", "TTFT"):
         r = benchmark_speed(model, iteration=2, sizes=(1, 16, 8), mode=mode, get_peak_memory=(mode == "TPS"))
         assert r[mode.lower()]["1.16.8"] > 0 and (("peak_memory" in r) == (mode == "TPS"))
-    with pytest.raises(NotImplementedError):
-        benchmark_speed(model, use_ft=False, sizes=(1, 16, 8))
+    # use_ft=False: the reference's non-FT loops (speed.py:22-46, 93-125) over HF's own forward / generate on the swapped model
+    for mode in ("TPS", "GeMV", "GeMM", "TTFT"):
+        r = benchmark_speed(model, use_ft=False, iteration=2, sizes=(1, 16, 8), mode=mode, get_peak_memory=False)
+        assert r[mode.lower()]["1.16.8"] > 0
+    r = benchmark_speed(model, use_ft=False, iteration=1, sizes=(2, 16, 4), mode="GeMV", get_peak_memory=False)     # HF's forward takes a batch
+    assert r["gemv"]["2.16.4"] > 0
+
+
+@pytest.mark.parametrize("n_kv_heads", [2, 1])
+def test_hf_generate_on_the_swapped_model(n_kv_heads):
+    """the reference's TPS call (amq/utils/speed.py:31-36): ``model.generate(ids, min_new_tokens=G, max_new_tokens=G, do_sample=False,
+    num_beams=1, attention_mask=...)`` on the prepare_for_inference'd HF model -- HF's generation loop, cache and sampling code over
+    the fused modules.  Same tokens as the plain module swap (every fusion is value-preserving up to the norm's summation order) and,
+    while the arg-max margins allow, as the same HF model on the oracle's dequantized weights."""
+    from amq_amd.patching import prepare_for_inference
+    G = 8
+    model, ref = _quantize_linears(_tiny_llama(n_kv_heads))
+    prepare_for_inference(model, backend="hip")
+    plain, _ = _quantize_linears(_tiny_llama(n_kv_heads))
+    prepare_for_inference(plain, backend="hip", group_siblings=False, fuse_mlp=False, fuse_layers=False)
+    ids = torch.randint(0, 1000, (1, 9), generator=torch.Generator().manual_seed(4)).to("cuda:0")
+    kw = dict(min_new_tokens=G, max_new_tokens=G, do_sample=False, num_beams=1, attention_mask=torch.ones_like(ids), pad_token_id=0)
+    with torch.inference_mode():
+        out = model.generate(ids, **kw)
+        out_plain = plain.generate(ids, **kw)
+        out_ref = ref.generate(ids, **kw)
+        again = model.generate(ids, **kw)
+    assert out.shape == (1, 9 + G) and torch.equal(out[:, :9], ids)
+    assert torch.equal(out, again)                                       # repeatable: no state leaks between calls (deferred norms all consumed)
+    # token-level agreement: identical until a step whose top-2 logit margin is inside the numerical distance of the two stacks
+    def first_diff(a, b):
+        d = (a[0] != b[0]).nonzero()
+        return int(d[0]) if len(d) else a.shape[1]
+    assert first_diff(out, out_plain) >= 9 + 1 and first_diff(out, out_ref) >= 9 + 1
+    for other, tol in ((out_plain, 4e-3), (out_ref, 3e-2)):
+        k = first_diff(out, other)
+        if k < 9 + G:                                                   # a divergence must be a near-tie, not an error
+            with torch.inference_mode():
+                lg = model(out[:, :k]).logits[0, -1].float()
+            top2 = lg.topk(2).values
+            assert float(top2[0] - top2[1]) <= 2 * tol * float(lg.abs().max()), (k, top2)
+
+
+def test_prepare_warns_when_a_fusion_step_matches_nothing():
+    """a model that holds HIPQuantLinear projections under the Llama names but whose containers the fusion steps do not recognise
+    (here: an MLP whose activation is not SiLU, decoder layers of an unknown class) gets ONE warning per step instead of a silent
+    fall-back to one launch per projection; a recognised model stays silent."""
+    import warnings
+    from amq_amd.patching import prepare_for_inference
+    model, _ = _quantize_linears(_tiny_llama(2))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        prepare_for_inference(model, backend="hip")                                   # everything fuses: no warning
+    odd, _ = _quantize_linears(_tiny_llama(2))
+    for layer in odd.model.layers:
+        layer.mlp.act_fn = torch.nn.GELU()                                             # not a SiLU-gated MLP any more
+    with pytest.warns(RuntimeWarning) as rec:
+        prepare_for_inference(odd, backend="hip")
+    msgs = " | ".join(str(w.message) for w in rec)
+    assert "no MLP was fused" in msgs and "grouped" not in msgs            # (input_layernorm still fuses into q/k/v: no norm warning)
+    odd2, _ = _quantize_linears(_tiny_llama(2))
+    for layer in odd2.model.layers:                                          # a decoder-layer class the forward patch does not know
+        layer.__class__ = type("RefactoredDecoderLayer", (layer.__class__,), {})
+    with pytest.warns(RuntimeWarning, match="none took the fused forward"):
+        prepare_for_inference(odd2, backend="hip")
+    ids = torch.randint(0, 1000, (1, 3), generator=torch.Generator().manual_seed(1)).to("cuda:0")
+    with torch.inference_mode():
+        assert torch.isfinite(odd(ids).logits.float()).all()                          # (and the model still runs, unfused)
+
+
+def test_fused_norm_follows_its_consumer_when_siblings_are_replaced():
+    """replacing a sibling after prepare_for_inference (or preparing twice) must not leave a fused norm pointing at a group
+    that no longer runs: the norm checks its consumer on every forward (falls back to HF's module), a second prepare re-targets it,
+    and a forward that dies between the norm and its consumer does not brick the model."""
+    from amq_amd.patching import prepare_for_inference
+    from amq_amd.quant_linear import HIPRMSNorm
+    model, _ = _quantize_linears(_tiny_llama(2))
+    prepare_for_inference(model, backend="hip")
+    ids = torch.randint(0, 1000, (1, 1), generator=torch.Generator().manual_seed(3)).to("cuda:0")
+    with torch.inference_mode():
+        y0 = model(ids).logits.float().clone()
+    # replace k_proj of layer 0 by a copy of itself (same weights; the copy carries a group of COPIES, not the layer's q/k/v group)
+    attn = model.model.layers[0].self_attn
+    old = attn.k_proj
+    new = copy.deepcopy(old)
+    assert new.__dict__["_group"][0] is not old.__dict__["_group"][0]
+    attn.k_proj = new
+    norm = model.model.layers[0].input_layernorm
+    assert isinstance(norm, HIPRMSNorm)
+    with torch.inference_mode():
+        y1 = model(ids).logits.float().clone()               # stale group: the norm notices and runs HF's module; q/v still group-launch
+        y1b = model(ids).logits.float()
+    assert torch.equal(y1, y1b)
+    assert (y1 - y0).abs().max() <= 4e-3 * y0.abs().max()    # same function (the norm's summation order differs)
+    prepare_for_inference(model, backend="hip")              # regroups q/k/v around the new sibling and re-targets the norm
+    g = attn.q_proj.__dict__["_group"][0]
+    assert g.members[1] is new and norm.__dict__["_consumer"] is g
+    with torch.inference_mode():
+        y2 = model(ids).logits.float()
+    assert torch.equal(y2, y0)                                # fused again: the original bits
+    # a forward that dies after the norm deferred: the next forward reports it once, the one after works
+    x = torch.randn(1, 1, 256, device="cuda:0").half()
+    with torch.inference_mode():
+        norm(x)
+        with pytest.raises(RuntimeError, match="never consumed"):
+            norm(x)
+        assert torch.equal(model(ids).logits.float(), y0)
 
 
 def test_reference_driver_assembly_of_a_mixed_model():
