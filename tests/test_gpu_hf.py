@@ -63,7 +63,8 @@ def test_hf_llama_with_swapped_linears_matches_oracle_weights(n_kv_heads, seq):
         y_ref = ref(ids).logits.float()
     assert torch.isfinite(y).all()
     # HF's own fp16 matmuls on the oracle weights accumulate in a different order: logits agree to fp16 rounding of the stack
-    assert (y - y_ref).abs().max() <= 2e-2 * y_ref.abs().max()
+    # (measured on MI355X: <= 8e-4 of the largest logit over both head layouts and 1 / 5 / 24 rows; the bar is 2.5 x that)
+    assert (y - y_ref).abs().max() <= 2e-3 * y_ref.abs().max()
     from amq_amd.quant_linear import HIPRMSNorm
     assert sum(isinstance(m, HIPRMSNorm) for m in model.modules()) == 4           # both norms of both layers fused into their consumers
     # grouped and ungrouped swaps are the same function, bit for bit (one launch vs three: same kernel per segment)
@@ -178,7 +179,7 @@ def test_hf_greedy_loop_with_past_key_values(n_kv_heads):
             assert torch.equal(a, c)                     # 6 prompt rows: deferred norms do not apply; residual epilogues round like the adds
         else:
             assert (a - c).abs().max() <= 4e-3 * c.abs().max()      # single rows: the norm is formed in the GEMV prologue (another summation order)
-        assert (a - b).abs().max() <= 3e-2 * b.abs().max(), step   # HF's fp16 matmuls on the oracle weights; error compounds over the cached steps
+        assert (a - b).abs().max() <= 1e-2 * b.abs().max(), step   # HF's fp16 matmuls on the oracle weights; error compounds over the cached steps
 
 
 @pytest.mark.parametrize("n_kv_heads", [2, 1])
@@ -215,8 +216,8 @@ def test_runner_from_swapped_hf_model(n_kv_heads):
     same = True
     for i in range(steps):
         if same:
-            assert (got[i] - hf_logits[i]).abs().max() <= 3e-2 * hf_logits[i].abs().max(), i      # other attention kernels, same weights
-            assert (got[i] - ref_logits[i]).abs().max() <= 3e-2 * ref_logits[i].abs().max(), i
+            assert (got[i] - hf_logits[i]).abs().max() <= 1e-2 * hf_logits[i].abs().max(), i      # other attention kernels, same weights
+            assert (got[i] - ref_logits[i]).abs().max() <= 1e-2 * ref_logits[i].abs().max(), i
         same = same and tokens[i] == hf_tokens[i]
     assert tokens[0] == hf_tokens[0]
     with pytest.raises(ValueError, match="HIPQuantLinear"):
@@ -375,7 +376,7 @@ def test_reference_driver_assembly_of_a_mixed_model():
         y = model(ids).logits.float()
         y1 = model(ids[:, :1]).logits.float()
         y_ref = ref(ids).logits.float()
-    assert (y - y_ref).abs().max() <= 2e-2 * y_ref.abs().max()
+    assert (y - y_ref).abs().max() <= 2e-3 * y_ref.abs().max()
     assert not any(isinstance(m, (HIPLlamaMLP, HIPRMSNorm)) for m in model.modules())          # the base model's containers: nothing fused yet
     prepare_for_inference(model, backend="hip")                                   # no HQQ layer left to convert: regroup + fuse only
     l1 = model.model.layers[1]
@@ -389,6 +390,6 @@ def test_reference_driver_assembly_of_a_mixed_model():
     r = QuantLlama.from_hf(model, max_seq=64)
     assert [r.blocks[1][f"{m}.{n}"].bits for (m, n) in names] == [arch[k][1] for k in names]
     lg = r.prefill(ids[0]).float()
-    assert (lg - y[0, -1]).abs().max() <= 3e-2 * y[0, -1].abs().max() and int(lg.argmax()) == int(y[0, -1].argmax())
+    assert (lg - y[0, -1]).abs().max() <= 1e-2 * y[0, -1].abs().max() and int(lg.argmax()) == int(y[0, -1].argmax())
     out = benchmark_speed(model, iteration=1, sizes=(1, 12, 4), mode="GeMV", get_peak_memory=False)
     assert out["gemv"]["1.12.4"] > 0
