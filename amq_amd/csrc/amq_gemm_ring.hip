@@ -427,10 +427,24 @@ bool gemm_ring_ok(const GemmArgs& a) {
 // (profiles/r03_gemm_mid_sweep.txt, 3-bit TFLOP/s ring | wave-specialised): wherever the ring kernel would fall back to 128-row tiles,
 // or its 256-row tiles leave the last round mostly empty, the 256 x 128 tile wins by 4-9 % (4096x11008 M = 2048: 1099 | 1169;
 // 5120x13824 M = 4096: 1070 | 1135; 13824x5120 M = 512: 927 | 966); at equal fill the ring kernel wins by 5-15 %.
+// workgroup slots of one round = CUs of the current device (256 on an MI355X; smaller on a partitioned part)
+static long plan_slots() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cus[dev & 63];
+    if (c == 0) {
+        int v = 0;
+        c = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return c;
+}
+
 int gemm_many_rows_plan(int M, int N) {
     const long nt = (N + RG_BN - 1) / RG_BN, ntw = (N + 127) / 128;
     const long t256 = (long)((M + 255) / 256) * nt, t128 = (long)((M + 127) / 128) * nt, tws = (long)((M + 255) / 256) * ntw;
-    auto fill = [](long t) { return (double)t / (256.0 * (double)((t + 255) / 256)); };
+    const long S = plan_slots();
+    auto fill = [S](long t) { return (double)t / ((double)S * (double)((t + S - 1) / S)); };
     const double s256 = t256 >= 150 ? fill(t256) : 0.0, s128 = t128 >= 150 ? 0.85 * fill(t128) : 0.0;
 #ifdef AMQ_PLAN_NO_WS               /* A/B build: the round-2 policy (ring tiles only) */
     const double sws = 0.0;
@@ -446,7 +460,8 @@ int gemm_many_rows_plan(int M, int N) {
 int gemm_ring_rows(int M, int N) {
     const long nt = (N + RG_BN - 1) / RG_BN;
     const long t256 = (long)((M + 255) / 256) * nt, t128 = (long)((M + 127) / 128) * nt;
-    auto fill = [](long t) { return (double)t / (256.0 * (double)((t + 255) / 256)); };
+    const long S = plan_slots();
+    auto fill = [S](long t) { return (double)t / ((double)S * (double)((t + S - 1) / S)); };
     const double s256 = t256 >= 150 ? fill(t256) : 0.0, s128 = t128 >= 150 ? 0.85 * fill(t128) : 0.0;
     if (s256 == 0.0 && s128 == 0.0) return 0;
     return s256 >= s128 ? 256 : 128;

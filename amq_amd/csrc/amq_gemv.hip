@@ -811,7 +811,9 @@ __device__ __forceinline__ void qkv_attention(const AttnTail& at, int h, const _
             if (++spins > QA_SPIN_LIMIT) { bad = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
-        __hip_atomic_store(at.tickets + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // all 24 arrivals are in (or the launch gave up)
+        // all 24 arrivals are in: reset for the next launch.  After a time-out the ticket is LEFT ALONE -- late producers still add to it, and
+        // a reset here would leave it non-zero behind them without anybody knowing; the sticky error word tells the host to re-zero the tickets
+        if (!bad) __hip_atomic_store(at.tickets + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (bad || !pos_ok) *(int*)((char*)const_cast<void*>(at.state) + 260) = 1;               // sticky error word (amq_decode.hip)
         *flag = bad;
     }
@@ -1026,13 +1028,14 @@ hipError_t launch_gemv_qkv_attn(GemvArgs& a, const AttnArgs& t, int* tickets, hi
 #endif
     AttnTail at{t.kcache, t.vcache, t.rope_cur, t.out, tickets, t.n_heads, t.n_kv_heads, t.max_seq};
     const size_t lds = gemv_qkv_attn_lds_bytes(a.K, t.max_seq);
+    static unsigned long long attr2_done = 0, attr1_done = 0;        // (the LDS need is bounded by the limit the C ABI checks: one attribute value per kernel)
     if (two) {
         auto kern = gemv_qkv_attn_kernel<2, 2>;
-        if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+        if (lds > 64 * 1024) { hipError_t e = ensure_dyn_lds(attr2_done, (const void*)kern, 160 * 1024); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(kern, dim3(wg), dim3(512), lds, st, k.x, k.gamma, k.qweight[0], k.meta[0], k.K, 1 | (3 << 16), rpt, k.n_rt[0], k.key[0], k.eps, k, at);
     } else {
         auto kern = gemv_qkv_attn_kernel<2, 1>;
-        if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+        if (lds > 64 * 1024) { hipError_t e = ensure_dyn_lds(attr1_done, (const void*)kern, 160 * 1024); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(kern, dim3(wg), dim3(512), lds, st, k.x, k.gamma, k.qweight[0], k.meta[0], k.K, 1 | (3 << 16), rpt, k.n_rt[0], k.key[0], k.eps, k, at);
     }
     return hipGetLastError();

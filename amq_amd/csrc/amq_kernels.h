@@ -175,7 +175,7 @@ struct EngineDesc {
     void* x;                  // fp16 [H]: the residual stream, in / out
     void* scratch;            // engine_scratch_bytes(): q, k, v, attention output, gate, up
     const void* state;        // step-state block (cos/sin row of the current position, position, error word)
-    void* sync;               // engine_sync_bytes(): barrier words, zeroed by the launch function
+    void* sync;               // engine_sync_bytes(): barrier words -- zeroed ONCE by the caller (and again when the grid changes or after an error): epochs are monotonic across launches
     int grid;                 // workgroups; 0 = one per CU
     int depth;                // weight-ring slots per wave: 0 = by LDS budget, else 4 or 6
 };

@@ -259,9 +259,17 @@ class QuantLlama:
 
     def check(self):
         """raise if any decode step ran with its device-side position outside the cache (synchronises)"""
-        ops.check_step_state(self.step_err)
+        try:
+            ops.check_step_state(self.step_err)
+        except Exception:
+            self._tickets.zero_()               # (the fused q/k/v + attention launch leaves a timed-out ticket as it is: include/amq_hip.h)
+            raise
         if self.engine is not None:
-            self.engine.check()
+            try:
+                self.engine.check()
+            except Exception:
+                self.graph = None               # the engine re-zeroed its barrier words: the next decode_step re-captures
+                raise
 
     def set_token(self, token):
         """make ``token`` (int or 1-element tensor) the input of the next decode step; also re-derives what the step
@@ -563,6 +571,8 @@ class QuantLlama:
         for i in range(1, gen_len):
             self.decode_step(use_graph)
             out[:, i] = self.token
+        if self.engine is not None:
+            self.check()                        # a barrier time-out of the one-launch-per-token engine must not pass as tokens
         return out[0] if self.B == 1 else out
 
 

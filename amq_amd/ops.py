@@ -699,9 +699,13 @@ class DecodeEngine:
         """raise if a barrier poll of an earlier step ran into its bound (synchronises)"""
         word = int(self.sync[(2 + 2 * 32 - 1) * 64].item())
         if word != 0:
-            self._grid_used = None               # (re-zeroed before the next launch)
+            who = int(self.sync[(2 + 2 * 32 - 1) * 64 + 1].item())
+            # recover here, not only in step(): a runner replays a captured hipGraph and never comes through step(), and the sticky error
+            # word / the un-advanced epoch base would fail every later replay (ADVICE r3).  The caller drops its graph (QuantLlama.check).
+            self.sync.zero_()
+            self._grid_used = None
             raise _lib.AmqError("decode engine: a device-wide barrier timed out (barrier %d of the launch, first seen by workgroup %d)"
-                                % (word & 0xFFFF, int(self.sync[(2 + 2 * 32 - 1) * 64 + 1].item())))
+                                % (word & 0xFFFF, who))
 
     def vector(self, name):
         """fp16 view of one hand-off vector of the scratch buffer ('q', 'k', 'v', 'att', 'gate', 'up'): tests only"""

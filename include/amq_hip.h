@@ -325,7 +325,8 @@ int amq_attn_prefill_xfrag_f16(const void* q, const void* k, const void* v, void
  * inside the same kernel: the workgroups that produce a head's 24 row-tiles arrive on that head's ticket, the workgroup owning
  * the head's first q row-tile waits for it (bounded) and runs the attention.  out, the cache rows and the q / k / v vectors are
  * bit-identical to the two separate calls.  tickets: int32 [n_heads], zero before the first call (each call leaves them zero).
- * K <= 8192.  A ticket that does not fill (never observed) or a position outside the cache raises the step state's error word. */
+ * K <= 8192.  A ticket that does not fill (never observed) or a position outside the cache raises the step state's error word;
+ * after such an error the caller re-zeroes the tickets (a timed-out ticket is left as it is: late producers may still add to it). */
 int amq_gemv_qkv_attn_f16(const amq_segment* segments /* host, 3 */, const void* x, const void* gamma, float eps, int K, int group,
                           void* kcache, void* vcache, void* out, const void* step_state, int n_heads, int n_kv_heads, int head_dim,
                           int max_seq, void* tickets, void* stream);
