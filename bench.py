@@ -339,8 +339,8 @@ def parity_gate(dev, seed=7):
 
 def load_traffic():
     """HBM bytes per GEMV launch from this round's committed rocprofv3 PMC pass over the CURRENT kernels
-    (profiles/r03_gemv_pmc.json, tools/collect_round.sh r03), or None -- never a stale constant."""
-    p = os.path.join(ROOT, "profiles", "r03_gemv_pmc.json")
+    (profiles/r04_gemv_pmc.json, tools/collect_round.sh r04), or None -- never a stale constant."""
+    p = os.path.join(ROOT, "profiles", "r04_gemv_pmc.json")
     if os.path.exists(p):
         try:
             return json.load(open(p)).get("hbm_bytes_per_launch")
