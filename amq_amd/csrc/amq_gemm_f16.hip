@@ -37,7 +37,8 @@
 // Measured and NOT adopted (profiles/r04_gemm_f16pp.txt): four phases of 16 MFMAs (the same speed), the operand wait behind the barrier
 // instead of in front of it (same), accumulators pinned to AGPRs by inline-asm MFMAs (same), s_setprio 0 / 3 for the MFMA burst (same),
 // one phase of 64 MFMAs per K-tile (needs a third LDS set: a refilled set would be overwritten under the other wave group's reads),
-// half of the waves issuing their pieces BEFORE their operand reads (hand-over gap 59 -> 80-98 cycles: slower).
+// half of the waves issuing their pieces BEFORE their operand reads (hand-over gap 59 -> 80-98 cycles: slower), the pieces placed between the
+// MFMAs of the issuing wave's OWN burst instead of its read segment (one per four MFMAs: the burst grows from 593 to 627 cycles, -2.5 %).
 #include "amq_common.cuh"
 #include "amq_kernels.h"
 
@@ -52,7 +53,7 @@ constexpr int PP_BM = 256, PP_BN = 256;             // (K tiles are 64 deep)
 constexpr int PP_UNIT = 128 * 128;                  // one staging unit: 128 rows x 64 halves
 constexpr int PP_LDS = 8 * PP_UNIT;                 // 131,072 B: one workgroup per CU
 #ifdef AMQ_PP_TRACE
-constexpr int PP_LDS_ALLOC = PP_LDS + 16384;
+constexpr int PP_LDS_ALLOC = PP_LDS + 32768;
 #else
 constexpr int PP_LDS_ALLOC = PP_LDS;
 #endif
@@ -85,7 +86,7 @@ __device__ __forceinline__ pp_i4 pp_make_rsrc(const void* base) {      // raw bu
 __device__ unsigned amq_pp_stamp_buf[256 * 8 * 16];
 #endif
 #ifdef AMQ_PP_TRACE
-__device__ unsigned long long amq_pp_trace_buf[16 * 8 * 128 * 2];
+__device__ unsigned long long amq_pp_trace_buf[16 * 8 * 128 * 4];
 #endif
 
 struct GemmF16Args {
@@ -213,13 +214,15 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
 
 #ifdef AMQ_PP_TRACE                /* diagnostic build: MFMA-burst begin / end stamps of the first 128 phases, per wave (tools/f16pp_trace.py) */
     int tr_n = 0;
-    unsigned long long tr_t4 = 0, tr_t5 = 0;
-#define PP_TRACE_BEGIN() do { __builtin_amdgcn_sched_barrier(0); tr_t4 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    unsigned long long tr_t3 = 0, tr_t3p = 0, tr_t4 = 0, tr_t5 = 0;      // end of the read segment (just before its barrier), burst begin, burst end
+#define PP_TRACE_READY() do { __builtin_amdgcn_sched_barrier(0); tr_t3 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_TRACE_BEGIN() do { __builtin_amdgcn_sched_barrier(0); tr_t3p = tr_t3; tr_t4 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_TRACE_END() do { __builtin_amdgcn_sched_barrier(0); tr_t5 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 // (the stamps are sampled asynchronously; they are written out in the NEXT phase's read segment, where their latency hides)
-#define PP_TRACE_FLUSH() do { if (tr_t5) { if (tr_n < 128 && lane == 0) { unsigned long long* d_ = (unsigned long long*)(smem + PP_LDS + (wave * 128 + tr_n) * 16); \
-        d_[0] = tr_t4; d_[1] = tr_t5; } ++tr_n; } } while (0)
+#define PP_TRACE_FLUSH() do { if (tr_t5) { if (tr_n < 128 && lane == 0) { unsigned long long* d_ = (unsigned long long*)(smem + PP_LDS + (wave * 128 + tr_n) * 32); \
+        d_[0] = tr_t4; d_[1] = tr_t5; d_[2] = tr_t3p; } ++tr_n; } } while (0)
 #else
+#define PP_TRACE_READY() do { } while (0)
 #define PP_TRACE_BEGIN() do { } while (0)
 #define PP_TRACE_END() do { } while (0)
 #define PP_TRACE_FLUSH() do { } while (0)
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
         PP_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this phase's operands are in registers; the slots they came from may be refilled
         PP_STAMP(3);
+        PP_TRACE_READY();
         __builtin_amdgcn_sched_barrier(0);
         PP_BARRIER();
         PP_STAMP(4);
@@ -349,8 +353,8 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
 #ifdef AMQ_PP_TRACE
     __syncthreads();
     if (blockIdx.x < 16)
-        for (int i = threadIdx.x; i < 8 * 128 * 2; i += PP_THREADS)
-            amq_pp_trace_buf[(size_t)blockIdx.x * 8 * 128 * 2 + i] = ((const unsigned long long*)(smem + PP_LDS))[i];
+        for (int i = threadIdx.x; i < 8 * 128 * 4; i += PP_THREADS)
+            amq_pp_trace_buf[(size_t)blockIdx.x * 8 * 128 * 4 + i] = ((const unsigned long long*)(smem + PP_LDS))[i];
 #endif
 #ifdef AMQ_PP_STAMP
     if (lane == 0 && blockIdx.x < 256) {

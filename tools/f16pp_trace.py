@@ -18,12 +18,12 @@ for _ in range(2):
     ops.gemm_f16w(x, w, out=y)
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = np.zeros(16 * 8 * 128 * 2, dtype=np.uint64)
+buf = np.zeros(16 * 8 * 128 * 4, dtype=np.uint64)
 fn = lib.amq_debug_pp_trace
 fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]
 assert fn(buf.ctypes.data, buf.nbytes) == 0
-t = buf.reshape(16, 8, 128, 2).astype(np.int64)
-res = {k_: [] for k_ in ("len", "skew_begin", "skew_end", "gap_01", "gap_10", "same_simd_gap", "period")}
+t = buf.reshape(16, 8, 128, 4).astype(np.int64)      # [.., 0] burst begin, 1 burst end, 2 end of the read segment that preceded the burst
+res = {k_: [] for k_ in ("len", "skew_begin", "skew_end", "gap_01", "gap_10", "same_simd_gap", "period", "reader_slack_01", "release_after_last_arrival")}
 for g in range(16):
     b, e = t[g, :, 8:120, 0], t[g, :, 8:120, 1]            # [wave, phase]; waves 0-3: wr = 0, 4-7: wr = 1
     res["len"].append((e - b).mean())
@@ -35,6 +35,10 @@ for g in range(16):
     res["gap_10"].append((b[0:4, 1:].min(0) - e[4:8, :-1].max(0)).mean())
     res["same_simd_gap"].append((b[4:8] - e[0:4]).mean())   # the partner's begin minus this wave's end, same SIMD (waves w and w + 4)
     res["period"].append((b[0, 1:] - b[0, :-1]).mean())
+    rdy = t[g, :, 8:120, 2]
+    # hand-over group 0 -> group 1: the barrier needs group 0's bursts ended AND group 1's read segments ended
+    res["reader_slack_01"].append((e[0:4].max(0) - rdy[4:8].max(0)).mean())       # > 0: the readers were there first
+    res["release_after_last_arrival"].append((b[4:8].min(0) - np.maximum(e[0:4].max(0), rdy[4:8].max(0))).mean())
 for k_, v in res.items():
     print(f"{k_:14s} mean {np.mean(v):8.1f}   min {np.min(v):8.1f}   max {np.max(v):8.1f}")
 g = 3
