@@ -11,6 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # The product always loads THIS file.  A/B build variants (`make variant`) are loaded by tools/ only, through
 # ``use_library(path)`` called explicitly before the first ``load()`` -- no environment variable changes what the product runs.
 LIB_PATH = os.path.join(_HERE, "libamq_hip.so")
+# the A/B routes of the decode step (include/amq_hip_ab.h: one launch per token, q/k/v + attention in one launch): built, bit-identical,
+# slower -- their own library (`make -C amq_amd/csrc ab`), loaded only by ops.DecodeEngine / ops.gemv_qkv_attn
+AB_LIB_PATH = os.path.join(_HERE, "libamq_hip_ab.so")
 
 AMQ_OK = 0
 MODE_HQQ, MODE_FMA = 0, 1
@@ -86,12 +89,6 @@ SIGNATURES = {
     "amq_attn_prefill_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 10 + [_vp]),
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_cache_batch_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "amq_gemv_qkv_attn_f16": (_i, [ctypes.POINTER(Segment), _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "amq_decode_engine_image_bytes": (_sz, [_i]),
-    "amq_decode_engine_scratch_bytes": (_sz, [_i, _i, _i]),
-    "amq_decode_engine_sync_bytes": (_sz, []),
-    "amq_decode_engine_image": (_i, [ctypes.POINTER(EngineBlock), _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "amq_decode_engine_f16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp, _vp, _sz, _i, _vp]),
     "amq_rope_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_silu_mul_f16": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, ctypes.POINTER(GemvOpts), _vp]),
@@ -100,7 +97,18 @@ SIGNATURES = {
     "amq_gemm_route_f16": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 
+# name -> (restype, argtypes) of include/amq_hip_ab.h
+AB_SIGNATURES = {
+    "amq_gemv_qkv_attn_f16": (_i, [ctypes.POINTER(Segment), _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "amq_decode_engine_image_bytes": (_sz, [_i]),
+    "amq_decode_engine_scratch_bytes": (_sz, [_i, _i, _i]),
+    "amq_decode_engine_sync_bytes": (_sz, []),
+    "amq_decode_engine_image": (_i, [ctypes.POINTER(EngineBlock), _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "amq_decode_engine_f16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp, _vp, _sz, _i, _vp]),
+}
+
 _lib = None
+_ab_lib = None
 
 
 class AmqError(RuntimeError):
@@ -129,12 +137,37 @@ def load():
     return lib
 
 
+def load_ab():
+    """Load libamq_hip_ab.so (the A/B routes of include/amq_hip_ab.h) once; raise if it has not been built."""
+    global _ab_lib
+    if _ab_lib is not None:
+        return _ab_lib
+    if not os.path.exists(AB_LIB_PATH):
+        raise AmqError(f"{AB_LIB_PATH} not found: the A/B routes (decode engine, fused q/k/v + attention) live in their own library -- "
+                       "`make -C amq_amd/csrc ab` (or __graft_entry__.build()).  They are slower than the product step and not needed for it.")
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(AB_LIB_PATH)
+    for name, (res, args) in AB_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    lib.amq_last_error.restype = ctypes.c_char_p
+    _ab_lib = lib
+    return lib
+
+
+def check_ab(rc):
+    if rc != AMQ_OK:
+        raise AmqError(f"libamq_hip_ab error {rc}: {load_ab().amq_last_error().decode('utf-8', 'replace')}")
+
+
 def use_library(path):
     """tools/ only: load an A/B build variant instead of the product library.  Must be called before the first load()."""
     global LIB_PATH
-    if _lib is not None:
+    global AB_LIB_PATH
+    if _lib is not None or _ab_lib is not None:
         raise AmqError("use_library() must be called before the library is first loaded")
     LIB_PATH = os.path.abspath(path)
+    AB_LIB_PATH = LIB_PATH          # (a variant that carries the A/B routes -- `make abvariant` -- serves them too; others fail loudly on load_ab)
 
 
 def check(rc):

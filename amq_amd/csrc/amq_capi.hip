@@ -1,6 +1,9 @@
 // amq_capi.hip -- extern "C" boundary of libamq_hip.so (see include/amq_hip.h).
 // Argument validation + dispatch only; no allocation, no synchronisation.
 #include "../../include/amq_hip.h"
+#ifdef AMQ_AB_ROUTES
+#include "../../include/amq_hip_ab.h"
+#endif
 #include "amq_common.cuh"
 #include "amq_kernels.h"
 
@@ -314,6 +317,7 @@ int amq_gemm_xfrag_grouped_f16(const amq_segment* segs, int nseg, const void* xf
     return check_hip(amq::launch_gemm_xfrag_grouped(xf, M, K, gs, nseg, (hipStream_t)stream), "gemm_xfrag_grouped");
 }
 
+#ifdef AMQ_AB_ROUTES     /* A/B routes: exported by libamq_hip_ab.so (make ab), declared in include/amq_hip_ab.h */
 int amq_gemv_qkv_attn_f16(const amq_segment* segs, const void* x, const void* gamma, float eps, int K, int group, void* kcache,
                           void* vcache, void* out, const void* step_state, int n_heads, int n_kv_heads, int head_dim, int max_seq,
                           void* tickets, void* stream) {
@@ -408,6 +412,7 @@ int amq_decode_engine_f16(const void* blocks_dev, int n_block, int hidden, int i
                     max_seq, hidden, inter, LDS_LIMIT);
     return check_hip(amq::launch_decode_engine(d, (hipStream_t)stream), "decode_engine");
 }
+#endif  // AMQ_AB_ROUTES
 
 int amq_rope_cache_f16(void* q, const void* k, const void* v, void* kcache, void* vcache, const void* rope_table,
                        int rope_rows, int pos0, int S, int n_heads, int n_kv_heads, int head_dim, int max_seq, void* stream) {

@@ -721,6 +721,7 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const v
 #endif
 }
 
+#ifdef AMQ_AB_ROUTES     /* an A/B route (slower than the two launches it replaces): compiled into libamq_hip_ab.so only -- make ab */
 // ---------------------------------------------------------------- q/k/v GEMV + attention in ONE launch (decode, batch 1)
 // VERDICT r2 item 1(a).  The q/k/v launch and the attention launch of a decode block become one: a workgroup stores its row-tiles
 // of q, k or v as agent-scope stores, drains them, and adds its row-tile count to the ticket of every query head they belong to
@@ -1040,6 +1041,8 @@ hipError_t launch_gemv_qkv_attn(GemvArgs& a, const AttnArgs& t, int* tickets, hi
     }
     return hipGetLastError();
 }
+
+#endif  // AMQ_AB_ROUTES
 
 #ifdef AMQ_STAMP
 unsigned long long* g_stamp_ptr = nullptr;

@@ -612,7 +612,7 @@ def check_step_state(err):
 
 
 def gemv_qkv_attn(x, segments, K, gamma, eps, kcache, vcache, out, cur, n_heads, n_kv_heads, tickets):
-    """q / k / v GEMV (RMSNorm prologue) + decode attention of one block as ONE launch (include/amq_hip.h: amq_gemv_qkv_attn_f16).
+    """q / k / v GEMV (RMSNorm prologue) + decode attention of one block as ONE launch (include/amq_hip_ab.h: amq_gemv_qkv_attn_f16; an A/B route in libamq_hip_ab.so).
     segments: three dicts {qn, mn, bits, mode, N, y} (q, k, v; y fp16 [N]); caches [1, n_kv_heads, max_seq, 128]; ``cur``: the
     fp16 [128] view of a step-state block; ``tickets``: int32 [>= n_heads], zero (left zero)."""
     xx = _prep_x(x, K)
@@ -632,7 +632,7 @@ def gemv_qkv_attn(x, segments, K, gamma, eps, kcache, vcache, out, cur, n_heads,
     _need(cur, torch.float16, "rope_cur", 128)
     if tickets.dtype != torch.int32 or tickets.numel() < n_heads or not tickets.is_cuda:
         raise ValueError("tickets: int32 [n_heads] on the GPU")
-    _lib.check(_lib.load().amq_gemv_qkv_attn_f16(arr, _lib.ptr(xx), _lib.ptr(gamma), ctypes.c_float(eps), K, GROUP, _lib.ptr(kcache),
+    _lib.check_ab(_lib.load_ab().amq_gemv_qkv_attn_f16(arr, _lib.ptr(xx), _lib.ptr(gamma), ctypes.c_float(eps), K, GROUP, _lib.ptr(kcache),
                                                  _lib.ptr(vcache), _lib.ptr(out), _lib.ptr(cur), n_heads, n_kv_heads, 128, max_seq,
                                                  _lib.ptr(tickets), _lib.current_stream()))
 
@@ -642,7 +642,7 @@ ENGINE_LINEARS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "s
 
 
 class DecodeEngine:
-    """One decode token of a whole model as ONE persistent launch (include/amq_hip.h: amq_decode_engine_f16; counterpart of
+    """One decode token of a whole model as ONE persistent launch (include/amq_hip_ab.h: amq_decode_engine_f16, an A/B route in libamq_hip_ab.so; counterpart of
     the per-token loop of amq/kernel/monkeypatch/ftllama_modeling.py:167-230).
 
     blocks: list of dicts, one per decoder block: the seven linears under ENGINE_LINEARS as dicts {qn, mn, bits, mode, N}
@@ -651,7 +651,7 @@ class DecodeEngine:
     The device table, scratch and barrier words are owned by this object; step() only enqueues (graph-capturable)."""
 
     def __init__(self, blocks, hidden, inter, n_heads, n_kv_heads, max_seq, eps, x, step_cur, grid=0):
-        lib = _lib.load()
+        lib = _lib.load_ab()
         dev = x.device
         nb = len(blocks)
         _need(x, torch.float16, "x", hidden)
@@ -677,7 +677,7 @@ class DecodeEngine:
             keep += [blk["ln1"], blk["ln2"], blk["kc"], blk["vc"]]
         nbytes = int(lib.amq_decode_engine_image_bytes(nb))
         host = (ctypes.c_ubyte * nbytes)()
-        _lib.check(lib.amq_decode_engine_image(arr, nb, hidden, inter, n_heads, n_kv_heads, 128, GROUP, host))
+        _lib.check_ab(lib.amq_decode_engine_image(arr, nb, hidden, inter, n_heads, n_kv_heads, 128, GROUP, host))
         self.image = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
         self.scratch = torch.zeros(int(lib.amq_decode_engine_scratch_bytes(hidden, inter, n_kv_heads)), dtype=torch.uint8, device=dev)
         self.sync = torch.zeros(int(lib.amq_decode_engine_sync_bytes()) // 4, dtype=torch.int32, device=dev)
@@ -691,7 +691,7 @@ class DecodeEngine:
         if self._grid_used != self.grid:         # the barrier words count arrivals of ONE grid size across launches
             self.sync.zero_()
             self._grid_used = self.grid
-        _lib.check(_lib.load().amq_decode_engine_f16(_lib.ptr(self.image), *self.args, _lib.ptr(self.x), _lib.ptr(self.scratch),
+        _lib.check_ab(_lib.load_ab().amq_decode_engine_f16(_lib.ptr(self.image), *self.args, _lib.ptr(self.x), _lib.ptr(self.scratch),
                                                      self.scratch.numel(), _lib.ptr(self.cur), _lib.ptr(self.sync),
                                                      self.sync.numel() * 4, self.grid, _lib.current_stream()))
 

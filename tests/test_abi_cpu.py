@@ -11,8 +11,8 @@ from amq_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "amq_hip.h")).read()
+def _declared_symbols(header="amq_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(amq_[a-z0-9_]+)\s*\(", src)))
 
@@ -25,6 +25,15 @@ def test_header_symbols_exported_and_bound():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in amq_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, "ctypes SIGNATURES out of sync with amq_hip.h"
+    # the A/B routes (include/amq_hip_ab.h) live in their own library: the product library does NOT export them
+    ab = _declared_symbols("amq_hip_ab.h")
+    assert sorted(_lib.AB_SIGNATURES) == ab and len(ab) == 6
+    for s in ab:
+        assert not hasattr(lib, s), f"{s} is an A/B route and must not be exported by the product library"
+    assert os.path.exists(_lib.AB_LIB_PATH), "run __graft_entry__.build() first (make ab)"
+    ablib = ctypes.CDLL(_lib.AB_LIB_PATH)
+    for s in ab + syms:
+        assert hasattr(ablib, s), f"{s} not exported by libamq_hip_ab.so"
 
 
 def test_version_sizes_and_validation():
@@ -65,8 +74,9 @@ def test_version_sizes_and_validation():
 
 
 def test_decode_engine_host_side():
-    """the one-launch-per-token engine: sizes, the host-side table builder and argument validation (no GPU needed)"""
-    lib = _lib.load()
+    """the one-launch-per-token engine (an A/B route, libamq_hip_ab.so): sizes, the host-side table builder and argument validation
+    (no GPU needed)"""
+    lib = _lib.load_ab()
     assert lib.amq_decode_engine_sync_bytes() % 256 == 0 and lib.amq_decode_engine_sync_bytes() >= 66 * 256
     assert lib.amq_decode_engine_image_bytes(32) == 32 * lib.amq_decode_engine_image_bytes(1) > 0
     H, I, nh, nkv = 4096, 11008, 32, 32

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-workgroup phase timeline of the decode engine (diagnostic build -DAMQ_ENG_STAMP):
-    make -C amq_amd/csrc tuvariant TU=amq_engine TAG=engstamp EXTRA=-DAMQ_ENG_STAMP
+    make -C amq_amd/csrc abvariant TAG=engstamp EXTRA=-DAMQ_ENG_STAMP      (the engine is an A/B route: libraries that carry it are built with abvariant)
     python tools/with_variant.py engstamp tools/stamp_engine.py [block]
 Stamps are the 100 MHz realtime counter (10 ns), thread 0 of every workgroup, for ONE decoder block of a graph-less step of
 the bench workload; printed: per stage, median / max over workgroups of each phase, relative to the stage's barrier release."""
