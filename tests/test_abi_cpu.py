@@ -73,6 +73,33 @@ def test_version_sizes_and_validation():
     assert lib.amq_gemm_gated_fused(3, 200000, 4096, 8192, 0) == 1          # 3.3 GB
 
 
+def test_dequantize_once_route_host_side():
+    """route 6 (AMQ_GEMM_DEQ: dequantize once into the caller's workspace + the fp16 ping-pong GEMM) and the dense entry: workspace
+    sizes, AUTO's crossover and argument validation -- host logic, no GPU"""
+    lib = _lib.load()
+    N, K = 13824, 5120
+    assert lib.amq_gemm_route_workspace_bytes(_lib.GEMM_DEQ, 64, N, K) == N * K * 2            # forced: always the fp16 weights
+    assert lib.amq_gemm_route_workspace_bytes(_lib.GEMM_AUTO, 32768, N, K) == N * K * 2        # BASELINE configs[3]: MFMA-bound
+    assert lib.amq_gemm_route_workspace_bytes(_lib.GEMM_AUTO, 6144, N, K) == N * K * 2
+    assert lib.amq_gemm_route_workspace_bytes(_lib.GEMM_AUTO, 4096, N, K) == 0                 # fused kernels below the crossover
+    assert lib.amq_gemm_route_workspace_bytes(_lib.GEMM_AUTO, 8192, 1024, 1024) == 0           # < one round of 256 x 256 tiles
+    assert lib.amq_gemm_gated_fused(_lib.GEMM_DEQ, 8192, N, K, 1) == 1 and lib.amq_gemm_gated_fused(_lib.GEMM_DEQ, 8192, N, K, 0) == 0
+    one = ctypes.c_void_p(256)
+    # route 6 needs its workspace, of the right size
+    assert lib.amq_gemm_route_f16(_lib.GEMM_DEQ, 4, 0, one, one, one, None, None, one, 512, N, K, 128, 0, 0, None, 0, None) == -1
+    assert b"workspace" in lib.amq_last_error()
+    assert lib.amq_gemm_route_f16(_lib.GEMM_DEQ, 4, 0, one, one, one, None, None, one, 512, N, K, 128, 0, 0, one, 1024, None) == -1
+    assert lib.amq_gemm_route_f16(7, 4, 0, one, one, one, None, None, one, 512, N, K, 128, 0, 0, None, 0, None) == -1   # unknown route
+    # dense entry
+    f = lib.amq_gemm_f16w_f16
+    assert f(None, one, None, None, None, one, 512, N, K, 0, 0, None) == -1
+    assert f(one, one, None, one, one, one, 512, N, K, 0, 0, None) == -1 and b"exclusive" in lib.amq_last_error()
+    assert f(one, one, None, None, None, one, 512, N, K - 64, 0, 0, None) == -2                 # K % 128
+    assert f(one, one, None, None, None, one, 512, N + 8, K, 0, 0, None) == -2                  # N % 16
+    assert f(one, one, None, None, None, one, 512, N, K, K + 4, 0, None) == -2                  # x rows not 16-byte aligned
+    assert f(one, one, None, None, None, one, 1 << 20, N, 8192, 0, 0, None) == -2               # x spans >= 4 GiB
+
+
 def test_decode_engine_host_side():
     """the one-launch-per-token engine (an A/B route, libamq_hip_ab.so): sizes, the host-side table builder and argument validation
     (no GPU needed)"""
