@@ -38,7 +38,10 @@
 // instead of in front of it (same), accumulators pinned to AGPRs by inline-asm MFMAs (same), s_setprio 0 / 3 for the MFMA burst (same),
 // one phase of 64 MFMAs per K-tile (needs a third LDS set: a refilled set would be overwritten under the other wave group's reads),
 // half of the waves issuing their pieces BEFORE their operand reads (hand-over gap 59 -> 80-98 cycles: slower), the pieces placed between the
-// MFMAs of the issuing wave's OWN burst instead of its read segment (one per four MFMAs: the burst grows from 593 to 627 cycles, -2.5 %).
+// MFMAs of the issuing wave's OWN burst instead of its read segment (one per four MFMAs: the burst grows from 593 to 627 cycles, -2.5 %),
+// and hipBLASLt's wave geometry -- four waves, one per SIMD, 128 x 128 each (256 accumulators pinned to AGPRs, 0.25 operand reads per MFMA), the
+// whole K-tile written out as ONE hand-ordered inline-asm stream of 128 MFMAs, 32 ds_read_b128, 16 pieces, one counted wait and one barrier:
+// 1219-1223 vs 1270-1276 TFLOP/s (-4 %) untuned, and not repeatable across launches on multi-tile problems (not pursued).
 #include "amq_common.cuh"
 #include "amq_kernels.h"
 
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
     if (wr == 0) PP_BARRIER();                                          // barrier counts of the two wave groups match again
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the trailing re-reads must not land after the workgroup has gone
 }
+
 
 bool gemm_f16w_ok(int M, int N, int K, int x_stride, int y_stride) {
     // DMA sources are buffer base + 32-bit offset: x and W must each span < 4 GiB; 8-byte row-segment stores need 4-element
