@@ -41,7 +41,10 @@
 // MFMAs of the issuing wave's OWN burst instead of its read segment (one per four MFMAs: the burst grows from 593 to 627 cycles, -2.5 %),
 // and hipBLASLt's wave geometry -- four waves, one per SIMD, 128 x 128 each (256 accumulators pinned to AGPRs, 0.25 operand reads per MFMA), the
 // whole K-tile written out as ONE hand-ordered inline-asm stream of 128 MFMAs, 32 ds_read_b128, 16 pieces, one counted wait and one barrier:
-// 1219-1223 vs 1270-1276 TFLOP/s (-4 %) untuned, and not repeatable across launches on multi-tile problems (not pursued).
+// 1219-1223 vs 1270-1276 TFLOP/s (-4 %), not repeatable across launches; rebuilt with compiler-tracked operand reads and pinned order (correct, repeatable):
+// 1140-1153 vs 1310-1326.  tools/ubench/mfma_shadow.hip says why (profiles/r04_mfma_shadow.txt): a SIMD's lone wave has three issue slots per MFMA, and a 1 KiB
+// LDS-DMA piece holds its issue for ~27 cycles = 11-17 cycles of matrix-pipe time per piece (9-13 % of a K-tile), whatever the spacing; with two waves per SIMD the
+// partner's pieces issue beside the MFMAs for free -- this kernel's structure.
 #include "amq_common.cuh"
 #include "amq_kernels.h"
 
