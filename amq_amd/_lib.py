@@ -94,6 +94,7 @@ SIGNATURES = {
     "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, ctypes.POINTER(GemvOpts), _vp]),
     "amq_gemm_f16w_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amq_gemm_route_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "amq_gemm_route_workspace_bytes_g": (_sz, [_i, _i, _i, _i, _i]),
     "amq_gemm_route_f16": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 

@@ -36,8 +36,8 @@ def load_hqq_dir(path):
                 raise ValueError(f"{name}: only axis=1, non-float-view HQQ layers are supported")
             if meta.get("quant_scale", False) or meta.get("quant_zero", False):
                 raise ValueError(f"{name}: quantized scale/zero are not supported (deprecated in the reference as well)")
-            if int(meta["group_size"]) < GROUP or int(meta["group_size"]) % GROUP:
-                raise ValueError(f"{name}: group size {meta['group_size']} (multiples of 128 only)")
+            if int(meta["group_size"]) not in (64, 32) and (int(meta["group_size"]) < GROUP or int(meta["group_size"]) % GROUP):
+                raise ValueError(f"{name}: group size {meta['group_size']} (32, 64 or multiples of 128 only)")
             out[name] = HQQWeights(sd["W_q"], meta["scale"].to(torch.float16).reshape(-1, 1),
                                    meta["zero"].to(torch.float16).reshape(-1, 1), int(meta["nbits"]),
                                    tuple(int(v) for v in meta["shape"]), int(meta["group_size"]), sd.get("bias"), name.split(".")[-1])

@@ -32,11 +32,22 @@ int check_shape(int bits, int N, int K, int group) {
     if (bits != 2 && bits != 3 && bits != 4) return fail(AMQ_EINVAL, "bits must be 2, 3 or 4 (got %d)", bits);
     // 128, or a multiple of it that divides K: the repack entry points read such a source format and replicate each group's
     // (scale, zero) into the native layout's per-128 pairs; the compute entry points work on the native layout either way
-    if (group < 128 || (group % 128) != 0) return fail(AMQ_ESHAPE, "group size must be a multiple of 128 (got %d)", group);
+    // 64 / 32: the native meta holds 128 / group pairs per (row, tile) (amq_common.cuh); served by the repack / dequantize entry points, the GEMV
+    // kernel (<= 16 rows, exact math) and the dequantize-once GEMM route -- the other entry points refuse them (check_shape128)
+    if (group != 64 && group != 32 && (group < 128 || (group % 128) != 0))
+        return fail(AMQ_ESHAPE, "group size must be 32, 64 or a multiple of 128 (got %d)", group);
     if (N <= 0 || K <= 0 || (N % 16) != 0 || (K % 128) != 0)
         return fail(AMQ_ESHAPE, "need N %% 16 == 0 and K %% 128 == 0 (got N=%d K=%d)", N, K);
     if ((K % group) != 0) return fail(AMQ_ESHAPE, "group size %d does not divide K=%d", group, K);
     return AMQ_OK;
+}
+
+// entry points whose kernels read ONE (scale, zero) pair per (row, 128-column tile)
+int check_shape128(int bits, int N, int K, int group, const char* who) {
+    if (group == 64 || group == 32)
+        return fail(AMQ_ESHAPE, "%s serves groups of 128 (and multiples); groups of %d run through amq_gemv_f16 / amq_gemv_grouped_f16 (<= 16 rows) and "
+                    "amq_gemm_route_f16 / amq_gemm_gated_f16 with a workspace of N * K * 2 bytes", who, group);
+    return check_shape(bits, N, K, group);
 }
 
 int check_mode(int mode) {
@@ -68,7 +79,7 @@ int amq_query(int K, int* out, int cap) {
 }
 
 size_t amq_native_qweight_bytes(int bits, int N, int K) { return amq::native_qweight_bytes(bits, N, K); }
-size_t amq_native_meta_bytes(int N, int K, int group) { (void)group; return amq::native_meta_bytes(N, K); }
+size_t amq_native_meta_bytes(int N, int K, int group) { return amq::native_meta_bytes(N, K, group > 0 ? amq::meta_pairs(group) : 1); }
 
 int amq_repack_from_hqq(int bits, const void* W_q, const void* scale, const void* zero, int N, int K, int group,
                         void* qn, void* mn, void* stream) {
@@ -95,7 +106,7 @@ int amq_dequantize_f16(int bits, int mode, const void* qn, const void* mn, int N
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!qn || !mn || !W) return fail(AMQ_EINVAL, "null pointer");
-    return check_hip(amq::launch_dequantize(bits, mode, qn, mn, N, K, W, (hipStream_t)stream), "dequantize");
+    return check_hip(amq::launch_dequantize(bits, mode, qn, mn, N, K, W, (hipStream_t)stream, amq::meta_pairs(group)), "dequantize");
 }
 
 int amq_dequantize_hqq_f16(int bits, const void* W_q, const void* scale, const void* zero, int N, int K, int group,
@@ -139,6 +150,9 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     a.force_waves = o.waves;
     a.force_depth = o.depth;
     a.force_rpt = o.rpt;
+    a.gp = amq::meta_pairs(group);
+    if (a.gp > 1 && (o.dot || o.math != AMQ_MATH_EXACT || o.depth == 4))
+        return fail(AMQ_EINVAL, "groups of %d: the GEMV kernel's default form only (opts.math = AMQ_MATH_EXACT, opts.dot = 0, opts.depth = 0 / 2)", group);
     return check_hip(amq::launch_gemv(a, (hipStream_t)stream), "gemv");
 }
 
@@ -152,7 +166,7 @@ int amq_gemv_f16(int bits, int mode, const void* x, const void* qn, const void* 
 
 int amq_gemm_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
                  int M, int N, int K, int group, int x_stride, int y_stride, void* stream) {
-    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (int rc = check_shape128(bits, N, K, group, "amq_gemm_f16")) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
@@ -171,7 +185,7 @@ int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qn, const
                         void* stream) {
     const size_t need = amq_gemm_splitk_workspace_bytes(M, N, K);
     if (need == 0) return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, x_stride, y_stride, stream);
-    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (int rc = check_shape128(bits, N, K, group, "amq_gemm_splitk_f16")) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (!workspace || workspace_bytes < need) return fail(AMQ_EINVAL, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
@@ -181,15 +195,26 @@ int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qn, const
 }
 
 // the workspace of a route call holds the dequantized fp16 weights (dequantize-once route) or the split-K partials, never both
-static bool route_is_deq(int route, int M, int N, int K) {
+static bool route_is_deq(int route, int M, int N, int K, int group = 128) {
+    if (group == 64 || group == 32) return route == AMQ_GEMM_DEQ || route == AMQ_GEMM_AUTO;      // their only many-row route
     return route == AMQ_GEMM_DEQ || (route == AMQ_GEMM_AUTO && amq::gemm_takes_deq(M, N, K));
 }
 
-size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K) {
+size_t amq_gemm_route_workspace_bytes_g(int route, int M, int N, int K, int group) {
     if (M < 1 || N < 1 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_DEQ) return 0;
-    if (route_is_deq(route, M, N, K)) return (size_t)N * (size_t)K * 2;       // the dequantized fp16 weights
+    if (route_is_deq(route, M, N, K, group)) return (size_t)N * (size_t)K * 2;       // the dequantized fp16 weights
     const int s = amq::gemm_pick_splits(M, N, K, route);
     return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K) { return amq_gemm_route_workspace_bytes_g(route, M, N, K, 128); }
+
+// groups of 64 / 32 on a route call: AUTO or DEQ, with the workspace
+static int check_fine_route(int route, int group, const void* workspace) {
+    if (group != 64 && group != 32) return AMQ_OK;
+    if (route != AMQ_GEMM_AUTO && route != AMQ_GEMM_DEQ)
+        return fail(AMQ_EINVAL, "groups of %d run the dequantize-once route only (AMQ_GEMM_AUTO / AMQ_GEMM_DEQ): the fused kernels read one (scale, zero) per 128 columns", group);
+    if (!workspace) return fail(AMQ_EINVAL, "groups of %d need a workspace of N * K * 2 bytes for the fp16 weights (amq_gemm_route_workspace_bytes_g)", group);
+    return AMQ_OK;
 }
 
 int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
@@ -201,8 +226,10 @@ int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void*
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     if (route == AMQ_GEMM_SKINNY && M > 64) return fail(AMQ_ESHAPE, "the few-row kernel takes at most 64 rows (got %d)", M);
-    const size_t need = amq_gemm_route_workspace_bytes(route, M, N, K);
-    const bool deq = route_is_deq(route, M, N, K);
+    if (int rc = check_fine_route(route, group, workspace)) return rc;
+    const bool fine = group == 64 || group == 32;
+    const size_t need = amq_gemm_route_workspace_bytes_g(route, M, N, K, group);
+    const bool deq = route_is_deq(route, M, N, K, group);
     if (route == AMQ_GEMM_DEQ && !workspace) return fail(AMQ_EINVAL, "AMQ_GEMM_DEQ needs a workspace of N * K * 2 bytes for the fp16 weights");
     const bool use_ws = need != 0 && workspace != nullptr;         // no workspace: single pass through a fused kernel
     if (use_ws && workspace_bytes < need)
@@ -210,8 +237,8 @@ int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void*
     const bool split = use_ws && !deq;
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N,
                     split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, route) : 1, residual, nullptr,
-                    use_ws && deq ? workspace : nullptr};
-    if (route == AMQ_GEMM_DEQ && !amq::gemm_f16w_ok(M, N, K, a.x_stride, a.y_stride))
+                    use_ws && deq ? workspace : nullptr, amq::meta_pairs(group)};
+    if ((route == AMQ_GEMM_DEQ || fine) && !amq::gemm_f16w_ok(M, N, K, a.x_stride, a.y_stride))
         return fail(AMQ_ESHAPE, "AMQ_GEMM_DEQ: strides must be multiples of 8 (x) / 4 (y) halves and x, W must each span < 4 GiB");
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream, route), "gemm");
 }
@@ -235,8 +262,9 @@ int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void*
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     if (N % 8) return fail(AMQ_ESHAPE, "the gated product needs N %% 8 == 0 (got %d)", N);
     if (route == AMQ_GEMM_SKINNY && M > 64) return fail(AMQ_ESHAPE, "the few-row kernel takes at most 64 rows (got %d)", M);
-    const size_t need = amq_gemm_route_workspace_bytes(route, M, N, K);
-    const bool deq = route_is_deq(route, M, N, K);
+    if (int rc = check_fine_route(route, group, workspace)) return rc;
+    const size_t need = amq_gemm_route_workspace_bytes_g(route, M, N, K, group);
+    const bool deq = route_is_deq(route, M, N, K, group);
     if (route == AMQ_GEMM_DEQ && !workspace) return fail(AMQ_EINVAL, "AMQ_GEMM_DEQ needs a workspace of N * K * 2 bytes for the fp16 weights");
     const bool use_ws = need != 0 && workspace != nullptr;
     if (use_ws && workspace_bytes < need)
@@ -244,7 +272,9 @@ int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void*
     const bool split = use_ws && !deq;
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, N,
                     split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, route) : 1, nullptr, gate,
-                    use_ws && deq ? workspace : nullptr};
+                    use_ws && deq ? workspace : nullptr, amq::meta_pairs(group)};
+    if ((group == 64 || group == 32) && !amq::gemm_f16w_ok(M, N, K, a.x_stride, a.y_stride))
+        return fail(AMQ_ESHAPE, "groups of %d (dequantize-once route): x_stride must be a multiple of 8 halves, N of 4, x and W must each span < 4 GiB", group);
     if (gate == y && !amq::gemm_gate_fused(a, route))
         return fail(AMQ_EINVAL, "gate may alias y only where the kernel applies it in its epilogue (amq_gemm_gated_fused)");
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream, route), "gemm_gated");
@@ -289,7 +319,7 @@ int amq_rmsnorm_xfrag_f16(const void* x, const void* gamma, void* xf, int M, int
 int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qn, const void* mn, const void* bias,
                        const void* gate, const void* residual, void* y, int M, int N, int K, int group, int y_stride,
                        void* stream) {
-    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (int rc = check_shape128(bits, N, K, group, "amq_gemm_xfrag_f16")) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!xf || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
@@ -306,7 +336,7 @@ int amq_gemm_xfrag_grouped_f16(const amq_segment* segs, int nseg, const void* xf
     amq::GemvSeg gs[AMQ_MAX_SEGMENTS] = {};
     for (int i = 0; i < nseg; ++i) {
         const amq_segment& s = segs[i];
-        if (int rc = check_shape(s.bits, s.N, K, group)) return rc;
+        if (int rc = check_shape128(s.bits, s.N, K, group, "amq_gemm_xfrag_grouped_f16")) return rc;
         if (int rc = check_mode(s.mode)) return rc;
         if (!s.qweight_native || !s.meta_native || !s.y) return fail(AMQ_EINVAL, "segment %d: null pointer", i);
         amq::GemvSeg& d = gs[i];
@@ -330,7 +360,7 @@ int amq_gemv_qkv_attn_f16(const amq_segment* segs, const void* x, const void* ga
     amq::GemvArgs a{};
     for (int i = 0; i < 3; ++i) {
         const amq_segment& s = segs[i];
-        if (int rc = check_shape(s.bits, s.N, K, group)) return rc;
+        if (int rc = check_shape128(s.bits, s.N, K, group, "amq_gemv_qkv_attn_f16")) return rc;
         if (int rc = check_mode(s.mode)) return rc;
         if (s.N != Ns[i]) return fail(AMQ_ESHAPE, "segment %d: N = %d, expected %d", i, s.N, Ns[i]);
         if (!s.qweight_native || !s.meta_native || !s.y) return fail(AMQ_EINVAL, "segment %d: null pointer", i);
@@ -373,7 +403,7 @@ int amq_decode_engine_image(const amq_engine_block* blocks, int n_block, int hid
             const amq_engine_linear& l = blocks[b].lin[i];
             const int K = i == 6 ? inter : hidden;
             if (l.N != Ns[i]) return fail(AMQ_ESHAPE, "block %d linear %d: N = %d, expected %d", b, i, l.N, Ns[i]);
-            if (int rc = check_shape(l.bits, l.N, K, group)) return rc;
+            if (int rc = check_shape128(l.bits, l.N, K, group, "the decode engine")) return rc;
             if (int rc = check_mode(l.mode)) return rc;
             if (!l.qweight_native || !l.meta_native) return fail(AMQ_EINVAL, "block %d linear %d: null pointer", b, i);
             if (amq::native_qweight_bytes(l.bits, l.N, K) >= (1ull << 32)) return fail(AMQ_ESHAPE, "block %d linear %d spans 4 GiB or more", b, i);
@@ -459,6 +489,8 @@ int amq_linear_f16(int bits, int mode, const void* x, const void* qn, const void
     // few rows: weight-streaming GEMV family; otherwise the tiled MFMA GEMM
     if (M <= 8 && amq::gemv_lds_bytes(M, K, 1) <= 64 * 1024)
         return amq_gemv_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
+    if ((group == 64 || group == 32) && M <= amq::GEMV_MAX_M && amq::gemv_lds_bytes(M, K, 1) <= LDS_LIMIT)     // (more rows: amq_gemm_route_f16 + workspace)
+        return amq_gemv_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
     return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
 }
 
@@ -470,7 +502,7 @@ CompatWs carve(void* ws, int bits, int M, int N, int K) {
     char* p = (char*)ws;
     CompatWs c;
     c.qn = p; p += align256(amq::native_qweight_bytes(bits, N, K));
-    c.mn = p; p += align256(amq::native_meta_bytes(N, K));
+    c.mn = p; p += align256(amq::native_meta_bytes(N, K, 4));            // (room for the finest group the repack writes: 32)
     c.ytmp = p;
     (void)M;
     return c;
@@ -479,7 +511,7 @@ CompatWs carve(void* ws, int bits, int M, int N, int K) {
 
 size_t amq_compat_workspace_bytes(int bits, int M, int N, int K) {
     if (N <= 0 || K <= 0 || M <= 0) return 0;
-    return align256(amq::native_qweight_bytes(bits, N, K)) + align256(amq::native_meta_bytes(N, K)) + align256((size_t)M * N * 2);
+    return align256(amq::native_qweight_bytes(bits, N, K)) + align256(amq::native_meta_bytes(N, K, 4)) + align256((size_t)M * N * 2);
 }
 
 int amq_vecquantmatmul_faster_old(int bits, const void* vec, const void* mat, void* mul, const void* scales,

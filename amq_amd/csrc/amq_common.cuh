@@ -270,9 +270,11 @@ __host__ __device__ __forceinline__ void native_slot(int bits, int t, int j, int
 __host__ __device__ __forceinline__ size_t native_qweight_bytes(int bits, int N, int K) {
     return (size_t)(N / TILE_N) * (size_t)(K / TILE_K) * 64u * 4u * (size_t)bits;
 }
-__host__ __device__ __forceinline__ size_t native_meta_bytes(int N, int K) {
-    return (size_t)(N / TILE_N) * (size_t)(K / TILE_K) * TILE_N * 4u;
+__host__ __device__ __forceinline__ size_t native_meta_bytes(int N, int K, int gp = 1) {      // gp: (scale, zero) pairs per (row, tile) = 128 / group
+    return (size_t)(N / TILE_N) * (size_t)(K / TILE_K) * TILE_N * 4u * (size_t)gp;
 }
+// pairs per tile for a caller's group size: 1 for 128 and its multiples (each source group's pair is replicated per tile), 2 / 4 for 64 / 32
+__host__ __device__ __forceinline__ int meta_pairs(int group) { return group >= TILE_K ? 1 : TILE_K / group; }
 
 // ---- wave-load of one lane's tile payload (BITS dwords), non-temporal: the
 // weights are read exactly once per token, keep them from displacing x / KV.
@@ -305,5 +307,47 @@ __device__ __forceinline__ LanePayload<BITS> load_payload(const uint32_t* tile_b
     }
     return r;
 }
+
+// ---- groups finer than 128 (64 / 32 input columns per (scale, zero): HQQ's default group_size is 64, hqq/core/quantize.py:1078; the reference's GPTQ
+// kernels index their scales by k / groupsize for any groupsize, AutoGPTQ/auto_gptq_kernel.cu:203, 303, 419) -----------------------------------
+// The payload layout does not change; the meta array holds GP = 128 / group pairs per (row, tile): [N/16][K/128][16][GP] (one 8- or 16-byte load
+// per lane and tile), pair s covering k in [group s, group (s + 1)) of the tile = the MFMA steps t with (t GP) >> 2 == s.  A lane's register
+// pair P = 4 t + p therefore takes meta pair (P >> 2) GP >> 2: a compile-time choice of operand registers, no extra arithmetic.
+template <int GP> struct MetaG { h2 p[GP]; };
+template <int GP>
+__device__ __forceinline__ MetaG<GP> load_meta_g(const h2* lane_base) {          // lane_base: this lane's first pair of the tile
+    MetaG<GP> m;
+    if (GP == 1) m.p[0] = as_h2(AMQ_STREAM_LOAD((const uint32_t*)lane_base));
+    else if (GP == 2) { const u2 v = AMQ_STREAM_LOAD((const u2*)lane_base); m.p[0] = as_h2(v.x); m.p[1 % GP] = as_h2(v.y); }
+    else { const u4 v = AMQ_STREAM_LOAD((const u4*)lane_base); m.p[0] = as_h2(v.x); m.p[1 % GP] = as_h2(v.y); m.p[2 % GP] = as_h2(v.z); m.p[3 % GP] = as_h2(v.w); }
+    return m;
+}
+template <int GP> __host__ __device__ constexpr int meta_sub(int P) { return ((P >> 2) * GP) >> 2; }
+
+// dequant_lane with per-pair meta (the reference-exact two-rounding form; used by the dequantize kernel)
+template <int BITS, int MODE, int GP>
+__device__ __forceinline__ void dequant_lane_g(const uint32_t* w, const MetaG<GP>& meta, h2* out) {
+    h2 q[16];
+    dequant_lane<BITS, MODE_FMA>(w, (h2){(_Float16)1.0f, (_Float16)0.0f}, q);   // fma(q, 1, 0) = q exactly: the integer fields as halves
+#pragma unroll
+    for (int P = 0; P < 16; ++P) {
+        const h2 m = meta.p[meta_sub<GP>(P)];
+        out[P] = apply_meta<MODE>(q[P], bcast(m.x), bcast(m.y));
+    }
+}
+// dequant_lane_sd with per-pair meta (the matmul kernels' form, bit-identical to dequant_lane_g under dequant_lane_sd's conditions)
+template <int BITS, int MODE, int GP, int P>
+__device__ __forceinline__ void dequant_sd_g_step(const uint32_t* w, const SdMeta (&m)[GP], h2* out) {
+    out[P] = dequant_pair_sd<BITS, MODE, P>(w, m[meta_sub<GP>(P)]);
+    if constexpr (P + 1 < 16) dequant_sd_g_step<BITS, MODE, GP, P + 1>(w, m, out);
+}
+template <int BITS, int MODE, int GP>
+__device__ __forceinline__ void dequant_lane_sd_g(const uint32_t* w, const MetaG<GP>& meta, h2* out) {
+    SdMeta m[GP];
+#pragma unroll
+    for (int s = 0; s < GP; ++s) m[s] = sd_meta<BITS, MODE>(meta.p[s]);
+    dequant_sd_g_step<BITS, MODE, GP, 0>(w, m, out);
+}
+
 
 }  // namespace amq

@@ -588,6 +588,7 @@ bool gemm_takes_deq(int M, int N, int K) {
 // the dequantize-once route: forced, or AUTO's choice -- either way only with a scratch for the fp16 weights and without split-K
 static bool gemm_runs_deq(const GemmArgs& a, int route) {
     if (!a.w16 || a.splits > 1 || !gemm_f16w_ok(a.M, a.N, a.K, a.x_stride, a.y_stride)) return false;
+    if (a.gp > 1) return true;                             // groups of 64 / 32: the only many-row route (the fused kernels read one meta pair per tile)
     return route == GEMM_ROUTE_DEQ || (route == GEMM_ROUTE_AUTO && gemm_takes_deq(a.M, a.N, a.K));
 }
 
@@ -612,9 +613,10 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route) {
 static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route) {
     if (gemm_runs_deq(a, route)) {
         // MFMA-bound launches: the exact fp16 weights once (amq_dequantize_f16's kernel), then a GEMM with no unpack in its loop
-        if (hipError_t e = launch_dequantize(a.bits, a.mode, a.qweight, a.meta, a.N, a.K, a.w16, st)) return e;
+        if (hipError_t e = launch_dequantize(a.bits, a.mode, a.qweight, a.meta, a.N, a.K, a.w16, st, a.gp > 1 ? a.gp : 1)) return e;
         return launch_gemm_f16w(a.x, a.w16, a.bias, a.residual, a.gate, a.y, a.M, a.N, a.K, a.x_stride, a.y_stride, st);
     }
+    if (a.gp > 1) return hipErrorInvalidValue;             // (amq_capi.hip refuses such a call with its reason before it gets here)
     if (route == GEMM_ROUTE_RING && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
     if (route == GEMM_ROUTE_RING128 && gemm_ring_ok(a)) return launch_gemm_ring(a, st, 128);
     if (route == GEMM_ROUTE_WS && gemm_ring_ok(a)) return launch_gemm_ws(a, st);

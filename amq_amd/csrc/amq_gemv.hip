@@ -349,7 +349,8 @@ __device__ __forceinline__ void unpack_lane_sub(const uint32_t* w, h2* out) {
 // RS: floats per wave in the cross-wave sum buffer red[2][NW][RS]: 256 = 16 x-rows x 16 columns; 128 for launches of at most 8 rows
 // (several sequences decoded together), whose staged x is what limits the workgroups per CU
 // SC1: the outputs are agent-scope (write-through) stores -- for a consumer INSIDE the same launch (gemv_qkv_attn_kernel)
-template <int BITS, int MODE, int PRO, int NW, int U, int MATH, int XCH, int RS = 256, bool SC1 = false>
+// GP: (scale, zero) pairs per (row, tile) = 128 / group (amq_common.cuh); 2 / 4 are served by the exact-math body only
+template <int BITS, int MODE, int PRO, int NW, int U, int MATH, int XCH, int RS = 256, bool SC1 = false, int GP = 1>
 __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk, int sidx, const void* qweight, const void* meta_base,
                                           int seg_n_rt, int local, _Float16* lds_x, const _Float16* xl, float* xg,
                                           float* red, int xs, bool fastx, const XRegs& xr) {
@@ -362,12 +363,17 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     const int n_my = (seg_n_rt - rt0) < a.rpt ? (seg_n_rt - rt0) : a.rpt;
     const int total = n_my * nt;
     const uint32_t* qw = (const uint32_t*)qweight;
-    const h2* mt = (const h2*)meta_base + r;
+    static_assert(GP == 1 || MATH == MATH_EXACT, "groups finer than 128: exact math only");
+    const h2* mt = (const h2*)meta_base + r * GP;
 
 #ifdef AMQ_ABL_NOMETA      /* ablation: no scale/zero traffic */
 #define AMQ_META_LOAD(slot, tile_) meta[slot] = as_h2(0x40003c00u + (uint32_t)(tile_ & 1))
 #else
-#define AMQ_META_LOAD(slot, tile_) meta[slot] = as_h2(AMQ_STREAM_LOAD((const uint32_t*)(mt + (tile_) * 16)))
+#define AMQ_META_LOAD(slot, tile_)                                                               \
+    do {                                                                                         \
+        if constexpr (GP == 1) meta[slot] = as_h2(AMQ_STREAM_LOAD((const uint32_t*)(mt + (tile_) * 16)));   \
+        else metag[slot] = load_meta_g<GP>(mt + (tile_) * (16 * GP));                            \
+    } while (0)
 #endif
 #ifdef AMQ_ABL_NOXLDS      /* ablation: A operand from registers instead of LDS */
 #define AMQ_XREAD(p) ((h8){(_Float16)1, (_Float16)2, (_Float16)-1, (_Float16)0.5f, (_Float16)1, (_Float16)-2, (_Float16)1, (_Float16)3} + (h8)(_Float16)(float)(kbase & 1))
@@ -376,6 +382,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
 #endif
     LanePayload<BITS> pay[U];
     h2 meta[U];
+    [[maybe_unused]] MetaG<GP> metag[U];                           // (GP > 1: `meta` is unused)
     int ii = 0, ij = 0;                                           // issue cursor (tile, row-tile)
 #ifdef AMQ_ABL_NOLOAD      /* ablation build: no weight traffic, compute on whatever is in the registers */
 #define AMQ_ISSUE(slot)                                                                          \
@@ -495,7 +502,8 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
         const int kbase = g_ << 7;                                                               \
         h2 wv[16];                                                                               \
         if (MATH == MATH_LINEAR) unpack_lane_sub<BITS>(pay[slot].w, wv);                         \
-        else dequant_lane_sd<BITS, MODE>(pay[slot].w, meta[slot], wv);                           \
+        else if constexpr (GP == 1) dequant_lane_sd<BITS, MODE>(pay[slot].w, meta[slot], wv);    \
+        else dequant_lane_sd_g<BITS, MODE, GP>(pay[slot].w, metag[slot], wv);                    \
         if (MATH == MATH_DOT) {                                                                  \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                      \
                 const h8 xv = *(const h8*)(xl + kbase + 8 * o + 32 * t);                         \
@@ -646,7 +654,7 @@ struct GemvPre {            // not a kernel parameter type: just names the 14 dw
     int K, m_nseg, rpt, n_rt0, key0; float eps;
 };
 
-template <int PRO, int NW, int U, int MATH, int XCH, int RS = 256>
+template <int PRO, int NW, int U, int MATH, int XCH, int RS = 256, int GP = 1>
 __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const void* p_x, const void* p_xw, const void* p_qw0,
                                                                      const void* p_mt0, int p_K, int p_m_nseg, int p_rpt,
                                                                      int p_n_rt0, int p_key0, float p_eps, GemvKArgs blk) {
@@ -708,12 +716,12 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const v
 
     const _Float16* xuse = xl;
     switch (key) {
-        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, RS>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
     }
     if (threadIdx.x < 64) AMQ_STAMP_AT(blk, 4);
 #ifdef AMQ_STAMP
@@ -1072,9 +1080,9 @@ int gemv_pick_waves(int total_rt, int K) {
     return 8;
 }
 
-template <int PRO, int NW, int U, int MATH, int XCH = XCfg<NW>::XC, int RS = 256>
+template <int PRO, int NW, int U, int MATH, int XCH = XCfg<NW>::XC, int RS = 256, int GP = 1>
 static hipError_t launch_one(const GemvKArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    auto kern = gemv_kernel<PRO, NW, U, MATH, XCH, RS>;
+    auto kern = gemv_kernel<PRO, NW, U, MATH, XCH, RS, GP>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1102,6 +1110,15 @@ static hipError_t launch_nw(const GemvKArgs& a, int flags, int depth, int total_
     return launch_one<PRO, NW, 2, MATH_EXACT>(a, total_wg, lds, st);
 }
 
+// groups of 64 / 32 (GP = 2 / 4 meta pairs per tile): the default geometry of the exact-math body (two tile loads in flight, generic x staging
+// beyond its register-held chunks)
+template <int PRO, int GP>
+static hipError_t launch_pro_g(const GemvKArgs& a, int nw, int total_wg, size_t lds, hipStream_t st) {
+    if (nw == 4) return launch_one<PRO, 4, 2, MATH_EXACT, XCfg<4>::XC, 256, GP>(a, total_wg, lds, st);
+    if (nw == 16) return launch_one<PRO, 16, 2, MATH_EXACT, XCfg<16>::XC, 256, GP>(a, total_wg, lds, st);
+    return launch_one<PRO, 8, 2, MATH_EXACT, XCfg<8>::XC, 256, GP>(a, total_wg, lds, st);
+}
+
 template <int PRO>
 static hipError_t launch_pro(const GemvKArgs& a, int flags, int depth, int nw, int total_wg, size_t lds, hipStream_t st) {
     if (nw == 4) return launch_nw<PRO, 4>(a, flags, depth, total_wg, lds, st);
@@ -1120,9 +1137,12 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     // with at most 8 rows the cross-wave sum needs half its buffer (RS = 128): at 5 rows three 8-wave workgroups fit a CU again
     // (7B: 2.20 -> 2.01 ms a step); TWO 8-wave workgroups (6 - 8 rows) measured slower than one 16-wave workgroup (2.28 / 2.34 vs
     // 2.10 / 2.19 ms), so those keep the 16-wave form (profiles/r02_decode_batch.txt)
+    const int gp = a.gp > 1 ? a.gp : 1;                    // meta pairs per tile (groups of 64 / 32: 2 / 4)
+    if (gp != 1 && gp != 2 && gp != 4) return hipErrorInvalidValue;
+    if (gp > 1 && ((a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) || a.force_depth == 4)) return hipErrorInvalidValue;   // (the C ABI says so first)
     bool rs128 = false;
     if (!a.force_waves && a.M > 1 && nw == 8) {
-        const bool plain = !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4;
+        const bool plain = !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4 && gp == 1;
         const size_t lds128 = gemv_lds_bytes(a.M, a.K, 8) - 2 * 8 * 128 * 4;
         if (plain && a.M <= 8 && 3 * lds128 <= 160 * 1024) rs128 = true;
         else if (3 * gemv_lds_bytes(a.M, a.K, 8) > 160 * 1024) nw = 16;
@@ -1131,7 +1151,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     // (~90 VGPRs), instead of one 16-wave workgroup -- 13B 464 -> 485 tokens/s, 70B 126.5 -> 133.  The same trade for
     // 8192 < K <= 16384 (four chunks per thread) loses (13B 484 -> 467; 7B's K = 11008 with three chunks 808 -> 773), as do
     // three workgroups per CU (449 / 122).
-    const bool mid_k = !a.force_waves && nw == 16 && a.M == 1 && (a.K >> 3) > 512 && (a.K >> 3) <= 1024 &&
+    const bool mid_k = gp == 1 && !a.force_waves && nw == 16 && a.M == 1 && (a.K >> 3) > 512 && (a.K >> 3) <= 1024 &&
                        !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4;    // (only the exact-math body has the two-chunk variant)
     if (mid_k) nw = 8;
     // persistent-style grid: about 24 waves per CU (256 CUs) -- three 8-wave workgroups, but ONE 16-wave workgroup (two do
@@ -1166,6 +1186,20 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
 #ifdef AMQ_STAMP
     k.stamps = g_stamp_ptr;
 #endif
+    if (gp == 2) {
+        switch (a.prologue) {
+            case PRO_NONE: return launch_pro_g<PRO_NONE, 2>(k, nw, wg, lds, st);
+            case PRO_RMSNORM: return launch_pro_g<PRO_RMSNORM, 2>(k, nw, wg, lds, st);
+            default: return launch_pro_g<PRO_SILU_MUL, 2>(k, nw, wg, lds, st);
+        }
+    }
+    if (gp == 4) {
+        switch (a.prologue) {
+            case PRO_NONE: return launch_pro_g<PRO_NONE, 4>(k, nw, wg, lds, st);
+            case PRO_RMSNORM: return launch_pro_g<PRO_RMSNORM, 4>(k, nw, wg, lds, st);
+            default: return launch_pro_g<PRO_SILU_MUL, 4>(k, nw, wg, lds, st);
+        }
+    }
     switch (a.prologue) {
         case PRO_NONE: return launch_pro<PRO_NONE>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0), a.force_depth, nw, wg, lds, st);
         case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0), a.force_depth, nw, wg, lds, st);

@@ -71,6 +71,7 @@ struct GemvArgs {
     int force_waves;       // 0 = auto, else 4 / 8 / 16 waves per workgroup
     int force_depth;       // 0 = auto, else 2 / 4 tile loads in flight per wave
     int force_rpt;         // 0 = auto, else row-tiles per workgroup
+    int gp;                // (scale, zero) pairs per (row, tile) of every segment's meta: 0 / 1 (groups of 128), 2 (64), 4 (32)
 };
 enum { GEMV_FLAG_DOT = 1, GEMV_FLAG_LINEAR = 2, GEMV_FLAG_RS128 = 4 /* internal: half-size cross-wave sum buffer (<= 8 rows) */ };
 constexpr int GEMV_MAX_M = 16;
@@ -87,6 +88,7 @@ struct GemmArgs {
     const void* residual;   // fp16 [M, y_stride] added to the rounded result (y = residual + fp16(acc (+ bias))), or null
     const void* gate;       // few-row kernel only: fp16 [M, y_stride]; y = fp16(silu(gate)) * fp16(acc (+ bias)) (LlamaMLP), or null
     void* w16;              // GEMM_ROUTE_DEQ: caller-owned scratch for the dequantized fp16 weights [N, K] (else null)
+    int gp;                 // meta pairs per (row, tile): 0 / 1, or 2 / 4 for groups of 64 / 32 -- those run GEMM_ROUTE_DEQ (or the GEMV kernel up to 16 rows) only
 };
 // route: which kernel family serves the launch (AUTO: by shape; the others force one for tests / A-B tools)
 enum { GEMM_ROUTE_AUTO = 0, GEMM_ROUTE_TILED = 1, GEMM_ROUTE_SKINNY = 2, GEMM_ROUTE_RING = 3, GEMM_ROUTE_RING128 = 4, GEMM_ROUTE_WS = 5,
@@ -196,7 +198,7 @@ hipError_t launch_repack(int fmt, int bits, const void* qsrc, const void* s_src,
 hipError_t launch_accumulate_f32(void* mul, const void* y, size_t n, hipStream_t st);
 // native -> fp16 W[N,K]
 hipError_t launch_dequantize(int bits, int mode, const void* q_native, const void* meta_native,
-                             int N, int K, void* w_out, hipStream_t st);
+                             int N, int K, void* w_out, hipStream_t st, int gp = 1);    // gp: meta pairs per (row, tile), 1 / 2 / 4
 // HQQ Format A -> fp16 W[N,K] directly (ATEN-style standalone dequant, f-4)
 hipError_t launch_dequantize_hqq(int bits, const void* wq, const void* scale, const void* zero,
                                  int N, int K, void* w_out, hipStream_t st, int group = 128);

@@ -17,7 +17,8 @@ namespace amq {
 // FMT_HQQ  (Format A, hqq/core/bitpack.py:24-110; axis=1 grouping quantize.py:106-111)
 // FMT_GPTQ (Format B, autogptq.py:121-156)
 // FMT_AWQ  (Format C, ft.py:15-55)
-// gs: the SOURCE format's group size (a multiple of 128 dividing K); the native layout always keeps one (scale, zero) per 128 k
+// gs: the SOURCE format's group size: a multiple of 128 dividing K (the native layout keeps one (scale, zero) per 128 k: the source pair is
+// replicated), or 64 / 32 (the native meta holds 128 / gs pairs per (row, tile), amq_common.cuh)
 template <int FMT, int BITS>
 __device__ __forceinline__ uint32_t fetch_q(const void* src, int n, int k, int N, int K, int gs) {
     if (FMT == FMT_HQQ) {
@@ -97,9 +98,10 @@ __global__ __launch_bounds__(256) void repack_kernel(const void* qsrc, const voi
 #pragma unroll
     for (int d = 0; d < BITS; ++d) dst[d] = w[d];
 
-    if (o == 0) {   // one lane group also writes the (row, group) meta pair
+    const int gp = gs >= 128 ? 1 : 128 / gs;
+    if (o < gp) {   // lane group o also writes the tile row's meta pair o (one pair per tile for groups >= 128)
         h2 m;
-        const int gsrc = (g * 128) / gs;  // the source group this 128-k tile belongs to (its pair is replicated per tile)
+        const int gsrc = (g * 128 + o * (128 / gp)) / gs;  // the source group of this pair (groups > 128: its pair is replicated per tile)
         if (FMT == FMT_HQQ) {            // meta['scale'], meta['zero']: fp16 [N*K/gs, 1]
             const size_t row = (size_t)n * (K / gs) + gsrc;
             m.x = ((const _Float16*)s_src)[row];
@@ -111,11 +113,11 @@ __global__ __launch_bounds__(256) void repack_kernel(const void* qsrc, const voi
             m.x = ((const _Float16*)s_src)[(size_t)gsrc * N + n];
             m.y = ((const _Float16*)z_src)[(size_t)gsrc * N + n];
         }
-        mn[tile * 16 + r] = m;
+        mn[(tile * 16 + r) * gp + o] = m;
     }
 }
 
-template <int BITS, int MODE>
+template <int BITS, int MODE, int GP = 1>
 __global__ __launch_bounds__(256) void dequant_native_kernel(const uint32_t* qn, const h2* mn, int N, int K, _Float16* out) {
     const int G = K >> 7;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(256) void dequant_native_kernel(const uint32_t* qn,
     const int r = lane & 15, o = lane >> 4;
     LanePayload<BITS> p = load_payload<BITS>(qn + tile * 64 * BITS, lane);
     h2 wv[16];
-    dequant_lane<BITS, MODE>(p.w, mn[tile * 16 + r], wv);
+    if constexpr (GP == 1) dequant_lane<BITS, MODE>(p.w, mn[tile * 16 + r], wv);
+    else dequant_lane_g<BITS, MODE, GP>(p.w, load_meta_g<GP>(mn + (tile * 16 + r) * GP), wv);
     _Float16* row = out + (size_t)(rt * 16 + r) * K + g * 128 + 8 * o;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -215,13 +218,21 @@ hipError_t launch_repack(int fmt, int bits, const void* q, const void* s, const 
     return hipGetLastError();
 }
 
-hipError_t launch_dequantize(int bits, int mode, const void* qn, const void* mn, int N, int K, void* w, hipStream_t st) {
+hipError_t launch_dequantize(int bits, int mode, const void* qn, const void* mn, int N, int K, void* w, hipStream_t st, int gp) {
     const size_t threads = (size_t)(N >> 4) * (K >> 7) * 64;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
-#define AMQ_DQ(B, MD) hipLaunchKernelGGL((dequant_native_kernel<B, MD>), dim3(blocks), dim3(256), 0, st, \
-                                         (const uint32_t*)qn, (const h2*)mn, N, K, (_Float16*)w)
-    if (mode == MODE_HQQ) { if (bits == 4) AMQ_DQ(4, MODE_HQQ); else if (bits == 3) AMQ_DQ(3, MODE_HQQ); else AMQ_DQ(2, MODE_HQQ); }
-    else { if (bits == 4) AMQ_DQ(4, MODE_FMA); else if (bits == 3) AMQ_DQ(3, MODE_FMA); else AMQ_DQ(2, MODE_FMA); }
+#define AMQ_DQ(B, MD, G_) hipLaunchKernelGGL((dequant_native_kernel<B, MD, G_>), dim3(blocks), dim3(256), 0, st, \
+                                             (const uint32_t*)qn, (const h2*)mn, N, K, (_Float16*)w)
+#define AMQ_DQ_BM(G_)                                                                                                       \
+    do {                                                                                                                    \
+        if (mode == MODE_HQQ) { if (bits == 4) AMQ_DQ(4, MODE_HQQ, G_); else if (bits == 3) AMQ_DQ(3, MODE_HQQ, G_); else AMQ_DQ(2, MODE_HQQ, G_); } \
+        else { if (bits == 4) AMQ_DQ(4, MODE_FMA, G_); else if (bits == 3) AMQ_DQ(3, MODE_FMA, G_); else AMQ_DQ(2, MODE_FMA, G_); }             \
+    } while (0)
+    if (gp == 1) AMQ_DQ_BM(1);
+    else if (gp == 2) AMQ_DQ_BM(2);
+    else if (gp == 4) AMQ_DQ_BM(4);
+    else return hipErrorInvalidValue;
+#undef AMQ_DQ_BM
 #undef AMQ_DQ
     return hipGetLastError();
 }

@@ -71,7 +71,7 @@ def quantize_rtn(W: torch.Tensor, nbits: int, group_size: int = GROUP, bias=None
     (axis=1 grouping, inverted scale stored, fractional fp16 zero:
     quantize.py:106-155).  Not the HQQ optimizer -- accuracy is irrelevant to
     the speed path, only the format and value ranges matter."""
-    if group_size < GROUP or group_size % GROUP:
+    if group_size not in (64, 32) and (group_size < GROUP or group_size % GROUP):
         raise ValueError("group size must be a multiple of 128")
     n, k = W.shape
     wg = W.float().reshape(-1, group_size)
@@ -107,8 +107,8 @@ def from_hqq_layer(layer) -> HQQWeights:
         raise ValueError("only axis=1 HQQ layers are supported (AMQ uses axis=1)")
     if meta.get("view_as_float", False):
         raise ValueError("view_as_float HQQ payloads are not supported")
-    if meta["group_size"] < GROUP or meta["group_size"] % GROUP:
-        raise ValueError(f"group size must be a multiple of 128 (got {meta['group_size']})")
+    if meta["group_size"] not in (64, 32) and (meta["group_size"] < GROUP or meta["group_size"] % GROUP):
+        raise ValueError(f"group size must be 32, 64 or a multiple of 128 (got {meta['group_size']})")
     nbits = int(meta["nbits"])
     if nbits not in (2, 3, 4):
         raise NotImplementedError("Only 2,3,4 bits are supported.")

@@ -27,13 +27,21 @@ def _need(t, dtype, name, numel=None):
         raise ValueError(f"{name}: expected {numel} elements, got {t.numel()}")
 
 
-def native_sizes(bits, N, K):
+FINE_GROUPS = (64, 32)      # groups finer than the native tile: 128 / group (scale, zero) pairs per (row, tile) in the native meta
+
+
+def native_group(group):
+    """granularity of the NATIVE meta for a source-format group size: 128 for 128 and its multiples (pairs replicated), else the group"""
+    return int(group) if int(group) in FINE_GROUPS else GROUP
+
+
+def native_sizes(bits, N, K, group=GROUP):
     lib = _lib.load()
-    return int(lib.amq_native_qweight_bytes(bits, N, K)), int(lib.amq_native_meta_bytes(N, K, GROUP))
+    return int(lib.amq_native_qweight_bytes(bits, N, K)), int(lib.amq_native_meta_bytes(N, K, native_group(group)))
 
 
-def alloc_native(bits, N, K, device):
-    qb, mb = native_sizes(bits, N, K)
+def alloc_native(bits, N, K, device, group=GROUP):
+    qb, mb = native_sizes(bits, N, K, group)
     return (torch.empty(qb // 4, dtype=torch.int32, device=device),
             torch.empty(mb // 2, dtype=torch.float16, device=device))
 
@@ -47,10 +55,12 @@ def _check_shape(bits, N, K):
 
 def _check_group(group, K):
     """source-format group sizes the repack kernels read: 128 or a multiple of it that divides K (each group's (scale, zero) is
-    replicated into the native layout's per-128 pairs)"""
+    replicated into the native layout's per-128 pairs), or 64 / 32 (128 / group pairs per native tile row)"""
     group = int(group)
+    if group in FINE_GROUPS:
+        return group
     if group < GROUP or group % GROUP or K % group:
-        raise ValueError(f"group size must be a multiple of {GROUP} that divides K={K} (got {group})")
+        raise ValueError(f"group size must be 32, 64 or a multiple of {GROUP} that divides K={K} (got {group})")
     return group
 
 
@@ -66,7 +76,7 @@ def repack_from_hqq(W_q, scale, zero, bits, N, K, group=GROUP):
         _need(W_q, torch.uint8, "W_q", R * group * bits // 8)
     _need(scale, torch.float16, "scale", R)
     _need(zero, torch.float16, "zero", R)
-    qn, mn = alloc_native(bits, N, K, W_q.device)
+    qn, mn = alloc_native(bits, N, K, W_q.device, group)
     _lib.check(lib.amq_repack_from_hqq(bits, _lib.ptr(W_q), _lib.ptr(scale), _lib.ptr(zero), N, K, group,
                                        _lib.ptr(qn), _lib.ptr(mn), _lib.current_stream()))
     return qn, mn
@@ -80,7 +90,7 @@ def repack_from_gptq(qweight, scales, zeros, bits, N, K, group=GROUP):
     _need(qweight, torch.int32, "qweight", K // 32 * bits * N)
     _need(scales, torch.float32, "scales", K // group * N)
     _need(zeros, torch.float32, "zeros", K // group * N)
-    qn, mn = alloc_native(bits, N, K, qweight.device)
+    qn, mn = alloc_native(bits, N, K, qweight.device, group)
     _lib.check(lib.amq_repack_from_gptq(bits, _lib.ptr(qweight), _lib.ptr(scales), _lib.ptr(zeros), N, K, group,
                                         _lib.ptr(qn), _lib.ptr(mn), _lib.current_stream()))
     return qn, mn
@@ -96,25 +106,35 @@ def repack_from_awq(qweight, scales, scaled_zeros, N, K, group=GROUP):
     _need(qweight, torch.int16, "qweight", N // 4 * K)
     _need(scales, torch.float16, "scales", K // group * N)
     _need(scaled_zeros, torch.float16, "scaled_zeros", K // group * N)
-    qn, mn = alloc_native(4, N, K, qweight.device)
+    qn, mn = alloc_native(4, N, K, qweight.device, group)
     _lib.check(lib.amq_repack_from_awq(_lib.ptr(qweight), _lib.ptr(scales), _lib.ptr(scaled_zeros), N, K, group,
                                        _lib.ptr(qn), _lib.ptr(mn), _lib.current_stream()))
     return qn, mn
 
 
-def _check_native(qn, mn, bits, N, K):
+def _check_native(qn, mn, bits, N, K, fine=False):
+    """validates a native (payload, meta) pair and returns its group granularity: 128, or -- where the caller serves them (``fine``) --
+    64 / 32, recognised by the meta tensor's size (128 / group pairs per tile row)"""
     qb, mb = native_sizes(bits, N, K)
     _need(qn, torch.int32, "qweight_native", qb // 4)
+    if isinstance(mn, torch.Tensor) and mn.numel() != mb // 2 and mn.numel() in (mb, 2 * mb):
+        group = GROUP * (mb // 2) // mn.numel()
+        if not fine:
+            raise ValueError(f"meta_native holds groups of {group}: this entry point serves groups of 128 (and multiples); "
+                             f"groups of 64 / 32 run through gemv / gemv_grouped (<= 16 rows), gemm and dequantize")
+        _need(mn, torch.float16, "meta_native", mn.numel())
+        return group
     _need(mn, torch.float16, "meta_native", mb // 2)
+    return GROUP
 
 
 def dequantize(qn, mn, bits, mode, N, K, out=None):
     _check_shape(bits, N, K)
-    _check_native(qn, mn, bits, N, K)
+    group = _check_native(qn, mn, bits, N, K, fine=True)
     if out is None:
         out = torch.empty(N, K, dtype=torch.float16, device=qn.device)
     _need(out, torch.float16, "out", N * K)
-    _lib.check(_lib.load().amq_dequantize_f16(bits, mode, _lib.ptr(qn), _lib.ptr(mn), N, K, GROUP,
+    _lib.check(_lib.load().amq_dequantize_f16(bits, mode, _lib.ptr(qn), _lib.ptr(mn), N, K, group,
                                               _lib.ptr(out), _lib.current_stream()))
     return out
 
@@ -156,7 +176,7 @@ def gemv(x, qn, mn, bits, mode, N, K, bias=None, out=None, opts=None):
         gemv_grouped(x2, [dict(qn=qn, mn=mn, bits=bits, mode=mode, N=N, y=y, bias=bias)], K, opts=opts)
         return y.reshape(*x.shape[:-1], N)
     _check_shape(bits, N, K)
-    _check_native(qn, mn, bits, N, K)
+    group = _check_native(qn, mn, bits, N, K, fine=True)
     x2 = _prep_x(x, K)
     M = x2.shape[0]
     if bias is not None:
@@ -164,7 +184,7 @@ def gemv(x, qn, mn, bits, mode, N, K, bias=None, out=None, opts=None):
     y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=x.device)
     _need(y, torch.float16, "y", M * N)
     _lib.check(_lib.load().amq_gemv_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
-                                        _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.current_stream()))
+                                        _lib.ptr(y), M, N, K, group, 0, 0, _lib.current_stream()))
     return y.reshape(*x.shape[:-1], N)
 
 
@@ -214,10 +234,10 @@ def _dequant_scratch(device, numel):
     return _DEQ_SCRATCH.get(device, numel)[:numel]
 
 
-def _route_workspace(lib, device, route, M, N, K):
+def _route_workspace(lib, device, route, M, N, K, group=GROUP):
     """(tensor or None, bytes) for ``amq_gemm_route_f16`` / ``amq_gemm_gated_f16``: split-K partials for few rows, the dequantized
-    fp16 weights for the dequantize-once route (GEMM_DEQ, and GEMM_AUTO on MFMA-bound launches)."""
-    need = lib.amq_gemm_route_workspace_bytes(route, M, N, K)
+    fp16 weights for the dequantize-once route (GEMM_DEQ, GEMM_AUTO on MFMA-bound launches, and every launch over groups of 64 / 32)."""
+    need = lib.amq_gemm_route_workspace_bytes_g(route, M, N, K, group)
     if not need:
         return None, 0
     if need == N * K * 2 and (route == GEMM_DEQ or route == GEMM_AUTO):
@@ -245,7 +265,7 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=
     y = fp16(silu(gate)) * fp16(x . W^T (+ bias)), i.e. :func:`silu_mul` of the two projections with this one as ``up``.
     ``route`` != GEMM_AUTO forces one hand-written kernel family (tests, tools)."""
     _check_shape(bits, N, K)
-    _check_native(qn, mn, bits, N, K)
+    group = _check_native(qn, mn, bits, N, K, fine=True)
     x2 = _prep_x(x, K)
     M = x2.shape[0]
     if bias is not None:
@@ -260,14 +280,14 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=
     _need(y, torch.float16, "y", M * N)
     lib = _lib.load()
     if gate is not None:
-        ws, ws_bytes = _route_workspace(lib, x.device, route, M, N, K)
-        if y.data_ptr() == gate.data_ptr() and not lib.amq_gemm_gated_fused(route, M, N, K, 1 if ws_bytes else 0):
+        ws, ws_bytes = _route_workspace(lib, x.device, route, M, N, K, group)
+        if group == GROUP and y.data_ptr() == gate.data_ptr() and not lib.amq_gemm_gated_fused(route, M, N, K, 1 if ws_bytes else 0):
             # the tiled kernel cannot apply the gate itself: in place on the gate needs the projection somewhere else first
             up = gemm(x, qn, mn, bits, mode, N, K, bias=bias, route=route)
             silu_mul(gate, up.view(-1), out=y)
             return y.reshape(*x.shape[:-1], N)
         _lib.check(lib.amq_gemm_gated_f16(route, bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
-                                          _lib.ptr(gate), _lib.ptr(y), M, N, K, GROUP, 0, _lib.ptr(ws),
+                                          _lib.ptr(gate), _lib.ptr(y), M, N, K, group, 0, _lib.ptr(ws),
                                           ws_bytes, _lib.current_stream()))
         return y.reshape(*x.shape[:-1], N)
     if route == GEMM_AUTO and LIB_GEMM_ROWS and M >= LIB_GEMM_ROWS:
@@ -286,9 +306,9 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=
         else:
             torch.matmul(x2, w.t(), out=y2)
         return y.reshape(*x.shape[:-1], N)
-    ws, ws_bytes = _route_workspace(lib, x.device, route, M, N, K)
+    ws, ws_bytes = _route_workspace(lib, x.device, route, M, N, K, group)
     _lib.check(lib.amq_gemm_route_f16(route, bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
-                                      _lib.ptr(residual), _lib.ptr(y), M, N, K, GROUP, 0, 0, _lib.ptr(ws),
+                                      _lib.ptr(residual), _lib.ptr(y), M, N, K, group, 0, 0, _lib.ptr(ws),
                                       ws_bytes, _lib.current_stream()))
     return y.reshape(*x.shape[:-1], N)
 
@@ -382,11 +402,15 @@ def gemm_xfrag_grouped(xf, M, segments, K):
 def linear(x, qn, mn, bits, mode, N, K, bias=None):
     """Reference-style dispatch: few rows -> gemv family, otherwise gemm."""
     _check_shape(bits, N, K)
-    _check_native(qn, mn, bits, N, K)
+    group = _check_native(qn, mn, bits, N, K, fine=True)
     x2 = _prep_x(x, K)
     M = x2.shape[0]
     if bias is not None:
         _need(bias, torch.float16, "bias", N)
+    if group != GROUP and M > 0:    # groups of 64 / 32: the GEMV kernel as far as it reaches (16 rows), then dequantize once + the fp16 GEMM
+        if M <= gemv_max_rows(K):
+            return gemv(x, qn, mn, bits, mode, N, K, bias=bias)
+        return gemm(x, qn, mn, bits, mode, N, K, bias=bias)
     if M > 8:                       # tiled MFMA GEMM (split-K for few rows); amq_linear_f16 makes the same cut at 8 rows
         return gemm(x, qn, mn, bits, mode, N, K, bias=bias)
     y = torch.empty(M, N, dtype=torch.float16, device=x.device)
@@ -419,9 +443,13 @@ def gemv_grouped(x, segments, K, prologue=PRO_NONE, x2=None, gamma=None, eps=0.0
     if not 1 <= len(segments) <= _lib.MAX_SEGMENTS:
         raise ValueError(f"1..{_lib.MAX_SEGMENTS} segments")
     arr = (Segment * len(segments))()
+    group = None
     for i, s in enumerate(segments):
         _check_shape(s["bits"], s["N"], K)
-        _check_native(s["qn"], s["mn"], s["bits"], s["N"], K)
+        g = _check_native(s["qn"], s["mn"], s["bits"], s["N"], K, fine=True)
+        if group is not None and g != group:
+            raise ValueError(f"segments of one launch must share their group size (got {group} and {g})")
+        group = g
         _need(s["y"], torch.float16, "y", M * s["N"])
         if s.get("bias") is not None:
             _need(s["bias"], torch.float16, "bias", s["N"])
@@ -438,7 +466,7 @@ def gemv_grouped(x, segments, K, prologue=PRO_NONE, x2=None, gamma=None, eps=0.0
     if opts is None:
         opts = DEFAULT_GEMV_OPTS
     _lib.check(_lib.load().amq_gemv_grouped_f16(arr, len(segments), _lib.ptr(xx), _lib.ptr(x2), _lib.ptr(gamma),
-                                                ctypes.c_float(eps), prologue, M, K, GROUP, 0,
+                                                ctypes.c_float(eps), prologue, M, K, group, 0,
                                                 ctypes.byref(opts) if opts is not None else None, _lib.current_stream()))
 
 

@@ -19,6 +19,7 @@ import os
 
 import torch
 
+from . import ops
 from .hqq_format import HQQWeights, from_hqq_layer
 from .quant_linear import HIPLlamaMLP, HIPQuantLinear, HIPRMSNorm, LinearGroup
 
@@ -113,6 +114,12 @@ def _walk_hip(model, fct):
             _walk_hip(layer, fct)
 
 
+def _fusable(m):
+    """a HIPQuantLinear the grouped / fused launches take: groups of 128 (and multiples).  Groups of 64 / 32 stay plain modules (their
+    forwards run the GEMV kernel / dequantize-once GEMM one linear at a time)"""
+    return isinstance(m, HIPQuantLinear) and getattr(m, "native_group", ops.GROUP) == ops.GROUP
+
+
 def group_sibling_linears(model):
     """Install a :class:`LinearGroup` wherever a module holds HIPQuantLinear children named like one of SIBLING_GROUPS with equal
     input sizes: their few-row forwards then run as ONE grouped launch.  Returns the number of groups made.  The modules
@@ -123,7 +130,7 @@ def group_sibling_linears(model):
     for parent in model.modules():
         for names in SIBLING_GROUPS:
             mods = [getattr(parent, n, None) for n in names]
-            if not all(isinstance(m, HIPQuantLinear) for m in mods) or len({m.infeatures for m in mods}) != 1:
+            if not all(_fusable(m) for m in mods) or len({m.infeatures for m in mods}) != 1:
                 continue
             grps = [m.__dict__.get("_group") for m in mods]
             if all(g is not None and g[0] is grps[0][0] and g[1] == i for i, g in enumerate(grps)) and len(grps[0][0].members) == len(mods) \
@@ -146,7 +153,7 @@ def fuse_llama_mlps(model):
             kids = [getattr(mod, k, None) for k in ("gate_proj", "up_proj", "down_proj")]
             act = getattr(mod, "act_fn", None)
             is_silu = isinstance(act, torch.nn.SiLU) or type(act).__name__ in ("SiLUActivation", "SiLU")
-            if all(isinstance(k, HIPQuantLinear) and k.bias is None for k in kids) and is_silu:
+            if all(_fusable(k) and k.bias is None for k in kids) and is_silu:
                 setattr(parent, name, HIPLlamaMLP(*kids))
                 n += 1
     return n
@@ -167,7 +174,7 @@ def fuse_llama_norms(model):
         if attn is None or mlp is None:
             continue
         qkv = [getattr(attn, k, None) for k in SIBLING_GROUPS[0]]
-        grp = qkv[0].__dict__.get("_group") if all(isinstance(m, HIPQuantLinear) and m.bias is None for m in qkv) else None
+        grp = qkv[0].__dict__.get("_group") if all(_fusable(m) and m.bias is None for m in qkv) else None
         if grp is not None and not (len(grp[0].members) == 3 and all(a is b for a, b in zip(grp[0].members, qkv))):
             grp = None
         for name, consumer in (("input_layernorm", grp[0] if grp is not None else None),
@@ -194,7 +201,7 @@ def _fused_attention(layer, h, residual, call):
     """``residual + self_attn(h)`` with the add formed in o_proj's epilogue when that call can take it (HIPQuantLinear._forward_residual):
     the residual is offered to o_proj through a one-shot holder for the duration of the attention call only."""
     o_proj = getattr(layer.self_attn, "o_proj", None)
-    if not isinstance(o_proj, HIPQuantLinear) or not residual.is_cuda or residual.dtype is not torch.float16:
+    if not _fusable(o_proj) or not residual.is_cuda or residual.dtype is not torch.float16:
         return residual + call(h)
     hold = [residual]
     o_proj.__dict__["_residual"] = hold

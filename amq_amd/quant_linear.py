@@ -211,9 +211,10 @@ class HIPQuantLinear(nn.Module):
         if bits not in [2, 3, 4]:
             raise NotImplementedError("Only 2,3,4 bits are supported.")     # autogptq.py:44-45
         group_size = group_size if group_size != -1 else infeatures
-        if group_size < GROUP or group_size % GROUP or infeatures % group_size:
-            # 128 is what AMQ produces; coarser groups are read and their (scale, zero) replicated per 128 (native layout)
-            raise NotImplementedError("group_size must be a multiple of 128 that divides infeatures.")
+        if group_size not in ops.FINE_GROUPS and (group_size < GROUP or group_size % GROUP or infeatures % group_size):
+            # 128 is what AMQ produces; coarser groups are read and their (scale, zero) replicated per 128 (native layout); 64 / 32 keep
+            # 128 / group pairs per native tile row and run the GEMV kernel (<= 16 rows) or dequantize-once + the fp16 GEMM, unfused
+            raise NotImplementedError("group_size must be 32, 64 or a multiple of 128 that divides infeatures.")
         if infeatures % 128 or outfeatures % 16:
             raise ValueError(f"need infeatures % 128 == 0 and outfeatures % 16 == 0 (got {infeatures}, {outfeatures})")
         assert weight_dtype == torch.float16, "Only fp16 is supported."      # ft.py:62
@@ -225,7 +226,8 @@ class HIPQuantLinear(nn.Module):
         self.mode = mode
         self.name = name
         self.register_buffer("qweight", torch.zeros(infeatures * outfeatures * bits // 32, dtype=torch.int32))
-        self.register_buffer("meta", torch.zeros(infeatures // GROUP * outfeatures * 2, dtype=torch.float16))
+        self.native_group = ops.native_group(group_size)           # granularity of the native meta: 128, or the group itself for 64 / 32
+        self.register_buffer("meta", torch.zeros(infeatures // self.native_group * outfeatures * 2, dtype=torch.float16))
         # dequant arithmetic travels with the weights (0: (q - z) * s two roundings, 1: fma(q, s, c))
         self.register_buffer("mode_flag", torch.tensor([mode], dtype=torch.int32))
         if bias is not None and bias is not False:
@@ -321,7 +323,7 @@ class HIPQuantLinear(nn.Module):
         key = (self.qweight.data_ptr(), self.meta.data_ptr(), None if self.bias is None else self.bias.data_ptr())
         if self.__dict__.get("_ptrs_ok") != key:
             ops._check_shape(self.bits, self.outfeatures, self.infeatures)
-            ops._check_native(self.qweight, self.meta, self.bits, self.outfeatures, self.infeatures)
+            ops._check_native(self.qweight, self.meta, self.bits, self.outfeatures, self.infeatures, fine=True)
             if self.bias is not None:
                 ops._need(self.bias, torch.float16, "bias", self.outfeatures)
             self.__dict__["_ptrs_ok"] = key
@@ -336,7 +338,7 @@ class HIPQuantLinear(nn.Module):
         if x.shape[-1] != K:
             raise ValueError(f"x: last dim {x.shape[-1]} != K={K}")
         M = x.numel() // K
-        if M > 8 or M == 0 or not x.is_cuda:        # many rows: the GEMM route (workspace handling lives in ops.gemm)
+        if M > 8 or M == 0 or not x.is_cuda or self.native_group != GROUP:        # many rows (and groups of 64 / 32 at every size): ops.linear picks the kernels; workspaces live in ops.gemm
             out = ops.linear(x, self.qweight, self.meta, self.bits, self.mode, N, K, bias=self.bias)
             return out if x_dtype == torch.float16 else out.to(x_dtype)
         if x.device != self.qweight.device:

@@ -23,8 +23,13 @@
  *     group size 128 along K (what AMQ produces: amq/amq_quantization_proxy.py:22,36) or a multiple of 128 that divides K: the
  *     `group` argument of the amq_repack_from_* / amq_dequantize_hqq_f16 calls is the SOURCE format's group size (HQQ's packing
  *     geometry depends on it); each group's (scale, zero) is replicated into the native layout's per-128 pairs, so the compute
- *     entry points are the same kernels for every group size (their `group` argument is validated, not used).  Groups finer than
- *     128 (64, 32) are not supported.  N % 16 == 0, K % 128 == 0.
+ *     entry points are the same kernels for every such group size.  Groups of 64 and 32 (HQQ's default group_size is 64,
+ *     hqq/core/quantize.py:1078; the reference's GPTQ kernels take any groupsize, auto_gptq_kernel.cu:203) keep 128 / group pairs per
+ *     (row, 128-column tile) in the native meta (amq_native_meta_bytes grows accordingly) and are served by: the amq_repack_from_* and
+ *     amq_dequantize_* calls, the GEMV kernel (amq_gemv_f16 / amq_gemv_grouped_f16: <= 16 rows, every prologue, default options) and the
+ *     dequantize-once GEMM route (amq_gemm_route_f16 / amq_gemm_res_f16 / amq_gemm_gated_f16 with the amq_gemm_route_workspace_bytes_g
+ *     workspace); the other compute entry points return AMQ_ESHAPE for them.  The compute calls' `group` argument is therefore the
+ *     NATIVE buffers' granularity: 64, 32, or anything >= 128.  N % 16 == 0, K % 128 == 0.
  *   - "native" buffers are in the AMQ-T16 layout (amq_common.cuh);
  *     sizes from amq_native_*_bytes(); produced by the amq_repack_from_* calls.
  */
@@ -42,7 +47,7 @@ extern "C" {
 
 #define AMQ_OK            0
 #define AMQ_EINVAL       -1        /* bad argument (null pointer, bits, mode ...) */
-#define AMQ_ESHAPE       -2        /* unsupported shape (N % 16, K % 128, group not a multiple of 128 dividing K, M out of range) */
+#define AMQ_ESHAPE       -2        /* unsupported shape (N % 16, K % 128, group not 32 / 64 / a multiple of 128 dividing K, M out of range) */
 #define AMQ_ELAUNCH      -3        /* HIP launch failed (message carries hipGetErrorString) */
 #define AMQ_EUNSUPPORTED -4        /* valid request this build does not implement */
 
@@ -262,6 +267,9 @@ int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qweight_nati
  * matching workspace query (0: no workspace needed).  The workspace holds split-K partials (few rows) or the dequantized
  * fp16 weights (AMQ_GEMM_DEQ, and AUTO on MFMA-bound launches) -- never both; without it AUTO runs a fused kernel. */
 size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K);
+/* ... for a given group size: groups of 64 / 32 ALWAYS take the dequantize-once route beyond the GEMV's 16 rows (N * K * 2 bytes; AMQ_GEMM_AUTO or
+ * AMQ_GEMM_DEQ, the workspace is mandatory) -- the fused many-row kernels read one (scale, zero) pair per 128 columns. */
+size_t amq_gemm_route_workspace_bytes_g(int route, int M, int N, int K, int group);
 int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
                        const void* bias, const void* residual, void* y, int M, int N, int K, int group, int x_stride,
                        int y_stride, void* workspace, size_t workspace_bytes, void* stream);

@@ -49,7 +49,7 @@ def test_version_sizes_and_validation():
     assert rc == -1 and b"bits" in lib.amq_last_error()
     rc = lib.amq_gemv_f16(4, 0, one, one, one, None, one, 1, 4096, 4100, 128, 0, 0, None)
     assert rc == -2
-    rc = lib.amq_gemv_f16(4, 0, one, one, one, None, one, 1, 4096, 4096, 64, 0, 0, None)
+    rc = lib.amq_gemv_f16(4, 0, one, one, one, None, one, 1, 4096, 4096, 96, 0, 0, None)
     assert rc == -2 and b"group" in lib.amq_last_error()
     rc = lib.amq_gemv_f16(4, 0, one, one, one, None, one, 17, 4096, 4096, 128, 0, 0, None)
     assert rc == -2 and b"amq_gemm_f16" in lib.amq_last_error()
@@ -98,6 +98,35 @@ def test_dequantize_once_route_host_side():
     assert f(one, one, None, None, None, one, 512, N + 8, K, 0, 0, None) == -2                  # N % 16
     assert f(one, one, None, None, None, one, 512, N, K, K + 4, 0, None) == -2                  # x rows not 16-byte aligned
     assert f(one, one, None, None, None, one, 1 << 20, N, 8192, 0, 0, None) == -2               # x spans >= 4 GiB
+
+
+def test_finer_groups_host_side():
+    """groups of 64 / 32: native meta sizes, the workspace query, and which entry points take them (host logic, no GPU)"""
+    lib = _lib.load()
+    N, K = 4096, 4096
+    base = lib.amq_native_meta_bytes(N, K, 128)
+    assert lib.amq_native_meta_bytes(N, K, 256) == base and lib.amq_native_meta_bytes(N, K, 64) == 2 * base and lib.amq_native_meta_bytes(N, K, 32) == 4 * base
+    for g in (64, 32):
+        for m in (1, 17, 4096, 32768):
+            assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_AUTO, m, N, K, g) == N * K * 2       # always the dequantize-once route
+        assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_RING, 4096, N, K, g) == 0
+    assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_AUTO, 64, N, K, 128) == lib.amq_gemm_route_workspace_bytes(_lib.GEMM_AUTO, 64, N, K)
+    one = ctypes.c_void_p(256)
+    # the plain GEMM entry has no workspace: refused with the way out in the message
+    assert lib.amq_gemm_f16(4, 0, one, one, one, None, one, 40, N, K, 64, 0, 0, None) == -2
+    assert b"amq_gemm_route_f16" in lib.amq_last_error()
+    # route calls: AUTO / DEQ with the workspace
+    assert lib.amq_gemm_route_f16(_lib.GEMM_AUTO, 4, 0, one, one, one, None, None, one, 40, N, K, 64, 0, 0, None, 0, None) == -1
+    assert b"workspace" in lib.amq_last_error()
+    assert lib.amq_gemm_route_f16(_lib.GEMM_RING, 4, 0, one, one, one, None, None, one, 4096, N, K, 32, 0, 0, one, N * K * 2, None) == -1
+    assert b"dequantize-once" in lib.amq_last_error()
+    assert lib.amq_gemm_route_f16(_lib.GEMM_AUTO, 4, 0, one, one, one, None, None, one, 40, N, K, 64, 0, 0, one, 1024, None) == -1   # too small
+    # GEMV options other than the default form
+    seg = (_lib.Segment * 1)(_lib.Segment(256, 256, None, None, 256, N, 4, 0, 0))
+    for bad in (_lib.GemvOpts(math=1), _lib.GemvOpts(dot=1), _lib.GemvOpts(depth=4)):
+        assert lib.amq_gemv_grouped_f16(seg, 1, one, None, None, 0.0, 0, 1, K, 64, 0, ctypes.byref(bad), None) == -1
+        assert b"default form" in lib.amq_last_error()
+    assert lib.amq_gemm_xfrag_f16(4, 0, one, one, one, None, None, None, one, 17, N, K, 64, 0, None) == -2
 
 
 def test_decode_engine_host_side():

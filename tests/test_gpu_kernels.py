@@ -130,8 +130,9 @@ GCASES = sorted(glob.glob(os.path.join(GOLDEN, "hqq_g*_b*.npz")))
 
 @pytest.mark.parametrize("path", GCASES, ids=[os.path.basename(c) for c in GCASES])
 def test_group256_reference_golden(path):
-    """the reference's own group-256 layer (HQQ Format A payload and GPTQLinear buffers): native dequant == its W_deq bit for bit,
-    outputs vs its captured CPU results, GPTQ import == the reference kernels' fma dequant"""
+    """the reference's own group-256, group-64 and group-32 layers (HQQ Format A payload and GPTQLinear buffers): native dequant == its
+    W_deq bit for bit, outputs vs its captured CPU results (GEMV kernel; 128 rows: the fused kernels at 256, dequantize-once + the fp16
+    GEMM at 64 / 32), GPTQ import == the reference kernels' fma dequant"""
     from amq_amd import ops
     g = _load(path)
     bits, (n, k), G = int(g["nbits"]), tuple(int(v) for v in g["shape"]), int(g["group_size"])
@@ -140,9 +141,9 @@ def test_group256_reference_golden(path):
     assert np.array_equal(w.view(np.uint16), g["W_deq"].view(np.uint16))
     w2 = ops.dequantize_hqq(_t(g["W_q"]), _t(g["scale"].reshape(-1)), _t(g["zero"].reshape(-1)), bits, n, k, group=G).cpu().numpy()
     assert np.array_equal(w2.view(np.uint16), g["W_deq"].view(np.uint16))
-    _assert_close(ops.gemv(_t(g["x"]), qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy(), g["y_ref"], "gemv M=3, group 256")
+    _assert_close(ops.gemv(_t(g["x"]), qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy(), g["y_ref"], f"gemv M=3, group {G}")
     _assert_close(ops.gemm(_t(g["gptq_x"]), qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy(),
-                  linear_ref.linear_f16(g["gptq_x"], g["W_deq"]), "gemm M=128, group 256")
+                  linear_ref.linear_f16(g["gptq_x"], g["W_deq"]), f"gemm M=128, group {G}")
     qg, mg = ops.repack_from_gptq(_t(g["gptq_qweight"]), _t(g["gptq_scales"]), _t(g["gptq_zeros"]), bits, n, k, group=G)
     wg = ops.dequantize(qg, mg, bits, ops.MODE_FMA, n, k).cpu().numpy()
     assert np.array_equal(wg.view(np.uint16), gptq_ref.dequant_kernel(g["gptq_qweight"], g["gptq_scales"], g["gptq_zeros"], bits, G).view(np.uint16))
@@ -188,7 +189,102 @@ def test_coarser_groups_are_read_bit_exact(bits, n, k, group):
         got = ops.dequantize(m3.qweight, m3.meta, 4, ops.MODE_FMA, n, k).cpu().numpy()
         assert np.array_equal(got.view(np.uint16), np.asarray(want, np.float16).view(np.uint16))
     with pytest.raises(ValueError):
-        ops.repack_from_hqq(hd.W_q, hd.scale.reshape(-1), hd.zero.reshape(-1), bits, n, k, group=64)
+        ops.repack_from_hqq(hd.W_q, hd.scale.reshape(-1), hd.zero.reshape(-1), bits, n, k, group=96)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("group", [64, 32])
+@pytest.mark.parametrize("n,k", [(64, 512), (48, 1536), (4096, 4096), (1024, 11008)])
+def test_finer_groups(bits, group, n, k):
+    """groups of 64 / 32 (128 / group (scale, zero) pairs per native tile row): repack from all three source formats -> dequantize == the
+    oracle's dequant of the same buffers, bit for bit; the standalone HQQ dequant too; the GEMV kernel (1 / 3 / 16 rows, bias, the fused
+    RMSNorm and SiLU-mul prologues, residual, grouped segments) and the dequantize-once GEMM (17 / 300 rows, bias / residual / gate)
+    within the output tolerance; the module; entry points that read one pair per tile refuse them"""
+    from amq_amd import ops
+    from amq_amd.hqq_format import random_hqq
+    from amq_amd.quant_linear import HIPQuantLinear
+    dev = _dev()
+    h = random_hqq(n, k, bits, seed=11 * bits + group, group=group, bias=True)
+    w_ref = np.asarray(hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (n, k), group_size=group), np.float16)
+    hd = h.to(dev)
+    qn, mn = ops.repack_from_hqq(hd.W_q, hd.scale.reshape(-1), hd.zero.reshape(-1), bits, n, k, group=group)
+    assert mn.numel() == n * k // group * 2
+    w = ops.dequantize(qn, mn, bits, ops.MODE_HQQ, n, k).cpu().numpy()
+    assert np.array_equal(w.view(np.uint16), w_ref.view(np.uint16))
+    w2 = ops.dequantize_hqq(hd.W_q, hd.scale.reshape(-1), hd.zero.reshape(-1), bits, n, k, group=group).cpu().numpy()
+    assert np.array_equal(w2.view(np.uint16), w_ref.view(np.uint16))
+    gen = torch.Generator().manual_seed(3)
+    bias = h.bias
+    for m in (1, 3, min(16, ops.gemv_max_rows(k))):            # (the kernel stages its x rows in LDS: fewer than 16 for long rows)
+        x = torch.randn(m, k, generator=gen).to(torch.float16)
+        y = ops.gemv(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias.to(dev)).cpu().numpy()
+        _assert_close(y, linear_ref.linear_f16(x.numpy(), w_ref, bias.numpy()), f"gemv M={m}, group {group}")
+    # prologues + residual + two segments of one launch (the second: the same weights again)
+    x = torch.randn(2, k, generator=gen).to(torch.float16)
+    gamma = (1.0 + 0.1 * torch.randn(k, generator=gen)).to(torch.float16)
+    res = torch.randn(2, n, generator=gen).to(torch.float16)
+    y0, y1 = torch.empty(2, n, dtype=torch.float16, device=dev), torch.empty(2, n, dtype=torch.float16, device=dev)
+    ops.gemv_grouped(x.to(dev), [dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_HQQ, N=n, y=y0, residual=res.to(dev)),
+                                 dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_HQQ, N=n, y=y1)], k,
+                     prologue=ops.PRO_RMSNORM, gamma=gamma.to(dev), eps=1e-5)
+    xn = ops.rmsnorm(x.to(dev), gamma.to(dev), 1e-5).cpu()
+    want = linear_ref.linear_f16(xn.numpy(), w_ref)
+    _assert_close(y1.cpu().numpy(), want, f"rmsnorm prologue, group {group}")
+    _assert_close(y0.cpu().numpy(), (res.float() + torch.from_numpy(np.asarray(want, np.float16)).float()).to(torch.float16).numpy(), f"residual, group {group}")
+    up = torch.randn(2, k, generator=gen).to(torch.float16)
+    y2 = torch.empty(2, n, dtype=torch.float16, device=dev)
+    ops.gemv_grouped(x.to(dev), [dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_HQQ, N=n, y=y2)], k, prologue=ops.PRO_SILU_MUL, x2=up.to(dev))
+    act = ops.silu_mul(x.to(dev).reshape(-1), up.to(dev).reshape(-1)).reshape(2, k).cpu()
+    _assert_close(y2.cpu().numpy(), linear_ref.linear_f16(act.numpy(), w_ref), f"silu-mul prologue, group {group}")
+    # many rows: dequantize once + the fp16 GEMM (the only many-row route of these groups)
+    for m in (17, 300):
+        x = torch.randn(m, k, generator=gen).to(torch.float16)
+        y0 = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k)
+        _assert_close(y0.cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref), f"gemm M={m}, group {group}")
+        y = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias.to(dev))
+        assert torch.equal(y, y0 + bias.to(dev))                   # fp16(x . W^T), then the bias as a separate fp16 add (the unfused reference's roundings)
+        assert torch.equal(y, ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias.to(dev), route=ops.GEMM_DEQ))
+        r = torch.randn(m, n, generator=gen).to(torch.float16)
+        yr = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias.to(dev), residual=r.to(dev))
+        assert torch.equal(yr.cpu(), (r.float() + torch.from_numpy(y.cpu().numpy()).float()).to(torch.float16))
+        if n % 8 == 0:
+            g = torch.randn(m, n, generator=gen).to(torch.float16)
+            yg = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, gate=g.to(dev))
+            up_ = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k)
+            assert torch.equal(yg.reshape(-1), ops.silu_mul(g.to(dev).reshape(-1), up_.reshape(-1)))
+        with pytest.raises(Exception, match="dequantize-once"):
+            ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, route=ops.GEMM_RING)
+    # the module (plain forwards: GEMV kernel / dequantize-once GEMM), state_dict round trip
+    mod = HIPQuantLinear.from_hqq(h, device=dev)
+    assert mod.group_size == group and mod.native_group == group
+    for m in (1, 5, 40):
+        x = torch.randn(m, k, generator=gen).to(torch.float16)
+        _assert_close(mod(x.to(dev)).cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref, bias.numpy()), f"module M={m}, group {group}")
+    m2 = HIPQuantLinear(bits, group, k, n, bias=True).to(dev)
+    m2.load_state_dict(mod.state_dict())
+    assert torch.equal(m2(x.to(dev)), mod(x.to(dev)))
+    # GPTQ int32 / AWQ int16 buffers of the same layer
+    s_ng, z_ng = h.scale.numpy().reshape(n, k // group), h.zero.numpy().reshape(n, k // group)
+    qweight, scales, zeros = gptq_ref.pack(w_ref, s_ng, z_ng, bits, group_size=group)
+    want = np.asarray(gptq_ref.dequant_kernel(qweight, scales, zeros, bits, group_size=group), np.float16)
+    m3 = HIPQuantLinear.from_gptq_buffers(torch.from_numpy(qweight).to(dev), torch.from_numpy(scales).to(dev), torch.from_numpy(zeros).to(dev), bits)
+    assert m3.group_size == group
+    got = ops.dequantize(m3.qweight, m3.meta, bits, ops.MODE_FMA, n, k).cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    x = torch.randn(2, k, generator=gen).to(torch.float16)
+    _assert_close(m3(x.to(dev)).cpu().numpy(), linear_ref.linear_f16(x.numpy(), want), f"gptq module, group {group}")
+    if bits == 4 and n % 4 == 0 and k % 64 == 0:
+        qw, sc, szr = awq_ref.pack(w_ref, s_ng, z_ng, group_size=group)
+        want = np.asarray(awq_ref.dequant_kernel(qw, sc, szr, group_size=group), np.float16)
+        m4 = HIPQuantLinear.from_ft_buffers(torch.from_numpy(qw).to(dev), torch.from_numpy(sc).to(dev), torch.from_numpy(szr).to(dev))
+        got = ops.dequantize(m4.qweight, m4.meta, 4, ops.MODE_FMA, n, k).cpu().numpy()
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    # entry points that read one pair per tile
+    with pytest.raises(ValueError, match="groups of 128"):
+        ops.gemm_xfrag_grouped(torch.empty(64 * k, dtype=torch.float16, device=dev), 17,
+                               [dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_HQQ, N=n, y=torch.empty(17, n, dtype=torch.float16, device=dev))], k)
+    with pytest.raises(Exception, match="default form"):
+        ops.gemv(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, opts=ops.GemvOpts(math=ops.MATH_LINEAR))
 
 
 @pytest.mark.parametrize("bits", [2, 3, 4])

@@ -44,7 +44,7 @@ def test_from_hqq_layer_duck_typing_and_rejections():
     layer.W_q, layer.meta, layer.bias, layer.name = torch.nn.Parameter(h.W_q, requires_grad=False), dict(h.meta), h.bias, "q_proj"
     got = hqq_format.from_hqq_layer(layer)
     assert got.nbits == 3 and tuple(got.shape) == (32, 256) and got.name == "q_proj" and torch.equal(got.W_q, h.W_q)
-    for key, val, exc in (("axis", 0, ValueError), ("group_size", 64, ValueError), ("nbits", 8, NotImplementedError),
+    for key, val, exc in (("axis", 0, ValueError), ("group_size", 96, ValueError), ("nbits", 8, NotImplementedError),
                           ("view_as_float", True, ValueError)):
         bad = dict(h.meta); bad[key] = val
         layer.meta = bad

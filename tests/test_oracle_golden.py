@@ -128,21 +128,21 @@ def test_awq_pack_bit_exact(path):
     assert np.max(np.abs(wk - wd)) <= 2.0 ** -9 * np.max(np.abs(wd))
 
 
-# ---- a group size other than 128 (256), captured from the real reference by tests/golden/gen_golden_groups.py
+# ---- group sizes other than 128 (256; 64 and 32), captured from the real reference by tests/golden/gen_golden_groups.py
 GCASES = sorted(glob.glob(os.path.join(GOLDEN, "hqq_g*_b*.npz")))
 
 
 def test_group_fixture_inventory():
-    assert len(GCASES) == 3
+    assert len(GCASES) == 9
 
 
 @pytest.mark.parametrize("path", GCASES, ids=[os.path.basename(c) for c in GCASES])
 def test_coarser_group_oracle_matches_reference(path):
-    """the oracle's group_size parameter against the reference at group 256: Format A dequant and pack / unpack bit-exact (the
+    """the oracle's group_size parameter against the reference at groups 256, 64 and 32: Format A dequant and pack / unpack bit-exact (the
     packing geometry depends on the group), forward within one fp16 ulp, GPTQ pack bit-exact and its fallback forward"""
     g = _load(path)
     bits, (n, k), G = int(g["nbits"]), tuple(int(v) for v in g["shape"]), int(g["group_size"])
-    assert G == 256
+    assert G in (256, 64, 32)
     w = hqq_ref.dequantize(g["W_q"], g["scale"], g["zero"], bits, (n, k), G)
     assert np.array_equal(w.view(np.uint16), g["W_deq"].view(np.uint16))
     q = hqq_ref.unpack(g["W_q"], bits, (n, k), G)
