@@ -82,7 +82,8 @@ def test_float32_input_is_cast_like_the_reference():
     with pytest.raises(NotImplementedError):
         HIPQuantLinear(8, 128, 256, 64)
     with pytest.raises(NotImplementedError):
-        HIPQuantLinear(4, 64, 256, 64)
+        HIPQuantLinear(4, 96, 256, 64)
+    assert HIPQuantLinear(4, 64, 256, 64).meta.numel() == 256 // 64 * 64 * 2       # groups of 64 / 32: 128 / group pairs per native tile row
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "hqq_b*_128x512.npz"))), ids=os.path.basename)
@@ -152,6 +153,42 @@ def test_reference_ffi_shaped_entry_points(path):
             _lib.check(fn(vp(x), vp(kq), vp(sc), vp(sz), vp(y), m, n, k, 128, vp(ws), ws.numel(), 0, st))
             ref = linear_ref.linear_f16(g["gptq_x"][:m], w).astype(np.float32)
             assert np.all(np.abs(y.float().cpu().numpy() - ref) <= 1e-3 * np.abs(ref) + 1e-3 * np.sqrt(np.mean(ref ** 2)))
+
+
+FINE_CASES = sorted(glob.glob(os.path.join(GOLDEN, "hqq_g64_b*.npz")) + glob.glob(os.path.join(GOLDEN, "hqq_g32_b*.npz")))
+
+
+@pytest.mark.parametrize("path", FINE_CASES, ids=[os.path.basename(c) for c in FINE_CASES])
+def test_reference_ffi_shaped_gptq_call_with_finer_groups(path):
+    """vecquant{2,3,4}matmul_faster_old takes any groupsize (auto_gptq_kernel.cu:203: g = k / groupsize): the reference's own GPTQLinear
+    buffers of its group-64 / group-32 layers through amq_vecquantmatmul_faster_old, up to the GEMV kernel's 16 rows; more rows are
+    refused with the way out in the message (this call carries no workspace for the dequantized weights)"""
+    import ctypes
+    from amq_amd import _lib
+    from oracle import gptq_ref
+    lib = _lib.load()
+    g = {k: v for k, v in np.load(path).items()}
+    bits, (n, k), G = int(g["nbits"]), tuple(int(v) for v in g["shape"]), int(g["group_size"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+    vp = lambda x: ctypes.c_void_p(x.data_ptr())
+    st = _lib.current_stream()
+    qw, sc, zr = t(g["gptq_qweight"]), t(g["gptq_scales"]), t(g["gptq_zeros"])
+    w = gptq_ref.dequant_kernel(g["gptq_qweight"], g["gptq_scales"], g["gptq_zeros"], bits, G)
+    for m in (1, 5, 16):
+        x = t(g["gptq_x"][:m])
+        ws = torch.empty(lib.amq_compat_workspace_bytes(bits, m, n, k), dtype=torch.uint8, device=_dev())
+        mul = torch.full((m, n), 0.5, dtype=torch.float32, device=_dev())
+        for valid in (0, 1):
+            _lib.check(lib.amq_vecquantmatmul_faster_old(bits, vp(x), vp(qw), vp(mul), vp(sc), vp(zr), G, k // 2, m,
+                                                         qw.shape[0], n, vp(ws), ws.numel(), valid, st))
+        ref = linear_ref.linear_f16(g["gptq_x"][:m], w).astype(np.float32)
+        assert np.all(np.abs(mul.cpu().numpy() - (0.5 + 2 * ref)) <= 2e-3 * np.abs(ref) + 2e-3 * np.sqrt(np.mean(ref ** 2)))
+    x = t(g["gptq_x"][:40])
+    ws = torch.empty(lib.amq_compat_workspace_bytes(bits, 40, n, k), dtype=torch.uint8, device=_dev())
+    mul = torch.zeros(40, n, dtype=torch.float32, device=_dev())
+    assert lib.amq_vecquantmatmul_faster_old(bits, vp(x), vp(qw), vp(mul), vp(sc), vp(zr), G, k // 2, 40, qw.shape[0], n,
+                                             vp(ws), ws.numel(), 0, st) == -2
+    assert b"amq_gemm_route_f16" in lib.amq_last_error()
 
 
 def test_module_walk_decode_matches_runner():
