@@ -49,11 +49,15 @@ void check_x(const at::Tensor& x, int64_t K) {
     TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kHalf && x.is_contiguous(), "x: expected a contiguous fp16 tensor on the GPU");
     TORCH_CHECK(x.dim() >= 1 && x.size(-1) == K, "x: last dim ", x.size(-1), " != K=", K);
 }
-void check_native(const at::Tensor& qw, const at::Tensor& mt, int64_t bits, int64_t N, int64_t K, const at::Tensor& x) {
+// returns the native meta's granularity: 128 (one (scale, zero) pair per tile row), or 64 / 32 (two / four pairs: amq_common.cuh)
+int check_native(const at::Tensor& qw, const at::Tensor& mt, int64_t bits, int64_t N, int64_t K, const at::Tensor& x) {
     TORCH_CHECK(bits >= 2 && bits <= 4 && N % 16 == 0 && K % 128 == 0, "bits must be 2..4, N % 16 == 0, K % 128 == 0");
     TORCH_CHECK(qw.scalar_type() == at::kInt && qw.is_contiguous() && qw.numel() == N * K * bits / 32, "qweight: not a native payload of this shape");
-    TORCH_CHECK(mt.scalar_type() == at::kHalf && mt.is_contiguous() && mt.numel() == N * (K / 128) * 2, "meta: not a native meta buffer of this shape");
+    const int64_t base = N * (K / 128) * 2;
+    TORCH_CHECK(mt.scalar_type() == at::kHalf && mt.is_contiguous() && (mt.numel() == base || mt.numel() == 2 * base || mt.numel() == 4 * base),
+                "meta: not a native meta buffer of this shape");
     TORCH_CHECK(qw.device() == x.device() && mt.device() == x.device(), "x and the weights must be on the same device");
+    return (int)(128 * base / mt.numel());
 }
 
 }  // namespace
@@ -77,7 +81,7 @@ at::Tensor linear(const at::Tensor& x, const at::Tensor& qweight, const at::Tens
                   int64_t bits, int64_t mode, int64_t N, int64_t K) {
     need_lib();
     check_x(x, K);
-    check_native(qweight, meta, bits, N, K, x);
+    const int group = check_native(qweight, meta, bits, N, K, x);
     const int64_t M = x.numel() / K;
     TORCH_CHECK(M >= 1 && M <= 8, "linear: 1..8 rows (got ", M, "); more rows take ops.linear / ops.gemm");
     if (bias) TORCH_CHECK(bias->scalar_type() == at::kHalf && bias->numel() == N && bias->device() == x.device(), "bias: fp16 [N] on x's device");
@@ -85,7 +89,7 @@ at::Tensor linear(const at::Tensor& x, const at::Tensor& qweight, const at::Tens
     sizes.back() = N;
     at::Tensor y = at::empty(sizes, x.options());
     check_rc(g_linear((int)bits, (int)mode, x.data_ptr(), qweight.data_ptr(), meta.data_ptr(), bias ? bias->data_ptr() : nullptr,
-                      y.data_ptr(), (int)M, (int)N, (int)K, 128, stream_of(x)), "amq_linear_f16");
+                      y.data_ptr(), (int)M, (int)N, (int)K, group, stream_of(x)), "amq_linear_f16");
     return y;
 }
 
@@ -104,8 +108,11 @@ std::vector<at::Tensor> grouped(const at::Tensor& x, const std::vector<at::Tenso
     std::vector<at::Tensor> ys;
     ys.reserve(n);
     auto sizes = x.sizes().vec();
+    int group = 0;
     for (size_t i = 0; i < n; ++i) {
-        check_native(qweights[i], metas[i], bits[i], Ns[i], K, x);
+        const int g = check_native(qweights[i], metas[i], bits[i], Ns[i], K, x);
+        TORCH_CHECK(group == 0 || g == group, "segments of one launch must share their group size");
+        group = g;
         sizes.back() = Ns[i];
         ys.push_back(at::empty(sizes, x.options()));
         segs[i] = Segment{qweights[i].data_ptr(), metas[i].data_ptr(), nullptr, nullptr, ys[i].data_ptr(), (int)Ns[i], (int)bits[i], (int)modes[i], 0};
@@ -122,7 +129,7 @@ std::vector<at::Tensor> grouped(const at::Tensor& x, const std::vector<at::Tenso
     } else {
         TORCH_CHECK(prologue == 0, "unknown prologue");
     }
-    check_rc(g_grouped(segs, (int)n, x.data_ptr(), x2, gamma, (float)eps, (int)prologue, (int)M, (int)K, 128, 0, nullptr, stream_of(x)),
+    check_rc(g_grouped(segs, (int)n, x.data_ptr(), x2, gamma, (float)eps, (int)prologue, (int)M, (int)K, group, 0, nullptr, stream_of(x)),
              "amq_gemv_grouped_f16");
     return ys;
 }
@@ -134,6 +141,7 @@ struct Group {
     std::vector<at::Tensor> qw, mt;
     std::vector<Segment> segs;
     int64_t K;
+    int group = 0;              // granularity of the members' native meta (all members alike): 128, 64 or 32
 
     Group(const std::vector<at::Tensor>& qweights, const std::vector<at::Tensor>& metas, const std::vector<int64_t>& Ns,
           const std::vector<int64_t>& bits, const std::vector<int64_t>& modes, int64_t K_) : qw(qweights), mt(metas), K(K_) {
@@ -141,7 +149,9 @@ struct Group {
         TORCH_CHECK(n >= 1 && n <= 4 && mt.size() == n && Ns.size() == n && bits.size() == n && modes.size() == n, "1..4 segments");
         for (size_t i = 0; i < n; ++i) {
             TORCH_CHECK(qw[i].is_cuda() && qw[i].device() == qw[0].device(), "the weights of a group live on one GPU");
-            check_native(qw[i], mt[i], bits[i], Ns[i], K, qw[0]);
+            const int g = check_native(qw[i], mt[i], bits[i], Ns[i], K, qw[0]);
+            TORCH_CHECK(group == 0 || g == group, "the members of a group must share their group size");
+            group = g;
             segs.push_back(Segment{qw[i].data_ptr(), mt[i].data_ptr(), nullptr, nullptr, nullptr, (int)Ns[i], (int)bits[i], (int)modes[i], 0});
         }
     }
@@ -182,7 +192,7 @@ struct Group {
         } else {
             TORCH_CHECK(prologue == 0, "unknown prologue");
         }
-        check_rc(g_grouped(local, (int)segs.size(), x.data_ptr(), x2, gamma, (float)eps, (int)prologue, (int)M, (int)K, 128, 0, nullptr, stream_of(x)),
+        check_rc(g_grouped(local, (int)segs.size(), x.data_ptr(), x2, gamma, (float)eps, (int)prologue, (int)M, (int)K, group, 0, nullptr, stream_of(x)),
                  "amq_gemv_grouped_f16");
         return ys;
     }

@@ -115,9 +115,13 @@ def _walk_hip(model, fct):
 
 
 def _fusable(m):
-    """a HIPQuantLinear the grouped / fused launches take: groups of 128 (and multiples).  Groups of 64 / 32 stay plain modules (their
-    forwards run the GEMV kernel / dequantize-once GEMM one linear at a time)"""
-    return isinstance(m, HIPQuantLinear) and getattr(m, "native_group", ops.GROUP) == ops.GROUP
+    """a HIPQuantLinear the grouped / fused launches take"""
+    return isinstance(m, HIPQuantLinear)
+
+
+def _same_group(mods):
+    """siblings of ONE launch share the granularity of their native meta (128, or 64 / 32: amq_gemv_grouped_f16 takes one `group`)"""
+    return len({getattr(m, "native_group", ops.GROUP) for m in mods}) == 1
 
 
 def group_sibling_linears(model):
@@ -130,7 +134,7 @@ def group_sibling_linears(model):
     for parent in model.modules():
         for names in SIBLING_GROUPS:
             mods = [getattr(parent, n, None) for n in names]
-            if not all(_fusable(m) for m in mods) or len({m.infeatures for m in mods}) != 1:
+            if not all(_fusable(m) for m in mods) or len({m.infeatures for m in mods}) != 1 or not _same_group(mods):
                 continue
             grps = [m.__dict__.get("_group") for m in mods]
             if all(g is not None and g[0] is grps[0][0] and g[1] == i for i, g in enumerate(grps)) and len(grps[0][0].members) == len(mods) \
@@ -153,7 +157,7 @@ def fuse_llama_mlps(model):
             kids = [getattr(mod, k, None) for k in ("gate_proj", "up_proj", "down_proj")]
             act = getattr(mod, "act_fn", None)
             is_silu = isinstance(act, torch.nn.SiLU) or type(act).__name__ in ("SiLUActivation", "SiLU")
-            if all(_fusable(k) and k.bias is None for k in kids) and is_silu:
+            if all(_fusable(k) and k.bias is None for k in kids) and is_silu and _same_group(kids[:2]):      # (gate / up share a launch)
                 setattr(parent, name, HIPLlamaMLP(*kids))
                 n += 1
     return n

@@ -338,7 +338,7 @@ class HIPQuantLinear(nn.Module):
         if x.shape[-1] != K:
             raise ValueError(f"x: last dim {x.shape[-1]} != K={K}")
         M = x.numel() // K
-        if M > 8 or M == 0 or not x.is_cuda or self.native_group != GROUP:        # many rows (and groups of 64 / 32 at every size): ops.linear picks the kernels; workspaces live in ops.gemm
+        if M > 8 or M == 0 or not x.is_cuda:        # many rows: the GEMM route (workspace handling lives in ops.gemm)
             out = ops.linear(x, self.qweight, self.meta, self.bits, self.mode, N, K, bias=self.bias)
             return out if x_dtype == torch.float16 else out.to(x_dtype)
         if x.device != self.qweight.device:
@@ -365,7 +365,7 @@ class HIPQuantLinear(nn.Module):
         x2 = x if x.is_contiguous() else x.contiguous()
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float16, device=x.device)
         # the stream of x's device (not of whatever device is current): the pointers above belong to that device
-        rc = _lib.load().amq_linear_f16(self.bits, self.mode, x2.data_ptr(), qp, mp, bp, y.data_ptr(), M, N, K, GROUP,
+        rc = _lib.load().amq_linear_f16(self.bits, self.mode, x2.data_ptr(), qp, mp, bp, y.data_ptr(), M, N, K, self.native_group,
                                         _lib.stream_of(x.device))
         if rc != 0:
             _lib.check(rc)

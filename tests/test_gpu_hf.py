@@ -21,7 +21,7 @@ def _tiny_llama(n_kv_heads):
     return LlamaForCausalLM(cfg).to(torch.float16).to("cuda:0").eval()
 
 
-def _quantize_linears(model, bits_cycle=(4, 2, 3, 3, 2, 4, 3)):
+def _quantize_linears(model, bits_cycle=(4, 2, 3, 3, 2, 4, 3), group=128):
     """replace every decoder linear by an HQQ stand-in (random HQQ weights of the layer's shape); returns the model and a
     reference copy whose nn.Linear weights are the ORACLE's dequantized weights"""
     from amq_amd.hqq_format import random_hqq
@@ -38,9 +38,9 @@ def _quantize_linears(model, bits_cycle=(4, 2, 3, 3, 2, 4, 3)):
                     continue
                 n, k = lin.weight.shape
                 bits = bits_cycle[i % len(bits_cycle)]
-                h = random_hqq(n, k, bits, seed=100 + i)
+                h = random_hqq(n, k, bits, seed=100 + i, group=group)
                 i += 1
-                w = hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (n, k))
+                w = hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (n, k), group_size=group)
                 getattr(rparent, name).weight.data = torch.from_numpy(w.astype(np.float16)).to("cuda:0")
                 setattr(parent, name, HQQWeightsModule(h.to(torch.device("cuda:0"))))
     return model, ref
@@ -85,6 +85,44 @@ def test_hf_llama_with_swapped_linears_matches_oracle_weights(n_kv_heads, seq):
         assert torch.equal(y, y2)
     else:
         assert (y - y2).abs().max() <= 4e-3 * y2.abs().max()
+
+
+@pytest.mark.parametrize("group", [64, 32])
+@pytest.mark.parametrize("seq", [1, 5, 24])
+def test_hf_llama_with_finer_group_layers(group, seq):
+    """layers quantized with groups of 64 / 32 (HQQ's default group_size is 64) through the same drop-in flow: the sibling groups, the fused
+    MLP / norms / residual epilogues are the same launches (amq_gemv_grouped_f16 takes the group size); 24 rows: the GEMV kernel reaches 16,
+    the rest is dequantize-once + the fp16 GEMM per linear"""
+    from amq_amd.patching import prepare_for_inference
+    from amq_amd.quant_linear import HIPQuantLinear, HIPLlamaMLP, HIPRMSNorm
+    model, ref = _quantize_linears(_tiny_llama(2), group=group)
+    prepare_for_inference(model, backend="hip")
+    mods = [m for m in model.modules() if isinstance(m, HIPQuantLinear)]
+    assert len(mods) == 14 and all(m.group_size == group and m.native_group == group for m in mods)
+    assert all("_group" in m.__dict__ for m in mods if m.name in ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj"))
+    assert sum(isinstance(m, HIPLlamaMLP) for m in model.modules()) == 2 and sum(isinstance(m, HIPRMSNorm) for m in model.modules()) == 4
+    ids = torch.randint(0, 1000, (1, seq), generator=torch.Generator().manual_seed(seq)).to("cuda:0")
+    with torch.inference_mode():
+        y = model(ids).logits.float()
+        y_ref = ref(ids).logits.float()
+    assert torch.isfinite(y).all() and (y - y_ref).abs().max() <= 2e-3 * y_ref.abs().max()
+    model2, _ = _quantize_linears(_tiny_llama(2), group=group)
+    prepare_for_inference(model2, backend="hip", group_siblings=False, fuse_mlp=False, fuse_layers=False)      # the plain module swap
+    model3, _ = _quantize_linears(_tiny_llama(2), group=group)
+    prepare_for_inference(model3, backend="hip", fuse_norms=False)
+    with torch.inference_mode():
+        y2 = model2(ids).logits.float()
+        y3 = model3(ids).logits.float()
+    assert torch.equal(y3, y2)
+    if seq > 8:
+        assert torch.equal(y, y2)
+    else:
+        assert (y - y2).abs().max() <= 4e-3 * y2.abs().max()
+    # greedy decode through HF's generate on the prepared model == on the plain swap
+    with torch.inference_mode():
+        t1 = model3.generate(ids, min_new_tokens=6, max_new_tokens=6, do_sample=False, num_beams=1)
+        t2 = model2.generate(ids, min_new_tokens=6, max_new_tokens=6, do_sample=False, num_beams=1)
+    assert torch.equal(t1, t2)
 
 
 def test_deferred_norm_that_is_not_consumed_raises():
