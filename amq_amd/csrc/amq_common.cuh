@@ -336,17 +336,22 @@ __device__ __forceinline__ void dequant_lane_g(const uint32_t* w, const MetaG<GP
     }
 }
 // dequant_lane_sd with per-pair meta (the matmul kernels' form, bit-identical to dequant_lane_g under dequant_lane_sd's conditions)
-template <int BITS, int MODE, int GP, int P>
-__device__ __forceinline__ void dequant_sd_g_step(const uint32_t* w, const SdMeta (&m)[GP], h2* out) {
-    out[P] = dequant_pair_sd<BITS, MODE, P>(w, m[meta_sub<GP>(P)]);
-    if constexpr (P + 1 < 16) dequant_sd_g_step<BITS, MODE, GP, P + 1>(w, m, out);
+template <int BITS, int MODE, int P, int PEND>
+__device__ __forceinline__ void dequant_sd_g_range(const uint32_t* w, const SdMeta& m, h2* out) {
+    out[P] = dequant_pair_sd<BITS, MODE, P>(w, m);
+    if constexpr (P + 1 < PEND) dequant_sd_g_range<BITS, MODE, P + 1, PEND>(w, m, out);
+}
+template <int BITS, int MODE, int GP, int S>
+__device__ __forceinline__ void dequant_sd_g_sub(const uint32_t* w, const MetaG<GP>& meta, h2* out) {
+    // the 16 / GP register pairs of sub-group S, with ITS scaled (scale, zero) only live meanwhile
+    const SdMeta m = sd_meta<BITS, MODE>(meta.p[S]);
+    dequant_sd_g_range<BITS, MODE, S * (16 / GP), (S + 1) * (16 / GP)>(w, m, out);
+    if constexpr (S + 1 < GP) dequant_sd_g_sub<BITS, MODE, GP, S + 1>(w, meta, out);
 }
 template <int BITS, int MODE, int GP>
 __device__ __forceinline__ void dequant_lane_sd_g(const uint32_t* w, const MetaG<GP>& meta, h2* out) {
-    SdMeta m[GP];
-#pragma unroll
-    for (int s = 0; s < GP; ++s) m[s] = sd_meta<BITS, MODE>(meta.p[s]);
-    dequant_sd_g_step<BITS, MODE, GP, 0>(w, m, out);
+    static_assert(meta_sub<GP>(16 / GP - 1) == 0 && meta_sub<GP>(16 / GP) == 1 % GP, "pairs of a sub-group are consecutive");
+    dequant_sd_g_sub<BITS, MODE, GP, 0>(w, meta, out);
 }
 
 

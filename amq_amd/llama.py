@@ -68,6 +68,7 @@ class QuantLlama:
     # 755 vs 830 tokens/s (profiles/r03_qkv_attn_fused_negative.txt) -- so it is off unless a caller sets fuse_qkv_attn.
     FUSE_QKV_ATTN = False
     ENGINE_DEFAULT = False      # what engine=None means (the engine is opt-in until it beats the five-launch step: DESIGN.md 4)
+    fine = False                # any layer with groups of 64 / 32 (set by __init__)
 
     def __init__(self, config, arch_linear=None, device="cuda:0", max_seq=256, seed=0, synthetic=True,
                  hqq_layers=None, dense=None, batch=1, engine=None, prebuilt=None):
@@ -136,6 +137,13 @@ class QuantLlama:
             self.lm_head = (torch.randn(self.vocab, self.H, device=dev, generator=gen) / math.sqrt(self.H)).to(torch.float16)
             self.norm = (1.0 + 0.05 * torch.randn(self.H, device=dev, generator=gen)).to(torch.float16)
 
+        # layers with groups of 64 / 32 (HQQ's default group_size is 64): the decode step is the same five launches (amq_gemv_grouped_f16 takes the
+        # group size); the prompt pass leaves the fragment-ordered few-row kernels alone (they read one (scale, zero) pair per tile) and runs
+        # dequantize-once + the fp16 GEMM per linear; the A/B step forms are not offered
+        self.fine = any(blk[n].mn.numel() != ops.native_sizes(blk[n].bits, blk[n].N, blk[n].K)[1] // 2 for blk in self.blocks for n in config["linear"])
+        if self.fine and engine:
+            raise ValueError("the decode engine serves groups of 128")
+
         f16 = dict(dtype=torch.float16, device=dev)
         B = self.B
         self.x = torch.zeros(B, self.H, **f16)
@@ -155,10 +163,10 @@ class QuantLlama:
         self.graph = None
         self.host_pos = 0          # host mirror of self.pos (decode_step refuses to run past the cache without a device sync)
         self._down_rows_fit = self.B <= ops.gemv_max_rows(self.I)
-        self.can_fuse_qkv_attn = self.B == 1 and max_seq <= ops.ATTN_SPLIT_FROM and self.H <= 8192
+        self.can_fuse_qkv_attn = self.B == 1 and max_seq <= ops.ATTN_SPLIT_FROM and self.H <= 8192 and not self.fine
         self.fuse_qkv_attn = self.FUSE_QKV_ATTN and self.can_fuse_qkv_attn
         self._tickets = torch.zeros(max(self.nh, 64), dtype=torch.int32, device=dev)
-        eligible = self.B == 1 and max_seq <= self.ENGINE_MAX_SEQ and self.H == self.nh * 128
+        eligible = self.B == 1 and max_seq <= self.ENGINE_MAX_SEQ and self.H == self.nh * 128 and not self.fine
         if engine and not eligible:
             raise ValueError("the decode engine needs batch 1 and max_seq <= %d" % self.ENGINE_MAX_SEQ)
         self.engine = None
@@ -441,7 +449,7 @@ class QuantLlama:
         # up to 256 rows the projections that read a normed / attention activation take it in fragment order (written
         # that way by the producing launch): 1.2-1.6x faster few-row GEMMs; down_proj (K = 11008: the
         # per-workgroup x stream is what bounds that kernel) and longer prompts stay on the tiled kernel
-        frag = self.FRAG_ROWS[0] < S <= self.FRAG_ROWS[1]
+        frag = self.FRAG_ROWS[0] < S <= self.FRAG_ROWS[1] and not self.fine
         for blk in self.blocks:
             if frag:
                 h = ops.rmsnorm_xfrag(x, blk["ln1"], self.eps)

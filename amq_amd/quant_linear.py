@@ -204,6 +204,7 @@ class HIPRMSNorm(nn.Module):
 
 class HIPQuantLinear(nn.Module):
     QUANT_TYPE = "hip-amq-t16"
+    native_group = GROUP        # (instances set their own; the class default covers modules unpickled from before groups of 64 / 32 existed)
 
     def __init__(self, bits, group_size, infeatures, outfeatures, bias=False, name=None,
                  mode=ops.MODE_HQQ, weight_dtype=torch.float16):

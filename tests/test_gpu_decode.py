@@ -481,6 +481,51 @@ def test_speed_benchmark_cli_with_reference_checkpoints(tmp_path, monkeypatch):
                               "--seq_length", "8", "--gen_length", "4", "--target_bits", "3.0", "--arch_path", str(stats)])
 
 
+@pytest.mark.parametrize("group", [64, 32])
+def test_runner_over_finer_group_layers(group):
+    """the hipGraph runner over HQQ layers quantized with groups of 64 / 32: prompt pass (9 rows: GEMV kernel; 40 rows: dequantize-once + the
+    fp16 GEMM per linear, not the fragment-ordered few-row kernels) and decode steps (the same five launches per block) against the fp16 runner
+    on the oracle-exact dequantized weights; graph and eager forms agree bit for bit"""
+    from amq_amd import arch, ops
+    from amq_amd.hqq_format import random_hqq
+    from amq_amd.llama import QuantLlama, DenseLlama
+    cfg = dict(arch._cfg(2, 512, 1024, 4, 2, 1, vocab=1024))
+    bits = dict(zip(cfg["linear"], [4, 2, 3, 3, 2, 4, 3]))
+    al = {name: [b, b] for name, b in bits.items()}
+    layers = {(blk, name): random_hqq(*cfg["linear_shape"][name], bits[name], seed=17 * blk + i, group=group)
+              for blk in range(2) for i, name in enumerate(cfg["linear"])}
+    m = QuantLlama(cfg, al, device="cuda:0", max_seq=64, hqq_layers=layers, seed=3)
+    assert m.fine and m.engine is None
+    d = DenseLlama(cfg, device="cuda:0", max_seq=64, seed=3)
+    for b in range(2):
+        for name in cfg["linear"]:
+            l = m.blocks[b][name]
+            d.blocks[b][name] = ops.dequantize(l.qn, l.mn, l.bits, l.mode, l.N, l.K)
+        d.blocks[b]["ln1"], d.blocks[b]["ln2"] = m.blocks[b]["ln1"], m.blocks[b]["ln2"]
+    d.embed, d.lm_head, d.norm = m.embed, m.lm_head, m.norm
+    for S in (9, 40):
+        ids = torch.randint(0, 1024, (S,), generator=torch.Generator().manual_seed(S)).to(_dev())
+        m.reset(); d.reset()
+        lg = m.prefill(ids, use_graph=False).float().clone()
+        ld = d.prefill(ids, use_graph=False).float().clone()
+        assert torch.isfinite(lg).all() and (lg - ld).abs().max() <= 1e-2 * ld.abs().max()
+        m.decode_step(use_graph=False); d.decode_step(use_graph=False)          # one decode step each (same next token unless the argmax is a near-tie)
+        if int(m.token.item()) == int(d.token.item()):
+            m.decode_step(use_graph=False); d.decode_step(use_graph=False)
+            assert (m.logits.float() - d.logits.float()).abs().max() <= 1e-2 * d.logits.float().abs().max()
+        m.reset()
+        lg2 = m.prefill(ids, use_graph=True).float().clone()
+        assert torch.equal(lg2, lg)
+        toks = []
+        for _ in range(4):
+            m.decode_step(); toks.append(int(m.token.item()))
+        m.reset(); m.prefill(ids, use_graph=False)
+        toks2 = []
+        for _ in range(4):
+            m.decode_step(use_graph=False); toks2.append(int(m.token.item()))
+        assert toks == toks2
+
+
 @pytest.mark.parametrize("gqa", [False, True])
 def test_prefill_batch_matches_single_sequence_passes(gqa):
     """the batched prompt pass (GeMM mode at batch_size > 1) gives each sequence the logits of its own single-sequence pass"""
