@@ -654,8 +654,14 @@ struct GemvPre {            // not a kernel parameter type: just names the 14 dw
     int K, m_nseg, rpt, n_rt0, key0; float eps;
 };
 
+// (groups of 64 on 8-wave workgroups: the allocator is held to the three-workgroups-per-CU budget, 80 VGPRs -- left alone it takes 90-96 for the second
+//  meta pair and the launch runs at five waves per SIMD: 7B avg-3 decode 732 -> 773 tokens/s with the bound (5 spilled dwords); at groups of 32 the
+//  bound costs more than the sixth wave brings, 709 -> 689, so those keep the free allocation.  profiles/r04_fine_groups.txt)
+#ifndef AMQ_LB_WAVES_G
+#define AMQ_LB_WAVES_G(NW_, GP_) (((GP_) == 2 && (NW_) == 8) ? 6 : AMQ_LB_WAVES(NW_))
+#endif
 template <int PRO, int NW, int U, int MATH, int XCH, int RS = 256, int GP = 1>
-__global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES(NW)) void gemv_kernel(const void* p_x, const void* p_xw, const void* p_qw0,
+__global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_G(NW, GP)) void gemv_kernel(const void* p_x, const void* p_xw, const void* p_qw0,
                                                                      const void* p_mt0, int p_K, int p_m_nseg, int p_rpt,
                                                                      int p_n_rt0, int p_key0, float p_eps, GemvKArgs blk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

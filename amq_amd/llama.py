@@ -44,10 +44,10 @@ class _Lin:
         return self.qn.numel() * 4 + self.mn.numel() * 2
 
 
-def _synthetic_linear(n, k, bits, gen, device):
+def _synthetic_linear(n, k, bits, gen, device, group=128):
     """Random native payload + (scale, zero) giving roughly unit-gain layers:
-    any bit pattern is a valid weight matrix in the native layout."""
-    qb, mb = ops.native_sizes(bits, n, k)
+    any bit pattern is a valid weight matrix in the native layout (group: 128, or 64 / 32 = two / four pairs per tile row)."""
+    qb, mb = ops.native_sizes(bits, n, k, group)
     qn = torch.randint(-2 ** 31, 2 ** 31 - 1, (qb // 4,), dtype=torch.int32, device=device, generator=gen)
     std_q = math.sqrt((4.0 ** bits - 1.0) / 12.0)
     s0 = 0.5 / (math.sqrt(k) * std_q)
@@ -71,12 +71,13 @@ class QuantLlama:
     fine = False                # any layer with groups of 64 / 32 (set by __init__)
 
     def __init__(self, config, arch_linear=None, device="cuda:0", max_seq=256, seed=0, synthetic=True,
-                 hqq_layers=None, dense=None, batch=1, engine=None, prebuilt=None):
+                 hqq_layers=None, dense=None, batch=1, engine=None, prebuilt=None, group=128):
         """config: an entry of arch.MODEL_CONFIGS (or its name).
         arch_linear: {'self_attn.q_proj': [bits]*n_block, ...}; default uniform 4.
         hqq_layers: {(block, name): HQQWeights} real quantized layers (else synthetic).
         dense: {'embed','lm_head','norm','ln1'[n_block],'ln2'[n_block]} fp16 tensors (else synthetic).
         prebuilt: {(block, name): _Lin} linears already in the native layout (from_hf: shared with the modules that own them).
+        group: group size of the SYNTHETIC layers (128; 64 / 32: see ``fine``).
         batch: sequences decoded together, 1 .. 8 (same prompt length; one step = the same launches with ``batch`` rows: the
         weights are streamed once per step for all of them).  batch = 1 is the reference's FT configuration."""
         if isinstance(config, str):
@@ -117,7 +118,7 @@ class QuantLlama:
                 return _Lin(qn, mn, bits, ops.MODE_HQQ, n, k)
             if not synthetic:
                 raise ValueError("no weights given")
-            return _synthetic_linear(n, k, bits, gen, dev)
+            return _synthetic_linear(n, k, bits, gen, dev, group)
 
         self.blocks = []
         for b in range(self.nb):

@@ -38,7 +38,11 @@ for name, bits, uniform in cases:
         a, usage = arch.uniform_arch(cfg, int(bits)), bits + 0.25
     else:
         a, usage = arch.synthesize_arch(cfg, bits, seed=0, pinned=arch.PINNED_7B if "7b" in name else ())
-    m = QuantLlama(cfg, a["linear"], device=dev, max_seq=64 + steps + 24, seed=0)
+    group = int(os.environ.get("DECODE_GROUP", "128"))          # 64 / 32: layers with two / four (scale, zero) pairs per tile row
+    m = QuantLlama(cfg, a["linear"], device=dev, max_seq=64 + steps + 24, seed=0, group=group)
+    if group != 128:
+        name += f" group {group}"
+        usage += 4.0 * (1.0 / group - 1.0 / 128) * 8
     if "awq-import" in name:
         awq_import(m)
     ids = torch.randint(0, m.vocab - 1, (64,), generator=torch.Generator().manual_seed(0)).to(dev)
