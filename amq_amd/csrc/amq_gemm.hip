@@ -203,10 +203,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, con
 // 11008x4096  M=32 18.0|21.1  64 33.0|24.0;  4096x11008  M=32 18.0|19.8  64 29.9|20.9.
 constexpr int GEMM_SKINNY_MAX = 32;      // rows up to which launch_gemm (GEMM_ROUTE_AUTO) always takes this kernel
 
-template <int BITS, int MB, int NSUB>
-struct SkinnyTile { h8 xr[MB * 4]; LanePayload<BITS> pay[NSUB]; h2 meta[NSUB]; };
+// GP: (scale, zero) pairs per (row, tile) = 128 / group (amq_common.cuh); 2 / 4 only in the row-major form (XF = false)
+template <int GP> struct SkinnyMeta { typedef MetaG<GP> type; };
+template <> struct SkinnyMeta<1> { typedef h2 type; };
+template <int BITS, int MB, int NSUB, int GP = 1>
+struct SkinnyTile { h8 xr[MB * 4]; LanePayload<BITS> pay[NSUB]; typename SkinnyMeta<GP>::type meta[NSUB]; };
 
-template <int BITS, int MODE, int MB, int NSUB, int D, int NWV, bool XF>
+template <int BITS, int MODE, int MB, int NSUB, int D, int NWV, bool XF, int GP = 1>
 __device__ __forceinline__ void skinny_body(const GemmArgs& a, int bx, unsigned char* smem) {
     // per-wave transpose scratch (16*MB rows x 256 B, XOR-swizzled like the tiled kernel's x tiles); reused for the
     // cross-wave sum after the K loop
@@ -243,8 +246,8 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& a, int bx, unsigned 
 #pragma unroll
         for (int nb = 0; nb < NSUB; ++nb) acc[mb][nb] = (f4){0, 0, 0, 0};
 
-    SkinnyTile<BITS, MB, NSUB> ring[D];
-    auto load = [&](SkinnyTile<BITS, MB, NSUB>& T, int kt) {
+    SkinnyTile<BITS, MB, NSUB, GP> ring[D];
+    auto load = [&](SkinnyTile<BITS, MB, NSUB, GP>& T, int kt) {
         const bool valid = kt < G;
         const int ktc = valid ? kt : G - 1;
 #pragma unroll
@@ -253,8 +256,17 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& a, int bx, unsigned 
             const uint32_t* p = qw + tile * 64 * BITS + lane * BITS;
 #pragma unroll
             for (int d = 0; d < BITS; ++d) T.pay[nb].w[d] = p[d];
-            const h2 mv = mt[tile * 16 + r];
-            T.meta[nb] = valid ? mv : (h2){(_Float16)0.f, (_Float16)0.f};
+            if constexpr (GP == 1) {
+                const h2 mv = mt[tile * 16 + r];
+                T.meta[nb] = valid ? mv : (h2){(_Float16)0.f, (_Float16)0.f};
+            } else {
+                const h2* mp = mt + (tile * 16 + r) * GP;
+#pragma unroll
+                for (int s_ = 0; s_ < GP; ++s_) {
+                    const h2 mv = mp[s_];
+                    T.meta[nb].p[s_] = valid ? mv : (h2){(_Float16)0.f, (_Float16)0.f};
+                }
+            }
         }
         if (XF) {       // fragment-ordered x (amq_xfrag_f16): instruction j = mb*4 + t is one contiguous KiB, already an A operand
             const _Float16* xt = x + ((size_t)blockIdx.y * G + ktc) * (64 * 128) + lane * 8;
@@ -265,10 +277,13 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& a, int bx, unsigned 
             for (int j = 0; j < MB * 4; ++j) T.xr[j] = *(const h8*)(x + (size_t)xoff[j] + ktc * 128);
         }
     };
-    auto compute = [&](const SkinnyTile<BITS, MB, NSUB>& T) {
+    auto compute = [&](const SkinnyTile<BITS, MB, NSUB, GP>& T) {
         h2 wv[NSUB][16];
 #pragma unroll
-        for (int nb = 0; nb < NSUB; ++nb) dequant_lane_sd<BITS, MODE>(T.pay[nb].w, T.meta[nb], wv[nb]);
+        for (int nb = 0; nb < NSUB; ++nb) {
+            if constexpr (GP == 1) dequant_lane_sd<BITS, MODE>(T.pay[nb].w, T.meta[nb], wv[nb]);
+            else dequant_lane_sd_g<BITS, MODE, GP>(T.pay[nb].w, T.meta[nb], wv[nb]);
+        }
         if (!XF) {
 #pragma unroll
             for (int j = 0; j < MB * 4; ++j) {
@@ -346,10 +361,10 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& a, int bx, unsigned 
     }
 }
 
-template <int BITS, int MODE, int MB, int NSUB, int D, int NWV, bool XF>
+template <int BITS, int MODE, int MB, int NSUB, int D, int NWV, bool XF, int GP = 1>
 __global__ __launch_bounds__(NWV * 64) void gemm_skinny_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    skinny_body<BITS, MODE, MB, NSUB, D, NWV, XF>(a, (int)blockIdx.x, smem);
+    skinny_body<BITS, MODE, MB, NSUB, D, NWV, XF, GP>(a, (int)blockIdx.x, smem);
 }
 
 // Several linears that consume the same fragment-ordered x (q/k/v, gate/up of a prompt pass), each with its own bit-width, as
@@ -418,7 +433,7 @@ hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg
     return skinny_grouped_launch<4>(xf, M, K, sg, wg, st);
 }
 
-template <int BITS, int MODE, int MB>
+template <int BITS, int MODE, int MB, int GP = 1>
 static hipError_t skinny_launch_mb(const GemmArgs& a, hipStream_t st) {
     StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     // 8 waves split K (two per SIMD overlap each other's fetch / transpose / unpack / MFMA phases: 16.2 -> 12.8 us at
@@ -427,7 +442,7 @@ static hipError_t skinny_launch_mb(const GemmArgs& a, hipStream_t st) {
     constexpr int LDS = NWV * MB * 16 * 128 * 2;
     const int nblk = a.N >> 4;
     const int ny = (a.M + 16 * MB - 1) / (16 * MB);
-    auto k = gemm_skinny_kernel<BITS, MODE, MB, 1, 2, NWV, false>;
+    auto k = gemm_skinny_kernel<BITS, MODE, MB, 1, 2, NWV, false, GP>;
     if (LDS > 64 * 1024) {
         static unsigned long long attr_done = 0;
         const hipError_t attr = ensure_dyn_lds(attr_done, (const void*)k, LDS);
@@ -503,6 +518,30 @@ static hipError_t skinny_launch(const GemmArgs& a, hipStream_t st) {
     if (a.M <= 16) return skinny_launch_mb<BITS, MODE, 1>(a, st);
     if (a.M <= 32) return skinny_launch_mb<BITS, MODE, 2>(a, st);
     return skinny_launch_mb<BITS, MODE, 4>(a, st);
+}
+
+// Groups of 64 / 32 (two / four meta pairs per tile row): the few-row kernel is their only FUSED GEMM.  It serves any number of rows
+// (grid.y blocks of 64 rows, each streaming the packed weights once), and up to FINE_SKINNY_MAX_ROWS that beats dequantize-once + the
+// 256 x 256-tile fp16 GEMM, which leaves the chip idle at such sizes (7B shapes, 64 rows: ~100 us per linear; profiles/r04_fine_groups.txt)
+constexpr int FINE_SKINNY_MAX_ROWS = 256;
+bool gemm_fine_takes_skinny(int M) { return M <= FINE_SKINNY_MAX_ROWS; }
+
+template <int BITS, int MODE, int GP>
+static hipError_t skinny_launch_g(const GemmArgs& a, hipStream_t st) {
+    if (a.M <= 16) return skinny_launch_mb<BITS, MODE, 1, GP>(a, st);
+    if (a.M <= 32) return skinny_launch_mb<BITS, MODE, 2, GP>(a, st);
+    return skinny_launch_mb<BITS, MODE, 4, GP>(a, st);
+}
+template <int GP>
+static hipError_t skinny_launch_fine(const GemmArgs& a, hipStream_t st) {
+    if (a.mode == MODE_HQQ) {
+        if (a.bits == 4) return skinny_launch_g<4, MODE_HQQ, GP>(a, st);
+        if (a.bits == 3) return skinny_launch_g<3, MODE_HQQ, GP>(a, st);
+        return skinny_launch_g<2, MODE_HQQ, GP>(a, st);
+    }
+    if (a.bits == 4) return skinny_launch_g<4, MODE_FMA, GP>(a, st);
+    if (a.bits == 3) return skinny_launch_g<3, MODE_FMA, GP>(a, st);
+    return skinny_launch_g<2, MODE_FMA, GP>(a, st);
 }
 
 // up to g_gemm_skinny_max rows always; up to twice that while the column blocks fit one round of workgroups and K is
@@ -587,8 +626,9 @@ bool gemm_takes_deq(int M, int N, int K) {
 
 // the dequantize-once route: forced, or AUTO's choice -- either way only with a scratch for the fp16 weights and without split-K
 static bool gemm_runs_deq(const GemmArgs& a, int route) {
+    if (a.gp > 1 && route != GEMM_ROUTE_DEQ && gemm_fine_takes_skinny(a.M)) return false;      // groups of 64 / 32, few rows: the GP-aware few-row kernel
     if (!a.w16 || a.splits > 1 || !gemm_f16w_ok(a.M, a.N, a.K, a.x_stride, a.y_stride)) return false;
-    if (a.gp > 1) return true;                             // groups of 64 / 32: the only many-row route (the fused kernels read one meta pair per tile)
+    if (a.gp > 1) return true;                             // ... more rows: the only route (the other fused kernels read one meta pair per tile)
     return route == GEMM_ROUTE_DEQ || (route == GEMM_ROUTE_AUTO && gemm_takes_deq(a.M, a.N, a.K));
 }
 
@@ -598,6 +638,7 @@ static bool gemm_runs_deq(const GemmArgs& a, int route) {
 bool gemm_gate_fused(const GemmArgs& a, int route) {
     const bool ring = (route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128 || route == GEMM_ROUTE_WS ||
                        (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K))) && gemm_ring_ok(a);
+    if (a.gp > 1) return true;                             // groups of 64 / 32: few-row kernel or dequantize-once route, both apply it
     return ring || gemm_is_skinny(a.M, a.N, a.K, route) || gemm_runs_deq(a, route);
 }
 
@@ -616,7 +657,11 @@ static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int rout
         if (hipError_t e = launch_dequantize(a.bits, a.mode, a.qweight, a.meta, a.N, a.K, a.w16, st, a.gp > 1 ? a.gp : 1)) return e;
         return launch_gemm_f16w(a.x, a.w16, a.bias, a.residual, a.gate, a.y, a.M, a.N, a.K, a.x_stride, a.y_stride, st);
     }
-    if (a.gp > 1) return hipErrorInvalidValue;             // (amq_capi.hip refuses such a call with its reason before it gets here)
+    if (a.gp > 1) {
+        if ((route == GEMM_ROUTE_AUTO || route == GEMM_ROUTE_SKINNY) && gemm_fine_takes_skinny(a.M))
+            return a.gp == 2 ? skinny_launch_fine<2>(a, st) : skinny_launch_fine<4>(a, st);
+        return hipErrorInvalidValue;                       // (amq_capi.hip refuses such a call with its reason before it gets here)
+    }
     if (route == GEMM_ROUTE_RING && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
     if (route == GEMM_ROUTE_RING128 && gemm_ring_ok(a)) return launch_gemm_ring(a, st, 128);
     if (route == GEMM_ROUTE_WS && gemm_ring_ok(a)) return launch_gemm_ws(a, st);

@@ -198,8 +198,8 @@ def test_coarser_groups_are_read_bit_exact(bits, n, k, group):
 def test_finer_groups(bits, group, n, k):
     """groups of 64 / 32 (128 / group (scale, zero) pairs per native tile row): repack from all three source formats -> dequantize == the
     oracle's dequant of the same buffers, bit for bit; the standalone HQQ dequant too; the GEMV kernel (1 / 3 / 16 rows, bias, the fused
-    RMSNorm and SiLU-mul prologues, residual, grouped segments) and the dequantize-once GEMM (17 / 300 rows, bias / residual / gate)
-    within the output tolerance; the module; entry points that read one pair per tile refuse them"""
+    RMSNorm and SiLU-mul prologues, residual, grouped segments), the few-row GEMM (17 / 100 rows) and the dequantize-once GEMM (300 rows; bias /
+    residual / gate) within the output tolerance; the module; entry points that read one pair per tile refuse them"""
     from amq_amd import ops
     from amq_amd.hqq_format import random_hqq
     from amq_amd.quant_linear import HIPQuantLinear
@@ -236,14 +236,21 @@ def test_finer_groups(bits, group, n, k):
     ops.gemv_grouped(x.to(dev), [dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_HQQ, N=n, y=y2)], k, prologue=ops.PRO_SILU_MUL, x2=up.to(dev))
     act = ops.silu_mul(x.to(dev).reshape(-1), up.to(dev).reshape(-1)).reshape(2, k).cpu()
     _assert_close(y2.cpu().numpy(), linear_ref.linear_f16(act.numpy(), w_ref), f"silu-mul prologue, group {group}")
-    # many rows: dequantize once + the fp16 GEMM (the only many-row route of these groups)
-    for m in (17, 300):
+    # more rows: the pair-aware few-row kernel up to 256 rows (grid.y blocks of 64), beyond it dequantize once + the fp16 GEMM
+    for m in (17, 100, 300):
         x = torch.randn(m, k, generator=gen).to(torch.float16)
         y0 = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k)
         _assert_close(y0.cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref), f"gemm M={m}, group {group}")
         y = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias.to(dev))
         assert torch.equal(y, y0 + bias.to(dev))                   # fp16(x . W^T), then the bias as a separate fp16 add (the unfused reference's roundings)
-        assert torch.equal(y, ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias.to(dev), route=ops.GEMM_DEQ))
+        yd = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias.to(dev), route=ops.GEMM_DEQ)
+        if m > 256:
+            assert torch.equal(y, yd)                                  # AUTO is the dequantize-once route there
+        else:                                                          # few rows: the pair-aware few-row kernel; same weights, another summation order
+            yd0 = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, route=ops.GEMM_DEQ)
+            _assert_close(yd0.cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref), f"gemm DEQ M={m}, group {group}")
+            assert torch.equal(yd, yd0 + bias.to(dev))
+            assert torch.equal(y, ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias.to(dev), route=ops.GEMM_SKINNY))
         r = torch.randn(m, n, generator=gen).to(torch.float16)
         yr = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, k, bias=bias.to(dev), residual=r.to(dev))
         assert torch.equal(yr.cpu(), (r.float() + torch.from_numpy(y.cpu().numpy()).float()).to(torch.float16))

@@ -161,8 +161,8 @@ FINE_CASES = sorted(glob.glob(os.path.join(GOLDEN, "hqq_g64_b*.npz")) + glob.glo
 @pytest.mark.parametrize("path", FINE_CASES, ids=[os.path.basename(c) for c in FINE_CASES])
 def test_reference_ffi_shaped_gptq_call_with_finer_groups(path):
     """vecquant{2,3,4}matmul_faster_old takes any groupsize (auto_gptq_kernel.cu:203: g = k / groupsize): the reference's own GPTQLinear
-    buffers of its group-64 / group-32 layers through amq_vecquantmatmul_faster_old, up to the GEMV kernel's 16 rows; more rows are
-    refused with the way out in the message (this call carries no workspace for the dequantized weights)"""
+    buffers of its group-64 / group-32 layers through amq_vecquantmatmul_faster_old: the GEMV kernel up to 8 rows, the pair-aware few-row
+    GEMM up to 256; more rows are refused with the way out in the message (this call carries no workspace for the dequantized weights)"""
     import ctypes
     from amq_amd import _lib
     from oracle import gptq_ref
@@ -174,7 +174,7 @@ def test_reference_ffi_shaped_gptq_call_with_finer_groups(path):
     st = _lib.current_stream()
     qw, sc, zr = t(g["gptq_qweight"]), t(g["gptq_scales"]), t(g["gptq_zeros"])
     w = gptq_ref.dequant_kernel(g["gptq_qweight"], g["gptq_scales"], g["gptq_zeros"], bits, G)
-    for m in (1, 5, 16):
+    for m in (1, 5, 16, 40, 128):
         x = t(g["gptq_x"][:m])
         ws = torch.empty(lib.amq_compat_workspace_bytes(bits, m, n, k), dtype=torch.uint8, device=_dev())
         mul = torch.full((m, n), 0.5, dtype=torch.float32, device=_dev())
@@ -183,10 +183,10 @@ def test_reference_ffi_shaped_gptq_call_with_finer_groups(path):
                                                          qw.shape[0], n, vp(ws), ws.numel(), valid, st))
         ref = linear_ref.linear_f16(g["gptq_x"][:m], w).astype(np.float32)
         assert np.all(np.abs(mul.cpu().numpy() - (0.5 + 2 * ref)) <= 2e-3 * np.abs(ref) + 2e-3 * np.sqrt(np.mean(ref ** 2)))
-    x = t(g["gptq_x"][:40])
-    ws = torch.empty(lib.amq_compat_workspace_bytes(bits, 40, n, k), dtype=torch.uint8, device=_dev())
-    mul = torch.zeros(40, n, dtype=torch.float32, device=_dev())
-    assert lib.amq_vecquantmatmul_faster_old(bits, vp(x), vp(qw), vp(mul), vp(sc), vp(zr), G, k // 2, 40, qw.shape[0], n,
+    x = torch.zeros(300, k, dtype=torch.float16, device=_dev())
+    ws = torch.empty(lib.amq_compat_workspace_bytes(bits, 300, n, k), dtype=torch.uint8, device=_dev())
+    mul = torch.zeros(300, n, dtype=torch.float32, device=_dev())
+    assert lib.amq_vecquantmatmul_faster_old(bits, vp(x), vp(qw), vp(mul), vp(sc), vp(zr), G, k // 2, 300, qw.shape[0], n,
                                              vp(ws), ws.numel(), 0, st) == -2
     assert b"amq_gemm_route_f16" in lib.amq_last_error()
 
