@@ -1,5 +1,6 @@
+"""few-row GEMM launches over a layer quantized with groups of 128 / 64: what ops.gemm runs (auto) against dequantize-once forced (profiles/r04_fine_groups.txt)"""
 import sys, os, torch, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from amq_amd import ops
 from amq_amd.hqq_format import random_hqq
 dev = torch.device("cuda:0")
