@@ -72,7 +72,7 @@ def quantize_rtn(W: torch.Tensor, nbits: int, group_size: int = GROUP, bias=None
     quantize.py:106-155).  Not the HQQ optimizer -- accuracy is irrelevant to
     the speed path, only the format and value ranges matter."""
     if group_size not in (64, 32) and (group_size < GROUP or group_size % GROUP):
-        raise ValueError("group size must be a multiple of 128")
+        raise ValueError("group size must be 32, 64 or a multiple of 128")
     n, k = W.shape
     wg = W.float().reshape(-1, group_size)
     mn = wg.min(dim=1, keepdim=True)[0]

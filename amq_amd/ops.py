@@ -236,7 +236,7 @@ def _dequant_scratch(device, numel):
 
 def _route_workspace(lib, device, route, M, N, K, group=GROUP):
     """(tensor or None, bytes) for ``amq_gemm_route_f16`` / ``amq_gemm_gated_f16``: split-K partials for few rows, the dequantized
-    fp16 weights for the dequantize-once route (GEMM_DEQ, GEMM_AUTO on MFMA-bound launches, and every launch over groups of 64 / 32)."""
+    fp16 weights for the dequantize-once route (GEMM_DEQ, GEMM_AUTO on MFMA-bound launches, and launches of more than 256 rows over groups of 64 / 32)."""
     need = lib.amq_gemm_route_workspace_bytes_g(route, M, N, K, group)
     if not need:
         return None, 0
@@ -407,7 +407,7 @@ def linear(x, qn, mn, bits, mode, N, K, bias=None):
     M = x2.shape[0]
     if bias is not None:
         _need(bias, torch.float16, "bias", N)
-    if group != GROUP and M > 0:    # groups of 64 / 32: the GEMV kernel as far as it reaches (16 rows), then dequantize once + the fp16 GEMM
+    if group != GROUP and M > 0:    # groups of 64 / 32: the GEMV kernel as far as it reaches (16 rows), then gemm (few-row kernel up to 256 rows, dequantize once + the fp16 GEMM beyond)
         if M <= gemv_max_rows(K):
             return gemv(x, qn, mn, bits, mode, N, K, bias=bias)
         return gemm(x, qn, mn, bits, mode, N, K, bias=bias)
