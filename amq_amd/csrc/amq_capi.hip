@@ -166,8 +166,7 @@ int amq_gemv_f16(int bits, int mode, const void* x, const void* qn, const void* 
 
 int amq_gemm_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
                  int M, int N, int K, int group, int x_stride, int y_stride, void* stream) {
-    const bool fine = group == 64 || group == 32;       // groups of 64 / 32: the few-row kernel as far as it is their route (no workspace here for more rows)
-    if (int rc = (fine && M >= 1 && amq::gemm_fine_takes_skinny(M)) ? check_shape(bits, N, K, group) : check_shape128(bits, N, K, group, "amq_gemm_f16 beyond 256 rows")) return rc;
+    if (int rc = check_shape(bits, N, K, group)) return rc;          // (groups of 64 / 32: the few-row or the tiled kernel -- no workspace here, so never dequantize-once)
     if (int rc = check_mode(mode)) return rc;
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
@@ -198,27 +197,28 @@ int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qn, const
 
 // the workspace of a route call holds the dequantized fp16 weights (dequantize-once route) or the split-K partials, never both
 static bool route_is_deq(int route, int M, int N, int K, int group = 128) {
-    if (group == 64 || group == 32)       // few rows: the GP-aware few-row kernel; beyond: their only route
-        return route == AMQ_GEMM_DEQ || (route == AMQ_GEMM_AUTO && !amq::gemm_fine_takes_skinny(M));
+    if (group == 64 || group == 32)       // few rows: the pair-aware few-row kernel; then the tiled kernel; launches that fill 256 x 256 tiles: dequantize-once
+        return route == AMQ_GEMM_DEQ || (route == AMQ_GEMM_AUTO && amq::gemm_fine_takes_deq(M, N, K));
     return route == AMQ_GEMM_DEQ || (route == AMQ_GEMM_AUTO && amq::gemm_takes_deq(M, N, K));
 }
 
 size_t amq_gemm_route_workspace_bytes_g(int route, int M, int N, int K, int group) {
     if (M < 1 || N < 1 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_DEQ) return 0;
     if (route_is_deq(route, M, N, K, group)) return (size_t)N * (size_t)K * 2;       // the dequantized fp16 weights
-    if (group == 64 || group == 32) return 0;                                         // (their few-row kernel takes no workspace)
-    const int s = amq::gemm_pick_splits(M, N, K, route);
+    if ((group == 64 || group == 32) && amq::gemm_fine_takes_skinny(M)) return 0;     // (their few-row kernel takes no workspace)
+    const int s = amq::gemm_pick_splits(M, N, K, (group == 64 || group == 32) && route == AMQ_GEMM_AUTO ? (int)AMQ_GEMM_TILED : route);
     return s > 1 ? (size_t)s * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K) { return amq_gemm_route_workspace_bytes_g(route, M, N, K, 128); }
 
-// groups of 64 / 32 on a route call: the few-row kernel (AUTO / SKINNY, no workspace) up to gemm_fine_takes_skinny rows, else AUTO or DEQ with the workspace
-static int check_fine_route(int route, int group, int M, const void* workspace) {
+// groups of 64 / 32 on a route call: the few-row kernel (AUTO / SKINNY) up to gemm_fine_takes_skinny rows, the tiled kernel (AUTO / TILED) or
+// dequantize-once (AUTO where it fills the chip, given the workspace; DEQ) beyond; the ring / wave-specialised kernels read one pair per tile
+static int check_fine_route(int route, int group, int M, int N, int K, const void* workspace) {
     if (group != 64 && group != 32) return AMQ_OK;
-    if ((route == AMQ_GEMM_AUTO || route == AMQ_GEMM_SKINNY) && amq::gemm_fine_takes_skinny(M)) return AMQ_OK;
-    if (route != AMQ_GEMM_AUTO && route != AMQ_GEMM_DEQ)
-        return fail(AMQ_EINVAL, "groups of %d at %d rows run the dequantize-once route only (AMQ_GEMM_AUTO / AMQ_GEMM_DEQ): the fused many-row kernels read one (scale, zero) per 128 columns", group, M);
-    if (!workspace) return fail(AMQ_EINVAL, "groups of %d at %d rows need a workspace of N * K * 2 bytes for the fp16 weights (amq_gemm_route_workspace_bytes_g)", group, M);
+    if (route == AMQ_GEMM_RING || route == AMQ_GEMM_RING128 || route == AMQ_GEMM_WS)
+        return fail(AMQ_EINVAL, "groups of %d: the ring / wave-specialised kernels read one (scale, zero) per 128 columns (use AMQ_GEMM_AUTO, _SKINNY, _TILED or the dequantize-once route _DEQ)", group);
+    if (route == AMQ_GEMM_DEQ && !workspace) return fail(AMQ_EINVAL, "AMQ_GEMM_DEQ needs a workspace of N * K * 2 bytes for the fp16 weights");
+    (void)M; (void)N; (void)K;
     return AMQ_OK;
 }
 
@@ -232,7 +232,7 @@ int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void*
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     if (route == AMQ_GEMM_SKINNY && M > 64 && !((group == 64 || group == 32) && amq::gemm_fine_takes_skinny(M)))
         return fail(AMQ_ESHAPE, "the few-row kernel takes at most 64 rows (got %d)", M);
-    if (int rc = check_fine_route(route, group, M, workspace)) return rc;
+    if (int rc = check_fine_route(route, group, M, N, K, workspace)) return rc;
     const bool fine = group == 64 || group == 32;
     const size_t need = amq_gemm_route_workspace_bytes_g(route, M, N, K, group);
     const bool deq = route_is_deq(route, M, N, K, group);
@@ -241,8 +241,9 @@ int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void*
     if (use_ws && workspace_bytes < need)
         return fail(AMQ_EINVAL, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     const bool split = use_ws && !deq;
+    const int sroute = fine && route == AMQ_GEMM_AUTO ? (int)AMQ_GEMM_TILED : route;       // (groups of 64 / 32 beyond the few-row kernel: the tiled kernel)
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N,
-                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, route) : 1, residual, nullptr,
+                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, sroute) : 1, residual, nullptr,
                     use_ws && deq ? workspace : nullptr, amq::meta_pairs(group)};
     if ((route == AMQ_GEMM_DEQ || (fine && deq)) && !amq::gemm_f16w_ok(M, N, K, a.x_stride, a.y_stride))
         return fail(AMQ_ESHAPE, "AMQ_GEMM_DEQ: strides must be multiples of 8 (x) / 4 (y) halves and x, W must each span < 4 GiB");
@@ -269,7 +270,7 @@ int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void*
     if (N % 8) return fail(AMQ_ESHAPE, "the gated product needs N %% 8 == 0 (got %d)", N);
     if (route == AMQ_GEMM_SKINNY && M > 64 && !((group == 64 || group == 32) && amq::gemm_fine_takes_skinny(M)))
         return fail(AMQ_ESHAPE, "the few-row kernel takes at most 64 rows (got %d)", M);
-    if (int rc = check_fine_route(route, group, M, workspace)) return rc;
+    if (int rc = check_fine_route(route, group, M, N, K, workspace)) return rc;
     const size_t need = amq_gemm_route_workspace_bytes_g(route, M, N, K, group);
     const bool deq = route_is_deq(route, M, N, K, group);
     if (route == AMQ_GEMM_DEQ && !workspace) return fail(AMQ_EINVAL, "AMQ_GEMM_DEQ needs a workspace of N * K * 2 bytes for the fp16 weights");
@@ -277,8 +278,9 @@ int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void*
     if (use_ws && workspace_bytes < need)
         return fail(AMQ_EINVAL, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     const bool split = use_ws && !deq;
+    const int sroute = (group == 64 || group == 32) && route == AMQ_GEMM_AUTO ? (int)AMQ_GEMM_TILED : route;
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, N,
-                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, route) : 1, nullptr, gate,
+                    split ? (float*)workspace : nullptr, split ? amq::gemm_pick_splits(M, N, K, sroute) : 1, nullptr, gate,
                     use_ws && deq ? workspace : nullptr, amq::meta_pairs(group)};
     if ((group == 64 || group == 32) && deq && !amq::gemm_f16w_ok(M, N, K, a.x_stride, a.y_stride))
         return fail(AMQ_ESHAPE, "groups of %d (dequantize-once route): x_stride must be a multiple of 8 halves, N of 4, x and W must each span < 4 GiB", group);

@@ -27,7 +27,8 @@ constexpr int GM_LDA = 128;         // halves per staged x row: 256 B = 16 sixte
 
 // NSUB = 16-column sub-tiles per wave: every A fragment read from LDS feeds NSUB MFMAs (LDS read traffic per
 // MFMA falls as 1/NSUB; accumulators grow as BM/16 * NSUB * 4 VGPRs).  Workgroup tile = BM x (4 waves * 16 * NSUB).
-template <int BITS, int MODE, int BM, int NSUB>
+// GP: (scale, zero) pairs per (row, tile) = 128 / group (amq_common.cuh)
+template <int BITS, int MODE, int BM, int NSUB, int GP = 1>
 __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
     constexpr int GM_BN = 4 * 16 * NSUB;
     constexpr int MBLK = BM / 16;              // 16-row blocks per wave tile
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 
     LanePayload<BITS> pay[NSUB];
     h2 meta[NSUB];
+    [[maybe_unused]] MetaG<GP> metag[NSUB];                // (GP > 1: `meta` is unused)
     // LDS-DMA of one BM x 128 x tile: wave-instruction i (0 .. BM/4-1) fills rows 4i .. 4i+3; wave w issues i = w + 4j.
     // Lane l supplies row 4i + (l >> 4), LDS slot l & 15  <-  global slot (l & 15) ^ (row & 15).
     // Rows past M re-read row M-1 (computed, never stored).
@@ -87,8 +89,17 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
             const uint32_t* p = qw + tile * 64 * BITS + lane * BITS;
 #pragma unroll
             for (int d = 0; d < BITS; ++d) pay[nb].w[d] = p[d];
-            meta[nb] = mt[tile * 16 + r];
+            if constexpr (GP == 1) meta[nb] = mt[tile * 16 + r];
+            else {
+                const h2* mp = mt + (tile * 16 + r) * GP;
+#pragma unroll
+                for (int s_ = 0; s_ < GP; ++s_) metag[nb].p[s_] = mp[s_];
+            }
         }
+    };
+    auto unpack = [&](int nb, h2* out) {
+        if constexpr (GP == 1) dequant_lane_sd<BITS, MODE>(pay[nb].w, meta[nb], out);
+        else dequant_lane_sd_g<BITS, MODE, GP>(pay[nb].w, metag[nb], out);
     };
 
     issue_a(k0, abuf(0));
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 #ifdef AMQ_GABL_NODEQ      /* ablation: unpack once, outside the K loop */
     h2 wv[NSUB][16];
 #pragma unroll
-    for (int nb = 0; nb < NSUB; ++nb) dequant_lane_sd<BITS, MODE>(pay[nb].w, meta[nb], wv[nb]);
+    for (int nb = 0; nb < NSUB; ++nb) unpack(nb, wv[nb]);
 #endif
     for (int kt = k0; kt < k1; ++kt) {
 #ifdef AMQ_GABL_NOLOADA
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_kernel(GemmArgs a) {
 #ifndef AMQ_GABL_NODEQ
         h2 wv[NSUB][16];
 #pragma unroll
-        for (int nb = 0; nb < NSUB; ++nb) dequant_lane_sd<BITS, MODE>(pay[nb].w, meta[nb], wv[nb]);
+        for (int nb = 0; nb < NSUB; ++nb) unpack(nb, wv[nb]);
 #endif
 #ifdef AMQ_GABL_NOLOADA    /* ablation: the x tile is staged once; the K loop re-reads the same LDS image */
         if (kt + 1 < k1) { load_b(kt + 1); }
@@ -525,6 +536,12 @@ static hipError_t skinny_launch(const GemmArgs& a, hipStream_t st) {
 // 256 x 256-tile fp16 GEMM, which leaves the chip idle at such sizes (7B shapes, 64 rows: ~100 us per linear; profiles/r04_fine_groups.txt)
 constexpr int FINE_SKINNY_MAX_ROWS = 256;
 bool gemm_fine_takes_skinny(int M) { return M <= FINE_SKINNY_MAX_ROWS; }
+// ... and between the few-row kernel and launches that fill the chip with 256 x 256 tiles (where dequantize-once wins) the tiled kernel
+// of this file reads the pairs too (the ring / wave-specialised kernels do not)
+bool gemm_fine_takes_deq(int M, int N, int K) {
+    const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+    return M > FINE_SKINNY_MAX_ROWS && tiles >= 128 && K >= 256;
+}
 
 template <int BITS, int MODE, int GP>
 static hipError_t skinny_launch_g(const GemmArgs& a, hipStream_t st) {
@@ -571,12 +588,12 @@ int gemm_pick_splits(int M, int N, int K, int route) {
     return s < 1 ? 1 : s;
 }
 
-template <int BITS, int MODE, int BM, int NSUB>
+template <int BITS, int MODE, int BM, int NSUB, int GP = 1>
 static hipError_t gemm_launch_cfg(const GemmArgs& a, hipStream_t st) {
     constexpr int BN = 4 * 16 * NSUB;
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
     const size_t lds = 2 * BM * GM_LDA * 2;
-    auto k = gemm_kernel<BITS, MODE, BM, NSUB>;
+    auto k = gemm_kernel<BITS, MODE, BM, NSUB, GP>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -590,18 +607,30 @@ static hipError_t gemm_launch_cfg(const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int BITS, int MODE>
+template <int BITS, int MODE, int GP = 1>
 static hipError_t gemm_launch_bm(const GemmArgs& a, hipStream_t st) {
     // 64-row tiles while 128-row tiles would leave the chip under-filled (< 1.5 workgroups per CU)
     const long wg128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (a.splits > 1 && split_narrow(a.M)) return gemm_launch_cfg<BITS, MODE, 64, 1>(a, st);
+    if (a.splits > 1 && split_narrow(a.M)) return gemm_launch_cfg<BITS, MODE, 64, 1, GP>(a, st);
     // 64 x 64 tiles while 64 x 128 ones give at most 1.5 workgroups per CU: two waves per SIMD instead of one cover this kernel's
     // per-K-step drain (4096^2 3-bit, TFLOP/s: M = 512 415 -> 431, 768 490 -> 530; at 1024 rows the wide tile wins, 629 vs 587)
-    if (a.splits <= 1 && (long)((a.M + 63) / 64) * ((a.N + 127) / 128) <= 384) return gemm_launch_cfg<BITS, MODE, 64, 1>(a, st);
-    if (a.M <= 64 || wg128 < 384 || a.splits > 1) return gemm_launch_cfg<BITS, MODE, 64, 2>(a, st);
+    if (a.splits <= 1 && (long)((a.M + 63) / 64) * ((a.N + 127) / 128) <= 384) return gemm_launch_cfg<BITS, MODE, 64, 1, GP>(a, st);
+    if (a.M <= 64 || wg128 < 384 || a.splits > 1) return gemm_launch_cfg<BITS, MODE, 64, 2, GP>(a, st);
     // measured (5120x5120, M = 4096 / 16384): NSUB = 2 -> 0.81 / 0.89-0.92 PFLOP/s; NSUB = 4 needs ~390 VGPRs
     // (one wave per SIMD) and dropped to 0.68 / 0.76 (variant removed)
-    return gemm_launch_cfg<BITS, MODE, 128, 2>(a, st);
+    return gemm_launch_cfg<BITS, MODE, 128, 2, GP>(a, st);
+}
+
+template <int GP>
+static hipError_t tiled_launch_fine(const GemmArgs& a, hipStream_t st) {
+    if (a.mode == MODE_HQQ) {
+        if (a.bits == 4) return gemm_launch_bm<4, MODE_HQQ, GP>(a, st);
+        if (a.bits == 3) return gemm_launch_bm<3, MODE_HQQ, GP>(a, st);
+        return gemm_launch_bm<2, MODE_HQQ, GP>(a, st);
+    }
+    if (a.bits == 4) return gemm_launch_bm<4, MODE_FMA, GP>(a, st);
+    if (a.bits == 3) return gemm_launch_bm<3, MODE_FMA, GP>(a, st);
+    return gemm_launch_bm<2, MODE_FMA, GP>(a, st);
 }
 
 // Many-row policy: the ring kernel (amq_gemm_ring.hip) or the wave-specialised kernel (amq_gemm_ws.hip) whenever one of their tile shapes fills the chip (gemm_many_rows_plan),
@@ -626,9 +655,8 @@ bool gemm_takes_deq(int M, int N, int K) {
 
 // the dequantize-once route: forced, or AUTO's choice -- either way only with a scratch for the fp16 weights and without split-K
 static bool gemm_runs_deq(const GemmArgs& a, int route) {
-    if (a.gp > 1 && route != GEMM_ROUTE_DEQ && gemm_fine_takes_skinny(a.M)) return false;      // groups of 64 / 32, few rows: the GP-aware few-row kernel
     if (!a.w16 || a.splits > 1 || !gemm_f16w_ok(a.M, a.N, a.K, a.x_stride, a.y_stride)) return false;
-    if (a.gp > 1) return true;                             // ... more rows: the only route (the other fused kernels read one meta pair per tile)
+    if (a.gp > 1) return route == GEMM_ROUTE_DEQ || (route == GEMM_ROUTE_AUTO && gemm_fine_takes_deq(a.M, a.N, a.K));   // groups of 64 / 32
     return route == GEMM_ROUTE_DEQ || (route == GEMM_ROUTE_AUTO && gemm_takes_deq(a.M, a.N, a.K));
 }
 
@@ -638,7 +666,8 @@ static bool gemm_runs_deq(const GemmArgs& a, int route) {
 bool gemm_gate_fused(const GemmArgs& a, int route) {
     const bool ring = (route == GEMM_ROUTE_RING || route == GEMM_ROUTE_RING128 || route == GEMM_ROUTE_WS ||
                        (route == GEMM_ROUTE_AUTO && a.splits <= 1 && gemm_takes_ring(a.M, a.N, a.K))) && gemm_ring_ok(a);
-    if (a.gp > 1) return true;                             // groups of 64 / 32: few-row kernel or dequantize-once route, both apply it
+    if (a.gp > 1)                                          // groups of 64 / 32: the few-row kernel and the dequantize-once route apply it, the tiled kernel does not
+        return gemm_runs_deq(a, route) || ((route == GEMM_ROUTE_AUTO || route == GEMM_ROUTE_SKINNY) && gemm_fine_takes_skinny(a.M));
     return ring || gemm_is_skinny(a.M, a.N, a.K, route) || gemm_runs_deq(a, route);
 }
 
@@ -660,6 +689,8 @@ static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int rout
     if (a.gp > 1) {
         if ((route == GEMM_ROUTE_AUTO || route == GEMM_ROUTE_SKINNY) && gemm_fine_takes_skinny(a.M))
             return a.gp == 2 ? skinny_launch_fine<2>(a, st) : skinny_launch_fine<4>(a, st);
+        if (route == GEMM_ROUTE_AUTO || route == GEMM_ROUTE_TILED)
+            return a.gp == 2 ? tiled_launch_fine<2>(a, st) : tiled_launch_fine<4>(a, st);
         return hipErrorInvalidValue;                       // (amq_capi.hip refuses such a call with its reason before it gets here)
     }
     if (route == GEMM_ROUTE_RING && gemm_ring_ok(a)) return launch_gemm_ring(a, st);

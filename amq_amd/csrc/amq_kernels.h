@@ -109,6 +109,7 @@ int gemm_pick_splits(int M, int N, int K, int route = GEMM_ROUTE_AUTO);
 // amq_gemm_f16.hip: y = x . W^T with W as fp16 [N, K] (the dequantized weights, or any dense fp16 matrix): 256 x 256 tiles, two wave
 // groups in ping-pong, no VALU in the K loop; bias / residual / gate epilogues as GemmArgs
 bool gemm_f16w_ok(int M, int N, int K, int x_stride, int y_stride);
+bool gemm_fine_takes_deq(int M, int N, int K);                      // groups of 64 / 32: GEMM_ROUTE_AUTO runs dequantize-once (given the scratch); else few-row / tiled kernel
 bool gemm_fine_takes_skinny(int M);                                 // groups of 64 / 32: rows up to which the (GP-aware) few-row kernel serves them; beyond: dequantize-once
 bool gemm_takes_deq(int M, int N, int K);                           // GEMM_ROUTE_AUTO: dequantize once + fp16 GEMM (given a scratch) beats the fused kernels
 hipError_t launch_gemm_f16w(const void* x, const void* w, const void* bias, const void* residual, const void* gate, void* y,

@@ -27,9 +27,10 @@
  *     hqq/core/quantize.py:1078; the reference's GPTQ kernels take any groupsize, auto_gptq_kernel.cu:203) keep 128 / group pairs per
  *     (row, 128-column tile) in the native meta (amq_native_meta_bytes grows accordingly) and are served by: the amq_repack_from_* and
  *     amq_dequantize_* calls, the GEMV kernel (amq_gemv_f16 / amq_gemv_grouped_f16: <= 16 rows, every prologue, default options), the few-row
- *     GEMM up to 256 rows (amq_gemm_f16, and AMQ_GEMM_AUTO / AMQ_GEMM_SKINNY of the route calls: no workspace) and, beyond, the
- *     dequantize-once GEMM route (amq_gemm_route_f16 / amq_gemm_res_f16 / amq_gemm_gated_f16 with the amq_gemm_route_workspace_bytes_g
- *     workspace); the other compute entry points return AMQ_ESHAPE for them.  The compute calls' `group` argument is therefore the
+ *     GEMM up to 256 rows and the tiled GEMM beyond (amq_gemm_f16; AMQ_GEMM_AUTO / _SKINNY / _TILED of the route
+ *     calls) and, for launches that fill 256 x 256 tiles, the dequantize-once GEMM route (amq_gemm_route_f16 / amq_gemm_res_f16 /
+ *     amq_gemm_gated_f16 with the amq_gemm_route_workspace_bytes_g workspace); the ring / wave-specialised routes and the other compute
+ *     entry points return an error for them.  The compute calls' `group` argument is therefore the
  *     NATIVE buffers' granularity: 64, 32, or anything >= 128.  N % 16 == 0, K % 128 == 0.
  *   - "native" buffers are in the AMQ-T16 layout (amq_common.cuh);
  *     sizes from amq_native_*_bytes(); produced by the amq_repack_from_* calls.
@@ -268,8 +269,9 @@ int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qweight_nati
  * matching workspace query (0: no workspace needed).  The workspace holds split-K partials (few rows) or the dequantized
  * fp16 weights (AMQ_GEMM_DEQ, and AUTO on MFMA-bound launches) -- never both; without it AUTO runs a fused kernel. */
 size_t amq_gemm_route_workspace_bytes(int route, int M, int N, int K);
-/* ... for a given group size: groups of 64 / 32 take the few-row kernel up to 256 rows (0 bytes) and ALWAYS the dequantize-once route beyond
- * (N * K * 2 bytes; AMQ_GEMM_AUTO or AMQ_GEMM_DEQ, the workspace is mandatory) -- the fused many-row kernels read one (scale, zero) pair per 128 columns. */
+/* ... for a given group size: groups of 64 / 32 take the few-row kernel up to 256 rows (0 bytes), the tiled kernel beyond (split-K partials as for
+ * group 128) and the dequantize-once route (N * K * 2 bytes) for launches that fill 256 x 256 tiles -- the ring / wave-specialised kernels read one
+ * (scale, zero) pair per 128 columns. */
 size_t amq_gemm_route_workspace_bytes_g(int route, int M, int N, int K, int group);
 int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
                        const void* bias, const void* residual, void* y, int M, int N, int K, int group, int x_stride,

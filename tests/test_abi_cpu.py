@@ -110,20 +110,19 @@ def test_finer_groups_host_side():
         for m in (1, 17, 256):
             assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_AUTO, m, N, K, g) == 0               # the (pair-aware) few-row kernel: no workspace
             assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_DEQ, m, N, K, g) == N * K * 2
-        for m in (257, 4096, 32768):
-            assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_AUTO, m, N, K, g) == N * K * 2       # beyond: always the dequantize-once route
+        assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_AUTO, 300, N, K, g) != N * K * 2         # the tiled kernel (split-K partials, or nothing)
+        for m in (2048, 4096, 32768):
+            assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_AUTO, m, N, K, g) == N * K * 2       # launches that fill 256 x 256 tiles: dequantize-once
         assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_RING, 4096, N, K, g) == 0
     assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_AUTO, 64, N, K, 128) == lib.amq_gemm_route_workspace_bytes(_lib.GEMM_AUTO, 64, N, K)
     one = ctypes.c_void_p(256)
     # the plain GEMM entry has no workspace: refused with the way out in the message
-    assert lib.amq_gemm_f16(4, 0, one, one, one, None, one, 300, N, K, 64, 0, 0, None) == -2
-    assert b"amq_gemm_route_f16" in lib.amq_last_error()
-    # route calls beyond the few-row kernel's reach: AUTO / DEQ with the workspace
-    assert lib.amq_gemm_route_f16(_lib.GEMM_AUTO, 4, 0, one, one, one, None, None, one, 300, N, K, 64, 0, 0, None, 0, None) == -1
-    assert b"workspace" in lib.amq_last_error()
+    # route calls: the ring / wave-specialised kernels read one pair per tile; the dequantize-once route needs its workspace
     assert lib.amq_gemm_route_f16(_lib.GEMM_RING, 4, 0, one, one, one, None, None, one, 4096, N, K, 32, 0, 0, one, N * K * 2, None) == -1
     assert b"dequantize-once" in lib.amq_last_error()
-    assert lib.amq_gemm_route_f16(_lib.GEMM_AUTO, 4, 0, one, one, one, None, None, one, 300, N, K, 64, 0, 0, one, 1024, None) == -1   # too small
+    assert lib.amq_gemm_route_f16(_lib.GEMM_DEQ, 4, 0, one, one, one, None, None, one, 300, N, K, 64, 0, 0, None, 0, None) == -1
+    assert b"workspace" in lib.amq_last_error()
+    assert lib.amq_gemm_route_f16(_lib.GEMM_AUTO, 4, 0, one, one, one, None, None, one, 4096, N, K, 64, 0, 0, one, 1024, None) == -1  # too small
     assert lib.amq_gemm_route_f16(_lib.GEMM_SKINNY, 4, 0, one, one, one, None, None, one, 300, N, K, 64, 0, 0, None, 0, None) == -2  # past its rows
     # GEMV options other than the default form
     seg = (_lib.Segment * 1)(_lib.Segment(256, 256, None, None, 256, N, 4, 0, 0))

@@ -162,7 +162,7 @@ FINE_CASES = sorted(glob.glob(os.path.join(GOLDEN, "hqq_g64_b*.npz")) + glob.glo
 def test_reference_ffi_shaped_gptq_call_with_finer_groups(path):
     """vecquant{2,3,4}matmul_faster_old takes any groupsize (auto_gptq_kernel.cu:203: g = k / groupsize): the reference's own GPTQLinear
     buffers of its group-64 / group-32 layers through amq_vecquantmatmul_faster_old: the GEMV kernel up to 8 rows, the pair-aware few-row
-    GEMM up to 256; more rows are refused with the way out in the message (this call carries no workspace for the dequantized weights)"""
+    GEMM up to 256, the pair-aware tiled GEMM beyond (this call carries no workspace, so never the dequantize-once route)"""
     import ctypes
     from amq_amd import _lib
     from oracle import gptq_ref
@@ -183,12 +183,14 @@ def test_reference_ffi_shaped_gptq_call_with_finer_groups(path):
                                                          qw.shape[0], n, vp(ws), ws.numel(), valid, st))
         ref = linear_ref.linear_f16(g["gptq_x"][:m], w).astype(np.float32)
         assert np.all(np.abs(mul.cpu().numpy() - (0.5 + 2 * ref)) <= 2e-3 * np.abs(ref) + 2e-3 * np.sqrt(np.mean(ref ** 2)))
-    x = torch.zeros(300, k, dtype=torch.float16, device=_dev())
+    xs = np.concatenate([g["gptq_x"], g["gptq_x"], g["gptq_x"][:44]], axis=0)       # 300 rows
+    x = t(xs)
     ws = torch.empty(lib.amq_compat_workspace_bytes(bits, 300, n, k), dtype=torch.uint8, device=_dev())
     mul = torch.zeros(300, n, dtype=torch.float32, device=_dev())
-    assert lib.amq_vecquantmatmul_faster_old(bits, vp(x), vp(qw), vp(mul), vp(sc), vp(zr), G, k // 2, 300, qw.shape[0], n,
-                                             vp(ws), ws.numel(), 0, st) == -2
-    assert b"amq_gemm_route_f16" in lib.amq_last_error()
+    _lib.check(lib.amq_vecquantmatmul_faster_old(bits, vp(x), vp(qw), vp(mul), vp(sc), vp(zr), G, k // 2, 300, qw.shape[0], n,
+                                                 vp(ws), ws.numel(), 0, st))
+    ref = linear_ref.linear_f16(xs, w).astype(np.float32)
+    assert np.all(np.abs(mul.cpu().numpy() - ref) <= 2e-3 * np.abs(ref) + 2e-3 * np.sqrt(np.mean(ref ** 2)))
 
 
 def test_module_walk_decode_matches_runner():
