@@ -186,12 +186,12 @@ int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qn, const
                         void* stream) {
     const size_t need = amq_gemm_splitk_workspace_bytes(M, N, K);
     if (need == 0) return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, x_stride, y_stride, stream);
-    if (int rc = check_shape128(bits, N, K, group, "amq_gemm_splitk_f16")) return rc;
+    if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (!workspace || workspace_bytes < need) return fail(AMQ_EINVAL, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N,
-                    (float*)workspace, amq::gemm_pick_splits(M, N, K)};
+                    (float*)workspace, amq::gemm_pick_splits(M, N, K), nullptr, nullptr, nullptr, amq::meta_pairs(group)};
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream), "gemm_splitk");
 }
 
