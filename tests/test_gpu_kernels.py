@@ -204,7 +204,7 @@ def test_coarser_groups_are_read_bit_exact(bits, n, k, group):
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("group", [64, 32])
-@pytest.mark.parametrize("n,k", [(64, 512), (48, 1536), (4096, 4096), (1024, 11008)])
+@pytest.mark.parametrize("n,k", [(16, 128), (64, 512), (48, 1536), (272, 384), (4096, 4096), (1024, 11008)])
 def test_finer_groups(bits, group, n, k):
     """groups of 64 / 32 (128 / group (scale, zero) pairs per native tile row): repack from all three source formats -> dequantize == the
     oracle's dequant of the same buffers, bit for bit; the standalone HQQ dequant too; the GEMV kernel (1 / 3 / 16 rows, bias, the fused
