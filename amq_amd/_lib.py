@@ -79,6 +79,7 @@ SIGNATURES = {
     "amq_rmsnorm_xfrag_f16": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "amq_gemm_xfrag_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amq_gemm_gated_fused": (_i, [_i, _i, _i, _i, _i]),
+    "amq_gemm_gated_fused_g": (_i, [_i, _i, _i, _i, _i, _i]),
     "amq_gemm_gated_f16": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "amq_attn_decode_split_workspace_bytes": (_sz, [_i, _i, _i]),
     "amq_attn_decode_split_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _sz, _vp, _vp]),

@@ -250,14 +250,18 @@ int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void*
     return check_hip(amq::launch_gemm(a, (hipStream_t)stream, route), "gemm");
 }
 
-int amq_gemm_gated_fused(int route, int M, int N, int K, int use_workspace) {
+int amq_gemm_gated_fused_g(int route, int M, int N, int K, int use_workspace, int group) {
     if (M < 1 || N < 16 || K < 128 || route < AMQ_GEMM_AUTO || route > AMQ_GEMM_DEQ) return 0;
-    const bool deq = route_is_deq(route, M, N, K);
+    const bool fine = group == 64 || group == 32;
+    const bool deq = route_is_deq(route, M, N, K, group);
+    const int sroute = fine && route == AMQ_GEMM_AUTO ? (int)AMQ_GEMM_TILED : route;
     amq::GemmArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, M, N, K, 4, AMQ_MODE_HQQ, K, N, nullptr,
-                    use_workspace && !deq ? amq::gemm_pick_splits(M, N, K, route) : 1, nullptr, nullptr,
-                    use_workspace && deq ? (void*)&a : nullptr};      // (any non-null value: only tested for presence)
+                    use_workspace && !deq ? amq::gemm_pick_splits(M, N, K, sroute) : 1, nullptr, nullptr,
+                    use_workspace && deq ? (void*)&a : nullptr,       // (any non-null value: only tested for presence)
+                    amq::meta_pairs(group > 0 ? group : 128)};
     return amq::gemm_gate_fused(a, route) ? 1 : 0;
 }
+int amq_gemm_gated_fused(int route, int M, int N, int K, int use_workspace) { return amq_gemm_gated_fused_g(route, M, N, K, use_workspace, 128); }
 
 int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
                        const void* gate, void* y, int M, int N, int K, int group, int x_stride, void* workspace,

@@ -281,11 +281,7 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=
     lib = _lib.load()
     if gate is not None:
         ws, ws_bytes = _route_workspace(lib, x.device, route, M, N, K, group)
-        if group == GROUP:
-            fused = lib.amq_gemm_gated_fused(route, M, N, K, 1 if ws_bytes else 0)
-        else:       # groups of 64 / 32: the few-row kernel (<= 256 rows) and the dequantize-once route apply the gate, the tiled kernel between them does not
-            fused = (M <= 256 and route in (GEMM_AUTO, GEMM_SKINNY)) or ws_bytes == N * K * 2
-        if y.data_ptr() == gate.data_ptr() and not fused:
+        if y.data_ptr() == gate.data_ptr() and not lib.amq_gemm_gated_fused_g(route, M, N, K, 1 if ws_bytes else 0, group):
             # the tiled kernel cannot apply the gate itself: in place on the gate needs the projection somewhere else first
             up = gemm(x, qn, mn, bits, mode, N, K, bias=bias, route=route)
             silu_mul(gate, up.view(-1), out=y)

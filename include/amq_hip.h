@@ -289,6 +289,7 @@ int amq_gemm_f16w_f16(const void* x, const void* w_f16, const void* bias, const 
  * gate may alias y only in the first case: amq_gemm_gated_fused(route, M, N, K, use_workspace) says which it is
  * (use_workspace: whether a split-K workspace will be passed).  route / workspace as amq_gemm_route_f16. */
 int amq_gemm_gated_fused(int route, int M, int N, int K, int use_workspace);
+int amq_gemm_gated_fused_g(int route, int M, int N, int K, int use_workspace, int group);   /* ... for a given group size (64 / 32: few-row kernel and dequantize-once yes, tiled no) */
 int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
                        const void* bias, const void* gate, void* y, int M, int N, int K, int group, int x_stride,
                        void* workspace, size_t workspace_bytes, void* stream);

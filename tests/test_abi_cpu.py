@@ -115,6 +115,10 @@ def test_finer_groups_host_side():
             assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_AUTO, m, N, K, g) == N * K * 2       # launches that fill 256 x 256 tiles: dequantize-once
         assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_RING, 4096, N, K, g) == 0
     assert lib.amq_gemm_route_workspace_bytes_g(_lib.GEMM_AUTO, 64, N, K, 128) == lib.amq_gemm_route_workspace_bytes(_lib.GEMM_AUTO, 64, N, K)
+    # the gate is applied by the few-row kernel and by the dequantize-once route, not by the tiled kernel between them
+    assert lib.amq_gemm_gated_fused_g(_lib.GEMM_AUTO, 64, N, K, 0, 64) == 1 and lib.amq_gemm_gated_fused_g(_lib.GEMM_AUTO, 512, N, K, 1, 64) == 0
+    assert lib.amq_gemm_gated_fused_g(_lib.GEMM_AUTO, 4096, N, K, 1, 64) == 1 and lib.amq_gemm_gated_fused_g(_lib.GEMM_AUTO, 4096, N, K, 0, 64) == 0
+    assert lib.amq_gemm_gated_fused_g(_lib.GEMM_AUTO, 64, N, K, 0, 128) == lib.amq_gemm_gated_fused(_lib.GEMM_AUTO, 64, N, K, 0)
     one = ctypes.c_void_p(256)
     # the plain GEMM entry has no workspace: refused with the way out in the message
     # route calls: the ring / wave-specialised kernels read one pair per tile; the dequantize-once route needs its workspace
