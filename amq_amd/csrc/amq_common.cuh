@@ -179,7 +179,11 @@ __device__ __forceinline__ h2 sd_pair(uint32_t t, const SdMeta& m) {
     const _Float16 mul = (_Float16)(float)(1 << B);
     if (MODE == MODE_HQQ) {
         h2 d = __builtin_elementwise_fma(sub, bcast(mul), m.zc); // RN16((q - z) * 2^E)
+#ifdef AMQ_ABL_NOMUL               /* timing-only ablation: the second rounding's multiply dropped (one VOP3P per pair instead of two; wrong weights) */
+        return d;
+#else
         return d * m.sc;
+#endif
     } else {
         h2 qs = sub * bcast(mul);                                // q * 2^E, exact
         return __builtin_elementwise_fma(qs, m.sc, m.zc);
