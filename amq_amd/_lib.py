@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libamq_hip.so")
 AB_LIB_PATH = os.path.join(_HERE, "libamq_hip_ab.so")
 
 AMQ_OK = 0
-MODE_HQQ, MODE_FMA = 0, 1
+MODE_HQQ, MODE_FMA, MODE_FMA1 = 0, 1, 2
 PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
 MATH_EXACT, MATH_LINEAR = 0, 1
@@ -52,6 +52,7 @@ SIGNATURES = {
     "amq_last_error": (ctypes.c_char_p, []),
     "amq_query": (_i, [_i, ctypes.POINTER(_i), _i]),
     "amq_native_qweight_bytes": (_sz, [_i, _i, _i]),
+    "amq_fma1_scale_bound": (ctypes.c_float, [_i]),
     "amq_native_meta_bytes": (_sz, [_i, _i, _i]),
     "amq_repack_from_hqq": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "amq_repack_from_gptq": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -51,9 +51,11 @@ int check_shape128(int bits, int N, int K, int group, const char* who) {
 }
 
 int check_mode(int mode) {
-    if (mode != AMQ_MODE_HQQ && mode != AMQ_MODE_FMA) return fail(AMQ_EINVAL, "unknown dequant mode %d", mode);
+    if (mode != AMQ_MODE_HQQ && mode != AMQ_MODE_FMA && mode != AMQ_MODE_FMA1) return fail(AMQ_EINVAL, "unknown dequant mode %d", mode);
     return AMQ_OK;
 }
+// AMQ_MODE_FMA1 (scales within amq_fma1_scale_bound: the GEMV kernel's one-op unpack) is AMQ_MODE_FMA to every other kernel: the same results
+int kernel_mode(int mode) { return mode == AMQ_MODE_FMA1 ? AMQ_MODE_FMA : mode; }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
@@ -79,6 +81,7 @@ int amq_query(int K, int* out, int cap) {
 }
 
 size_t amq_native_qweight_bytes(int bits, int N, int K) { return amq::native_qweight_bytes(bits, N, K); }
+float amq_fma1_scale_bound(int bits) { return (bits == 2 || bits == 3 || bits == 4) ? amq::fma1_scale_bound(bits) : 0.0f; }
 size_t amq_native_meta_bytes(int N, int K, int group) { return amq::native_meta_bytes(N, K, group > 0 ? amq::meta_pairs(group) : 1); }
 
 int amq_repack_from_hqq(int bits, const void* W_q, const void* scale, const void* zero, int N, int K, int group,
@@ -105,6 +108,7 @@ int amq_repack_from_awq(const void* qweight, const void* scales, const void* sca
 int amq_dequantize_f16(int bits, int mode, const void* qn, const void* mn, int N, int K, int group, void* W, void* stream) {
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
+    mode = kernel_mode(mode);
     if (!qn || !mn || !W) return fail(AMQ_EINVAL, "null pointer");
     return check_hip(amq::launch_dequantize(bits, mode, qn, mn, N, K, W, (hipStream_t)stream, amq::meta_pairs(group)), "dequantize");
 }
@@ -168,6 +172,7 @@ int amq_gemm_f16(int bits, int mode, const void* x, const void* qn, const void* 
                  int M, int N, int K, int group, int x_stride, int y_stride, void* stream) {
     if (int rc = check_shape(bits, N, K, group)) return rc;          // (groups of 64 / 32: the few-row or the tiled kernel -- no workspace here, so never dequantize-once)
     if (int rc = check_mode(mode)) return rc;
+    mode = kernel_mode(mode);
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N, nullptr, 1,
@@ -188,6 +193,7 @@ int amq_gemm_splitk_f16(int bits, int mode, const void* x, const void* qn, const
     if (need == 0) return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, x_stride, y_stride, stream);
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
+    mode = kernel_mode(mode);
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (!workspace || workspace_bytes < need) return fail(AMQ_EINVAL, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     amq::GemmArgs a{x, qn, mn, bias, y, M, N, K, bits, mode, x_stride ? x_stride : K, y_stride ? y_stride : N,
@@ -228,6 +234,7 @@ int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void*
     if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_DEQ) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
+    mode = kernel_mode(mode);
     if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     if (route == AMQ_GEMM_SKINNY && M > 64 && !((group == 64 || group == 32) && amq::gemm_fine_takes_skinny(M)))
@@ -269,6 +276,7 @@ int amq_gemm_gated_f16(int route, int bits, int mode, const void* x, const void*
     if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_DEQ) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
+    mode = kernel_mode(mode);
     if (!x || !qn || !mn || !y || !gate) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     if (N % 8) return fail(AMQ_ESHAPE, "the gated product needs N %% 8 == 0 (got %d)", N);
@@ -334,6 +342,7 @@ int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qn, const
                        void* stream) {
     if (int rc = check_shape128(bits, N, K, group, "amq_gemm_xfrag_f16")) return rc;
     if (int rc = check_mode(mode)) return rc;
+    mode = kernel_mode(mode);
     if (!xf || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     if ((M + 63) / 64 > 65535) return fail(AMQ_ESHAPE, "M=%d exceeds one launch", M);
@@ -354,7 +363,7 @@ int amq_gemm_xfrag_grouped_f16(const amq_segment* segs, int nseg, const void* xf
         if (!s.qweight_native || !s.meta_native || !s.y) return fail(AMQ_EINVAL, "segment %d: null pointer", i);
         amq::GemvSeg& d = gs[i];
         d.qweight = s.qweight_native; d.meta = s.meta_native; d.bias = s.bias; d.residual = s.residual; d.y = s.y;
-        d.N = s.N; d.bits = s.bits; d.mode = s.mode;
+        d.N = s.N; d.bits = s.bits; d.mode = kernel_mode(s.mode);
         d.y_stride = s.y_stride ? s.y_stride : s.N;
     }
     return check_hip(amq::launch_gemm_xfrag_grouped(xf, M, K, gs, nseg, (hipStream_t)stream), "gemm_xfrag_grouped");
@@ -379,7 +388,7 @@ int amq_gemv_qkv_attn_f16(const amq_segment* segs, const void* x, const void* ga
         if (!s.qweight_native || !s.meta_native || !s.y) return fail(AMQ_EINVAL, "segment %d: null pointer", i);
         if (s.bias || s.residual) return fail(AMQ_EUNSUPPORTED, "segment %d: bias / residual are not part of the fused q/k/v + attention launch", i);
         amq::GemvSeg& d = a.seg[i];
-        d.qweight = s.qweight_native; d.meta = s.meta_native; d.y = s.y; d.N = s.N; d.bits = s.bits; d.mode = s.mode; d.y_stride = s.N;
+        d.qweight = s.qweight_native; d.meta = s.meta_native; d.y = s.y; d.N = s.N; d.bits = s.bits; d.mode = kernel_mode(s.mode); d.y_stride = s.N;
     }
     a.nseg = 3; a.M = 1; a.K = K; a.x_stride = K; a.x = x; a.gamma = gamma; a.eps = eps; a.prologue = amq::PRO_RMSNORM;
     amq::AttnArgs t{segs[0].y, segs[1].y, segs[2].y, kcache, vcache, out, nullptr, 0, n_heads, n_kv_heads, max_seq, 10000.0f, nullptr, step_state};
@@ -420,7 +429,7 @@ int amq_decode_engine_image(const amq_engine_block* blocks, int n_block, int hid
             if (int rc = check_mode(l.mode)) return rc;
             if (!l.qweight_native || !l.meta_native) return fail(AMQ_EINVAL, "block %d linear %d: null pointer", b, i);
             if (amq::native_qweight_bytes(l.bits, l.N, K) >= (1ull << 32)) return fail(AMQ_ESHAPE, "block %d linear %d spans 4 GiB or more", b, i);
-            lin[(size_t)b * 7 + i] = amq::EngineLinearH{l.qweight_native, l.meta_native, l.N, l.bits, l.mode};
+            lin[(size_t)b * 7 + i] = amq::EngineLinearH{l.qweight_native, l.meta_native, l.N, l.bits, kernel_mode(l.mode)};
         }
         if (!blocks[b].ln1 || !blocks[b].ln2 || !blocks[b].kcache || !blocks[b].vcache) return fail(AMQ_EINVAL, "block %d: null pointer", b);
         ln1[b] = blocks[b].ln1; ln2[b] = blocks[b].ln2; kc[b] = blocks[b].kcache; vc[b] = blocks[b].vcache;

@@ -47,7 +47,9 @@ typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
-enum { MODE_HQQ = 0, MODE_FMA = 1 };
+// MODE_FMA1: MODE_FMA for buffers whose scales are small enough for the GEMV's one-op unpack (fma1_scale_bound) -- same results; every other kernel
+// treats it as MODE_FMA (all mode tests are "== MODE_HQQ ? ... : fma form")
+enum { MODE_HQQ = 0, MODE_FMA = 1, MODE_FMA1 = 2 };
 enum { TILE_N = 16, TILE_K = 128, GROUP = 128 };
 
 __device__ __forceinline__ h2 as_h2(uint32_t u) { return __builtin_bit_cast(h2, u); }
@@ -231,6 +233,64 @@ __device__ __forceinline__ void dequant_lane_sd(const uint32_t* w, h2 meta, h2* 
         const uint32_t e = ((w[0] >> 8) & 0x00800080u) | ((w[1] >> 7) & 0x01000100u) |
                            ((w[2] >> 6) & 0x02000200u);
         out[15] = sd_pair<3, MODE, 7>(e, m);
+    }
+}
+
+// MODE_FMA in ONE packed op per pair: w = fma(q 2^(SH-24), s 2^(24-SH), c) = RN16(q s + c), the same single rounding as the two-op form above
+// (q 2^E exact, then fma with s 2^-E) -- bit-identical wherever s 2^(24-SH) is finite in fp16: with the fields at bit 4 / 6 / 7 / 8 of the halves
+// that is |s| <= 65504 / 2^20 (2-, 3-bit: a field at bit 4) or 65504 / 2^18 (4-bit: bit 6).  The bound is checked per LAYER at load time
+// (fma1_scale_bound; MODE_FMA1 in the buffers' mode): an in-kernel fallback would cost every body of the kernel its register budget.
+__host__ __device__ __forceinline__ float fma1_scale_bound(int bits) { return bits == 4 ? 65504.0f / 262144.0f : 65504.0f / 1048576.0f; }
+template <int BITS, int SH>
+__device__ __forceinline__ h2 fma1_pair(uint32_t t, h2 s_sh, h2 c2) {
+    constexpr uint32_t fm = (1u << BITS) - 1u;
+    constexpr uint32_t msk = (fm << SH) | ((fm << SH) << 16);
+    return __builtin_elementwise_fma(as_h2(t & msk), s_sh, c2);
+}
+template <int BITS>
+__device__ __forceinline__ void dequant_lane_fma1(const uint32_t* w, h2 meta, h2* out) {
+    const h2 s2 = bcast(meta.x), c2 = bcast(meta.y);
+    if (BITS == 4) {            // fields brought to bit 6 of each half: x 2^18
+        const h2 k6 = s2 * bcast((_Float16)512.0f) * bcast((_Float16)512.0f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t u = w[t];
+            out[4 * t + 0] = fma1_pair<4, 6>(u << 6, k6, c2);
+            out[4 * t + 1] = fma1_pair<4, 6>(u << 2, k6, c2);
+            out[4 * t + 2] = fma1_pair<4, 6>(u >> 2, k6, c2);
+            out[4 * t + 3] = fma1_pair<4, 6>(u >> 6, k6, c2);
+        }
+    } else if (BITS == 2) {     // fields at bit 4 / 6 / 8: x 2^20 / 2^18 / 2^16
+        const h2 k8 = s2 * bcast((_Float16)256.0f) * bcast((_Float16)256.0f);
+        const h2 k6 = k8 * bcast((_Float16)4.0f), k4 = k8 * bcast((_Float16)16.0f);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const uint32_t u = w[d];
+            const uint32_t a = u << 4, b = u >> 2, c = u >> 8;
+            out[8 * d + 0] = fma1_pair<2, 4>(a, k4, c2);
+            out[8 * d + 1] = fma1_pair<2, 6>(a, k6, c2);
+            out[8 * d + 2] = fma1_pair<2, 8>(a, k8, c2);
+            out[8 * d + 3] = fma1_pair<2, 4>(b, k4, c2);
+            out[8 * d + 4] = fma1_pair<2, 6>(b, k6, c2);
+            out[8 * d + 5] = fma1_pair<2, 8>(b, k8, c2);
+            out[8 * d + 6] = fma1_pair<2, 4>(c, k4, c2);
+            out[8 * d + 7] = fma1_pair<2, 6>(c, k6, c2);
+        }
+    } else {                    // fields at bit 4 / 7: x 2^20 / 2^17
+        const h2 k7 = s2 * bcast((_Float16)512.0f) * bcast((_Float16)256.0f);
+        const h2 k4 = k7 * bcast((_Float16)8.0f);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t u = w[d];
+            const uint32_t a = u << 4, b = u >> 2, c = u >> 8;
+            out[5 * d + 0] = fma1_pair<3, 4>(a, k4, c2);
+            out[5 * d + 1] = fma1_pair<3, 7>(a, k7, c2);
+            out[5 * d + 2] = fma1_pair<3, 4>(b, k4, c2);
+            out[5 * d + 3] = fma1_pair<3, 7>(b, k7, c2);
+            out[5 * d + 4] = fma1_pair<3, 4>(c, k4, c2);
+        }
+        const uint32_t e = ((w[0] >> 8) & 0x00800080u) | ((w[1] >> 7) & 0x01000100u) | ((w[2] >> 6) & 0x02000200u);
+        out[15] = fma1_pair<3, 7>(e, k7, c2);
     }
 }
 

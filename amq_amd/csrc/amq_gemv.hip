@@ -47,7 +47,7 @@ struct GemvKArgs {
     float eps; int rpt, pad0_, pad1_;
     int wg_begin[GEMV_MAX_SEG];
     int n_rt[GEMV_MAX_SEG];
-    int key[GEMV_MAX_SEG];                 // bits * 2 + mode
+    int key[GEMV_MAX_SEG];                 // bits * 4 + mode
     const void* qweight[GEMV_MAX_SEG];
     const void* meta[GEMV_MAX_SEG];
     // ---- cold: epilogue only
@@ -502,6 +502,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
         const int kbase = g_ << 7;                                                               \
         h2 wv[16];                                                                               \
         if (MATH == MATH_LINEAR) unpack_lane_sub<BITS>(pay[slot].w, wv);                         \
+        else if constexpr (GP == 1 && MODE == MODE_FMA1) dequant_lane_fma1<BITS>(pay[slot].w, meta[slot], wv);   /* reference-format weights, one op per pair */ \
         else if constexpr (GP == 1) dequant_lane_sd<BITS, MODE>(pay[slot].w, meta[slot], wv);    \
         else dequant_lane_sd_g<BITS, MODE, GP>(pay[slot].w, metag[slot], wv);                    \
         if (MATH == MATH_DOT) {                                                                  \
@@ -721,12 +722,19 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_G(NW, GP)) void gemv_kernel(c
     if (fastx) x_issue<PRO, NW, XCH>(a, xr);
 
     const _Float16* xuse = xl;
-    switch (key) {
-        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+    constexpr bool HAS_FMA1 = MATH == MATH_EXACT && GP == 1;      // (launch_gemv maps MODE_FMA1 to MODE_FMA for the kernels without those bodies)
+    bool done = false;
+    if constexpr (HAS_FMA1) {
+        if (key == 4 * 4 + MODE_FMA1) { gemv_body<4, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); done = true; }
+        else if (key == 3 * 4 + MODE_FMA1) { gemv_body<3, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); done = true; }
+        else if (key == 2 * 4 + MODE_FMA1) { gemv_body<2, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); done = true; }
+    }
+    if (!done) switch (key) {
+        case 4 * 4 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 4 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 2 * 4 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 4 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 3 * 4 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
         default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
     }
     if (threadIdx.x < 64) AMQ_STAMP_AT(blk, 4);
@@ -974,11 +982,11 @@ __global__ __launch_bounds__(512, 6) void gemv_qkv_attn_kernel(const void* p_x, 
     XRegs xr;
     x_issue<PRO, NW, XCH>(a, xr);
     switch (key) {
-        case 4 * 2 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
-        case 3 * 2 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
-        case 2 * 2 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
-        case 4 * 2 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
-        case 3 * 2 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
+        case 4 * 4 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
+        case 3 * 4 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
+        case 2 * 4 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
+        case 4 * 4 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
+        case 3 * 4 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
         default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
     }
     // ---- publish this workgroup's row-tiles: drain (the storing threads sit in wave 0), barrier, one lane adds to the tickets
@@ -1034,7 +1042,7 @@ hipError_t launch_gemv_qkv_attn(GemvArgs& a, const AttnArgs& t, int* tickets, hi
     k.M = 1; k.K = a.K; k.x_stride = a.K; k.nseg = 3; k.eps = a.eps; k.rpt = rpt;
     for (int i = 0; i < 3; ++i) {
         const GemvSeg& s = a.seg[i];
-        k.wg_begin[i] = s.wg_begin; k.n_rt[i] = s.n_rt; k.key[i] = s.bits * 2 + s.mode;
+        k.wg_begin[i] = s.wg_begin; k.n_rt[i] = s.n_rt; k.key[i] = s.bits * 4 + (s.mode == MODE_FMA1 ? (int)MODE_FMA : s.mode);
         k.qweight[i] = s.qweight; k.meta[i] = s.meta; k.bias[i] = nullptr; k.residual[i] = nullptr; k.y[i] = s.y; k.y_stride[i] = s.N;
     }
     k.wg_begin[3] = 0x7fffffff;
@@ -1185,7 +1193,9 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     k.eps = a.eps; k.rpt = rpt;
     for (int i = 0; i < a.nseg; ++i) {
         const GemvSeg& s = a.seg[i];
-        k.wg_begin[i] = s.wg_begin; k.n_rt[i] = s.n_rt; k.key[i] = s.bits * 2 + s.mode;
+        // (the one-op unpack of MODE_FMA1 exists in the exact-math, group-128 bodies; elsewhere such buffers run as MODE_FMA: same results)
+        const bool has_fma1 = gp == 1 && !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR));
+        k.wg_begin[i] = s.wg_begin; k.n_rt[i] = s.n_rt; k.key[i] = s.bits * 4 + (s.mode == MODE_FMA1 && !has_fma1 ? (int)MODE_FMA : s.mode);
         k.qweight[i] = s.qweight; k.meta[i] = s.meta;
         k.bias[i] = s.bias; k.residual[i] = s.residual; k.y[i] = s.y; k.y_stride[i] = s.y_stride;
     }

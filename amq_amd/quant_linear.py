@@ -271,7 +271,7 @@ class HIPQuantLinear(nn.Module):
         group = k // scales.shape[0]                       # scales [K / group, N]
         mod = cls(bits, group, k, n, bias=bias, name=name, mode=ops.MODE_FMA)
         qn, mn = ops.repack_from_gptq(qweight.contiguous(), scales.contiguous(), zeros.contiguous(), bits, n, k, group=group)
-        mod._set_native(qn, mn, ops.MODE_FMA)
+        mod._set_native(qn, mn, ops.fma_mode_for(mn, bits))        # MODE_FMA1 where the scales allow the one-op unpack (same weights, faster GEMV)
         return mod
 
     @classmethod
@@ -283,7 +283,7 @@ class HIPQuantLinear(nn.Module):
         group = k // scales.shape[0]
         mod = cls(4, group, k, n, bias=bias, name=name, mode=ops.MODE_FMA)
         qn, mn = ops.repack_from_awq(qweight.contiguous(), scales.contiguous(), scaled_zeros.contiguous(), n, k, group=group)
-        mod._set_native(qn, mn, ops.MODE_FMA)
+        mod._set_native(qn, mn, ops.fma_mode_for(mn, 4))
         return mod
 
     def pack(self, W, scales, zeros):

@@ -56,6 +56,9 @@ extern "C" {
 /* dequantisation arithmetic carried by a native buffer's meta */
 #define AMQ_MODE_HQQ 0             /* meta = (scale, zero):  w = fp16(fp16(q - zero) * scale)   quantize.py:198 */
 #define AMQ_MODE_FMA 1             /* meta = (scale, c):     w = fp16(fma(q, scale, c))          auto_gptq_kernel.cu:206, gemv_cuda.cu:151 */
+#define AMQ_MODE_FMA1 2            /* AMQ_MODE_FMA for a buffer whose scales satisfy |scale| <= amq_fma1_scale_bound(bits): the GEMV kernel then unpacks a
+                                    * weight pair with one packed fma instead of two ops -- the same weights, bit for bit (the caller vouches for the bound:
+                                    * larger scales overflow the pre-scaled multiplier); every other kernel treats it as AMQ_MODE_FMA */
 
 /* fused x transforms of amq_gemv_grouped_f16 */
 #define AMQ_PRO_NONE     0
@@ -100,6 +103,7 @@ int amq_query(int K, int* out, int cap);
 
 /* ---- native buffer sizes ------------------------------------------------ */
 size_t amq_native_qweight_bytes(int bits, int N, int K);
+float amq_fma1_scale_bound(int bits);   /* largest |scale| of an AMQ_MODE_FMA1 buffer: 65504 / 2^18 (4 bit), 65504 / 2^20 (2, 3 bit) */
 size_t amq_native_meta_bytes(int N, int K, int group);
 
 /* ---- load-time repack: reference formats -> native ---------------------- */

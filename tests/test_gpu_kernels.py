@@ -203,6 +203,66 @@ def test_coarser_groups_are_read_bit_exact(bits, n, k, group):
 
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("n,k", [(64, 512), (4096, 4096), (1024, 11008)])
+def test_fma1_mode_is_the_fma_mode_bit_for_bit(bits, n, k):
+    """AMQ_MODE_FMA1 (reference-format buffers whose scales are within amq_fma1_scale_bound: the GEMV kernel unpacks a pair with ONE packed fma)
+    gives the bits of AMQ_MODE_FMA on every kernel: GEMV (1 / 3 rows, bias, RMSNorm and SiLU-mul prologues, residual), GEMM, dequantize; the
+    module constructors choose it from the scales, and a layer with one scale past the bound keeps AMQ_MODE_FMA"""
+    from amq_amd import ops, _lib
+    from amq_amd.hqq_format import random_hqq
+    from amq_amd.quant_linear import HIPQuantLinear
+    dev = _dev()
+    h = random_hqq(n, k, bits, seed=5 * bits + 1, bias=True)
+    w_ref = np.asarray(hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (n, k)), np.float16)
+    s_ng, z_ng = h.scale.numpy().reshape(n, k // 128), h.zero.numpy().reshape(n, k // 128)
+    qweight, scales, zeros = gptq_ref.pack(w_ref, s_ng, z_ng, bits)
+    qn, mn = ops.repack_from_gptq(torch.from_numpy(qweight).to(dev), torch.from_numpy(scales).to(dev), torch.from_numpy(zeros).to(dev), bits, n, k)
+    bound = float(_lib.load().amq_fma1_scale_bound(bits))
+    assert abs(bound - 65504.0 / (2 ** 18 if bits == 4 else 2 ** 20)) < 1e-9
+    assert ops.fma_mode_for(mn, bits) == ops.MODE_FMA1                     # (synthetic scales ~ 1e-2)
+    gen = torch.Generator().manual_seed(2)
+    bias = h.bias.to(dev)
+    for m in (1, 3):
+        x = torch.randn(m, k, generator=gen).to(torch.float16).to(dev)
+        assert torch.equal(ops.gemv(x, qn, mn, bits, ops.MODE_FMA1, n, k, bias=bias), ops.gemv(x, qn, mn, bits, ops.MODE_FMA, n, k, bias=bias))
+    x = torch.randn(2, k, generator=gen).to(torch.float16).to(dev)
+    gamma = (1.0 + 0.1 * torch.randn(k, generator=gen)).to(torch.float16).to(dev)
+    res = torch.randn(2, n, generator=gen).to(torch.float16).to(dev)
+    outs = []
+    for mode in (ops.MODE_FMA1, ops.MODE_FMA):
+        y0, y1 = torch.empty(2, n, dtype=torch.float16, device=dev), torch.empty(2, n, dtype=torch.float16, device=dev)
+        ops.gemv_grouped(x, [dict(qn=qn, mn=mn, bits=bits, mode=mode, N=n, y=y0, residual=res), dict(qn=qn, mn=mn, bits=bits, mode=mode, N=n, y=y1)], k,
+                         prologue=ops.PRO_RMSNORM, gamma=gamma, eps=1e-5)
+        y2 = torch.empty(2, n, dtype=torch.float16, device=dev)
+        ops.gemv_grouped(x, [dict(qn=qn, mn=mn, bits=bits, mode=mode, N=n, y=y2)], k, prologue=ops.PRO_SILU_MUL, x2=gamma.expand(2, k).contiguous())
+        outs.append((y0, y1, y2))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # mixed segments of one launch: FMA1 beside HQQ
+    hq = h.to(dev)
+    qh, mh = ops.repack_from_hqq(hq.W_q, hq.scale.reshape(-1), hq.zero.reshape(-1), bits, n, k)
+    ya, yb = torch.empty(2, n, dtype=torch.float16, device=dev), torch.empty(2, n, dtype=torch.float16, device=dev)
+    ops.gemv_grouped(x, [dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_FMA1, N=n, y=ya), dict(qn=qh, mn=mh, bits=bits, mode=ops.MODE_HQQ, N=n, y=yb)], k)
+    assert torch.equal(ya, ops.gemv(x, qn, mn, bits, ops.MODE_FMA, n, k)) and torch.equal(yb, ops.gemv(x, qh, mh, bits, ops.MODE_HQQ, n, k))
+    # the other kernels treat it as MODE_FMA
+    xm = torch.randn(40, k, generator=gen).to(torch.float16).to(dev)
+    assert torch.equal(ops.gemm(xm, qn, mn, bits, ops.MODE_FMA1, n, k), ops.gemm(xm, qn, mn, bits, ops.MODE_FMA, n, k))
+    assert torch.equal(ops.dequantize(qn, mn, bits, ops.MODE_FMA1, n, k), ops.dequantize(qn, mn, bits, ops.MODE_FMA, n, k))
+    # module constructors
+    mod = HIPQuantLinear.from_gptq_buffers(torch.from_numpy(qweight).to(dev), torch.from_numpy(scales).to(dev), torch.from_numpy(zeros).to(dev), bits)
+    assert mod.mode == ops.MODE_FMA1 and torch.equal(mod(x), ops.linear(x, qn, mn, bits, ops.MODE_FMA, n, k))     # (same dispatch: GEMV, or the few-row GEMM for long rows)
+    m2 = HIPQuantLinear(bits, 128, k, n).to(dev)
+    m2.load_state_dict(mod.state_dict())
+    assert m2.mode == ops.MODE_FMA1 and torch.equal(m2(x), mod(x))
+    big = scales.copy()
+    big[0, 0] = 2.0 * bound                                               # one scale past the bound: the two-op form for the whole layer
+    mod3 = HIPQuantLinear.from_gptq_buffers(torch.from_numpy(qweight).to(dev), torch.from_numpy(big).to(dev), torch.from_numpy(zeros).to(dev), bits)
+    assert mod3.mode == ops.MODE_FMA
+    want = np.asarray(gptq_ref.dequant_kernel(qweight, big, zeros, bits), np.float16)
+    assert np.array_equal(mod3.dequantize().cpu().numpy().view(np.uint16), want.view(np.uint16))
+    _assert_close(mod3(x).cpu().numpy(), linear_ref.linear_f16(x.cpu().numpy(), want), "past the bound")
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4])
 @pytest.mark.parametrize("group", [64, 32])
 @pytest.mark.parametrize("n,k", [(16, 128), (64, 512), (48, 1536), (272, 384), (4096, 4096), (1024, 11008)])
 def test_finer_groups(bits, group, n, k):

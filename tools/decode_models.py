@@ -28,7 +28,7 @@ def awq_import(m):
             s = ((0.75 + 0.5 * torch.rand(k // 128, n, device=dev, generator=gen)) * 0.5 / (k ** 0.5 * 4.6)).half()
             sz = (-(7.5 + torch.rand(k // 128, n, device=dev, generator=gen) - 0.5) * s.float()).half()
             l.qn, l.mn = ops.repack_from_awq(qweight, s, sz, n, k)
-            l.mode = ops.MODE_FMA
+            l.mode = ops.fma_mode_for(l.mn, l.bits) if os.environ.get("DECODE_FMA1", "1") != "0" else ops.MODE_FMA
 
 if os.environ.get("DECODE_MODELS"):
     cases = [c for c in cases if any(k in c[0] for k in os.environ["DECODE_MODELS"].split(","))]
