@@ -109,6 +109,39 @@ def beyond_the_metric(dev):
         torch.cuda.empty_cache()
     except Exception as e:      # noqa: BLE001
         out["decode_tokens_per_s_8_sequences"] = "failed: %r" % (e,)
+    try:
+        # the same model with its weights in the REFERENCE's kernel arithmetic, w = fma(q, s, c) with c = -(z s) (one rounding: what its GPTQ / AWQ
+        # cache files decode to, auto_gptq_kernel.cu:206, gemv_cuda.cu:151), as a swapped model loaded from those files runs: AMQ_MODE_FMA1, one packed
+        # fma per weight pair in the GEMV kernel (bit-identical to AMQ_MODE_FMA).  NOT `value`: the headline is the HQQ arithmetic
+        # (two roundings) that the parity gate's W_deq is
+        from amq_amd import ops
+        m, _, _ = build_model(dev, seed=0, max_seq=PROMPT + 96)
+        modes = set()
+        for blk in m.blocks:
+            for name in m.cfg["linear"]:
+                l = blk[name]
+                mt = l.mn.view(-1, 2)
+                mt[:, 1] = (-(mt[:, 1].float() * mt[:, 0].float())).to(torch.float16)
+                l.mode = ops.fma_mode_for(l.mn, l.bits)
+                modes.add(l.mode)
+        ids = torch.randint(0, m.vocab - 1, (PROMPT,), generator=torch.Generator().manual_seed(0)).to(dev)
+        m.prefill(ids, use_graph=False)
+        m.capture()
+        for _ in range(8):
+            m.decode_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(64):
+            m.decode_step()
+        torch.cuda.synchronize(dev)
+        out["decode_tokens_per_s_reference_format_weights"] = round(64 / (time.perf_counter() - t0), 1)
+        out["reference_format_modes"] = sorted(modes)
+        m.check()
+        assert bool(torch.isfinite(m.logits.float()).all().item())
+        del m
+        torch.cuda.empty_cache()
+    except Exception as e:      # noqa: BLE001
+        out["decode_tokens_per_s_reference_format_weights"] = "failed: %r" % (e,)
     return out
 
 
