@@ -125,6 +125,65 @@ def test_hf_llama_with_finer_group_layers(group, seq):
     assert torch.equal(t1, t2)
 
 
+def test_kernel_arithmetic_option_matches_the_reference_kernels_weights():
+    """prepare_for_inference(kernel_arithmetic=True): every swapped linear decodes to the weights the reference's GPTQ kernels decode to for the same
+    HQQ layer (patch_hqq_to_gptq's buffers through the oracle's restatement of the kernel dequant), bit for bit; the HF model on those weights gives the
+    same logits to fp16 rounding; the default (HQQ arithmetic) model is within one weight ulp of it; greedy tokens of the fused and plain swaps agree"""
+    from amq_amd import ops
+    from amq_amd.hqq_format import random_hqq
+    from amq_amd.patching import prepare_for_inference
+    from amq_amd.quant_linear import HIPQuantLinear
+    from oracle import hqq_ref, gptq_ref
+    model, ref = _quantize_linears(_tiny_llama(2))
+    # the oracle side: GPTQLinear.pack(W_deq, scales, zeros) -> kernel dequant, per layer (same seeds as _quantize_linears)
+    names = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+    bits_cycle, i = (4, 2, 3, 3, 2, 4, 3), 0
+    kernel_w = {}
+    for li, rlayer in enumerate(ref.model.layers):
+        for parent in (rlayer.self_attn, rlayer.mlp):
+            for name in names:
+                lin = getattr(parent, name, None)
+                if lin is None:
+                    continue
+                n, k = lin.weight.shape
+                bits = bits_cycle[i % 7]
+                h = random_hqq(n, k, bits, seed=100 + i)
+                i += 1
+                w_deq = np.asarray(hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (n, k)), np.float16)
+                qw, sc, zr = gptq_ref.pack(w_deq, h.scale.numpy().reshape(n, -1), h.zero.numpy().reshape(n, -1), bits)
+                wk = np.asarray(gptq_ref.dequant_kernel(qw, sc, zr, bits), np.float16)
+                kernel_w[(li, name)] = wk
+                lin.weight.data = torch.from_numpy(wk).to("cuda:0")
+    prepare_for_inference(model, backend="hip", kernel_arithmetic=True)
+    mods = {(li, m.name): m for li, layer in enumerate(model.model.layers) for m in layer.modules() if isinstance(m, HIPQuantLinear)}
+    assert len(mods) == 14 and all(m.mode in (ops.MODE_FMA, ops.MODE_FMA1) for m in mods.values())
+    for key, m in mods.items():
+        assert np.array_equal(m.dequantize().cpu().numpy().view(np.uint16), kernel_w[key].view(np.uint16)), key
+    ids = torch.randint(0, 1000, (1, 5), generator=torch.Generator().manual_seed(5)).to("cuda:0")
+    with torch.inference_mode():
+        y = model(ids).logits.float()
+        y_ref = ref(ids).logits.float()
+    assert (y - y_ref).abs().max() <= 2e-3 * y_ref.abs().max()
+    model2, _ = _quantize_linears(_tiny_llama(2))
+    prepare_for_inference(model2, backend="hip", group_siblings=False, fuse_mlp=False, fuse_layers=False, kernel_arithmetic=True)
+    model3, _ = _quantize_linears(_tiny_llama(2))
+    prepare_for_inference(model3, backend="hip")                              # HQQ arithmetic: a weight ulp away
+    with torch.inference_mode():
+        t1 = model.generate(ids, min_new_tokens=6, max_new_tokens=6, do_sample=False, num_beams=1)
+        t2 = model2.generate(ids, min_new_tokens=6, max_new_tokens=6, do_sample=False, num_beams=1)
+        y3 = model3(ids).logits.float()
+    assert torch.equal(t1, t2)
+    assert (y3 - y).abs().max() <= 1e-2 * y.abs().max() and not torch.equal(y3, y)
+    # idempotent, and a converted module keeps working after a state_dict round trip
+    m = next(iter(mods.values()))
+    before = m.meta.clone()
+    assert m.to_kernel_arithmetic() is m and torch.equal(m.meta, before)
+    m2 = HIPQuantLinear(m.bits, m.group_size, m.infeatures, m.outfeatures).to("cuda:0")
+    m2.load_state_dict({k: v for k, v in m.state_dict().items() if k != "weight"})      # (the dummy .weight HF code queries is not a buffer of the module)
+    x = torch.randn(2, m.infeatures, device="cuda:0").half()
+    assert m2.mode == m.mode and torch.equal(m2(x), m(x))
+
+
 def test_deferred_norm_that_is_not_consumed_raises():
     """HIPRMSNorm hands its raw input on; if the grouped launch it was fused into never runs, the next forward fails loudly"""
     from amq_amd.patching import prepare_for_inference
