@@ -19,7 +19,8 @@ AMQ_OK = 0
 MODE_HQQ, MODE_FMA, MODE_FMA1 = 0, 1, 2
 PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
-MATH_EXACT, MATH_LINEAR = 0, 1
+MATH_DEFAULT, MATH_LINEAR, MATH_GROUPSCALE, MATH_EXACT = 0, 1, 2, 3
+ABI_VERSION = 500            # include/amq_hip.h AMQ_VERSION these bindings mirror (checked at load)
 GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, GEMM_WS, GEMM_DEQ = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -49,6 +50,7 @@ class GemvOpts(ctypes.Structure):
 # name -> (restype, argtypes); must list every symbol include/amq_hip.h declares
 SIGNATURES = {
     "amq_version": (_i, []),
+    "amq_default_gemv_math": (_i, []),
     "amq_last_error": (ctypes.c_char_p, []),
     "amq_query": (_i, [_i, ctypes.POINTER(_i), _i]),
     "amq_native_qweight_bytes": (_sz, [_i, _i, _i]),
@@ -136,6 +138,9 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
+    if lib.amq_version() != ABI_VERSION:
+        raise AmqError(f"{LIB_PATH} reports ABI version {lib.amq_version()}, these bindings were written against {ABI_VERSION} "
+                       "(include/amq_hip.h AMQ_VERSION): rebuild with `make -C amq_amd/csrc`")
     _lib = lib
     return lib
 

@@ -120,6 +120,11 @@ int amq_dequantize_hqq_f16(int bits, const void* W_q, const void* scale, const v
     return check_hip(amq::launch_dequantize_hqq(bits, W_q, scale, zero, N, K, W, (hipStream_t)stream, group), "dequantize_hqq");
 }
 
+#ifndef AMQ_GEMV_DEFAULT_MATH
+#define AMQ_GEMV_DEFAULT_MATH AMQ_MATH_EXACT
+#endif
+int amq_default_gemv_math(void) { return AMQ_GEMV_DEFAULT_MATH; }
+
 int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const void* x2, const void* gamma,
                          float eps, int prologue, int M, int K, int group, int x_stride, const amq_gemv_opts* opts,
                          void* stream) {
@@ -131,7 +136,9 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
     amq_gemv_opts o{};                                   // all zero = defaults
     if (opts) o = *opts;
-    if (o.math != AMQ_MATH_EXACT && o.math != AMQ_MATH_LINEAR) return fail(AMQ_EINVAL, "opts.math must be AMQ_MATH_EXACT or AMQ_MATH_LINEAR");
+    if (o.math < AMQ_MATH_DEFAULT || o.math > AMQ_MATH_EXACT)
+        return fail(AMQ_EINVAL, "opts.math must be AMQ_MATH_DEFAULT, AMQ_MATH_EXACT, AMQ_MATH_GROUPSCALE or AMQ_MATH_LINEAR");
+    if (o.math == AMQ_MATH_DEFAULT) o.math = amq_default_gemv_math();
     if (o.waves != 0 && o.waves != 4 && o.waves != 8 && o.waves != 16) return fail(AMQ_EINVAL, "opts.waves must be 0, 4, 8 or 16");
     if (o.depth != 0 && o.depth != 2 && o.depth != 4) return fail(AMQ_EINVAL, "opts.depth must be 0, 2 or 4");
     if (o.rpt < 0 || o.rpt > 64) return fail(AMQ_EINVAL, "opts.rpt (row-tiles per workgroup) must be 0..64");
@@ -150,12 +157,13 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     }
     a.nseg = nseg; a.M = M; a.K = K; a.x_stride = x_stride ? x_stride : K;
     a.x = x; a.x2 = x2; a.gamma = gamma; a.eps = eps; a.prologue = prologue;
-    a.flags = (o.dot ? amq::GEMV_FLAG_DOT : 0) | (o.math == AMQ_MATH_LINEAR ? amq::GEMV_FLAG_LINEAR : 0);
+    a.flags = (o.dot ? amq::GEMV_FLAG_DOT : 0) | (o.math == AMQ_MATH_LINEAR ? amq::GEMV_FLAG_LINEAR : 0) |
+              (o.math == AMQ_MATH_GROUPSCALE ? amq::GEMV_FLAG_GS : 0);
     a.force_waves = o.waves;
     a.force_depth = o.depth;
     a.force_rpt = o.rpt;
     a.gp = amq::meta_pairs(group);
-    if (a.gp > 1 && (o.dot || o.math != AMQ_MATH_EXACT || o.depth == 4))
+    if (a.gp > 1 && (o.dot || o.math == AMQ_MATH_LINEAR || o.depth == 4))
         return fail(AMQ_EINVAL, "groups of %d: the GEMV kernel's default form only (opts.math = AMQ_MATH_EXACT, opts.dot = 0, opts.depth = 0 / 2)", group);
     return check_hip(amq::launch_gemv(a, (hipStream_t)stream), "gemv");
 }

@@ -294,6 +294,73 @@ __device__ __forceinline__ void dequant_lane_fma1(const uint32_t* w, h2 meta, h2
     }
 }
 
+// ---------------------------------------------------------------------------
+// Group-scale unpack (MATH_GROUPSCALE of the GEMV kernel, MODE_HQQ): only the FIRST of the reference's two roundings is taken per weight,
+//     d = RN16((q - z) * 2^E)          one packed fma on the subnormal field, as above,
+// the tile's four MFMAs sum x * d in fp32 and the scale is applied ONCE per (row, group) to that sum:  y += (s * 2^-E) * sum_k x_k d_k.
+// What is dropped is the second rounding, RN16(d * s): one fp16 rounding of each weight (<= 2^-11 relative, ~2e-4 of rms(y) on the output;
+// the reference's own CUDA kernels round once as well, auto_gptq_kernel.cu:206-218).  Because the scale no longer has to be an fp16
+// constant, E is free -- and with E = -9 a field may stay where the packing put it: every field that lies inside the fp16 mantissa
+// (bit SH + BITS <= 10 of its half) is a subnormal q * 2^(SH-24) and takes the multiplier 2^(E+24-SH) <= 2^15 straight from a scalar
+// register.  4 bit: slots 0, 1 of u and of u >> 8; 3 bit: slots 0..2 of u, 3..4 from u >> 9; 2 bit: slots 0..4 of u, 5..7 from u >> 10 --
+// ONE shift per dword instead of one per pair, and + fma per pair: 6.5 VALU cycles per pair instead of 12.
+// d is the exact first rounding wherever (q - z) * 2^-9 and z * 2^-9 are normal halves (|q - z|, |z| >= 2^-5); below that the small value
+// (z, or q - z) is taken to a multiple of 2^-15 quantization steps first -- 2^-16 of a step off, which at worst moves the first rounding
+// by one fp16 ulp of (q - z) (tests/test_gpu_kernels.py::test_matmul_weights_equal_oracle_weights bounds both).
+constexpr int GS_E = -9;
+template <int BITS, int SH>
+__device__ __forceinline__ h2 gs_pair(uint32_t t, h2 zc) {
+    constexpr uint32_t fm = (1u << BITS) - 1u;
+    constexpr uint32_t msk = (fm << SH) | ((fm << SH) << 16);
+    constexpr int B = GS_E + 24 - SH;
+    static_assert(B <= 15 && B >= 0 && SH + BITS <= 10, "field must sit in the mantissa");
+    return __builtin_elementwise_fma(as_h2(t & msk), bcast((_Float16)(float)(1 << B)), zc);
+}
+// zc for gs_pair: -(z * 2^E)
+__device__ __forceinline__ h2 gs_zero(h2 meta) { return bcast(meta.y) * bcast((_Float16)(-1.0f / (float)(1 << (-GS_E)))); }
+// the fp32 factor of a tile's sum: s * 2^-E
+__device__ __forceinline__ float gs_scale(h2 meta) { return (float)meta.x * (float)(1 << (-GS_E)); }
+
+template <int BITS>
+__device__ __forceinline__ void dequant_lane_gs(const uint32_t* w, h2 zc, h2* out) {
+    if (BITS == 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t u = w[t], v = u >> 8;
+            out[4 * t + 0] = gs_pair<4, 0>(u, zc);
+            out[4 * t + 1] = gs_pair<4, 4>(u, zc);
+            out[4 * t + 2] = gs_pair<4, 0>(v, zc);
+            out[4 * t + 3] = gs_pair<4, 4>(v, zc);
+        }
+    } else if (BITS == 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const uint32_t u = w[d], v = u >> 10;
+            out[8 * d + 0] = gs_pair<2, 0>(u, zc);
+            out[8 * d + 1] = gs_pair<2, 2>(u, zc);
+            out[8 * d + 2] = gs_pair<2, 4>(u, zc);
+            out[8 * d + 3] = gs_pair<2, 6>(u, zc);
+            out[8 * d + 4] = gs_pair<2, 8>(u, zc);
+            out[8 * d + 5] = gs_pair<2, 0>(v, zc);
+            out[8 * d + 6] = gs_pair<2, 2>(v, zc);
+            out[8 * d + 7] = gs_pair<2, 4>(v, zc);
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t u = w[d], v = u >> 9;
+            out[5 * d + 0] = gs_pair<3, 0>(u, zc);
+            out[5 * d + 1] = gs_pair<3, 3>(u, zc);
+            out[5 * d + 2] = gs_pair<3, 6>(u, zc);
+            out[5 * d + 3] = gs_pair<3, 0>(v, zc);
+            out[5 * d + 4] = gs_pair<3, 3>(v, zc);
+        }
+        // pair 15: value bit b of the (low, high) weight = bit (15, 31) of dword b -> bits 7+b
+        const uint32_t e = ((w[0] >> 8) & 0x00800080u) | ((w[1] >> 7) & 0x01000100u) | ((w[2] >> 6) & 0x02000200u);
+        out[15] = gs_pair<3, 7>(e, zc);
+    }
+}
+
 // One pair of a lane's tile (compile-time pair index P = 4t + p), same arithmetic as dequant_lane_sd: lets a kernel spread
 // the unpack of a tile over its MFMA steps instead of doing all 16 pairs in one block.
 template <int BITS, int MODE, int P>

@@ -1,0 +1,5 @@
+// amq_gemv_pro1.hip -- the GEMV kernels with prologue PRO_RMSNORM, groups of 128 (amq_gemv_body.cuh)
+#include "amq_gemv_body.cuh"
+namespace amq {
+template hipError_t launch_pro<PRO_RMSNORM>(const GemvKArgs&, int, int, int, int, size_t, hipStream_t);
+}

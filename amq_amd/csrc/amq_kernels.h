@@ -73,7 +73,8 @@ struct GemvArgs {
     int force_rpt;         // 0 = auto, else row-tiles per workgroup
     int gp;                // (scale, zero) pairs per (row, tile) of every segment's meta: 0 / 1 (groups of 128), 2 (64), 4 (32)
 };
-enum { GEMV_FLAG_DOT = 1, GEMV_FLAG_LINEAR = 2, GEMV_FLAG_RS128 = 4 /* internal: half-size cross-wave sum buffer (<= 8 rows) */ };
+enum { GEMV_FLAG_DOT = 1, GEMV_FLAG_LINEAR = 2, GEMV_FLAG_RS128 = 4 /* internal: half-size cross-wave sum buffer (<= 8 rows) */,
+       GEMV_FLAG_GS = 8 /* group-scale arithmetic for the two-rounding (HQQ) segments */ };
 constexpr int GEMV_MAX_M = 16;
 
 size_t gemv_lds_bytes(int M, int K, int copies);

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (MODE_HQQ, MODE_FMA, MODE_FMA1, PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL, Segment, GemvOpts, EngineBlock, EngineLinear,  # noqa: F401
-                   GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, GEMM_WS, GEMM_DEQ, MATH_EXACT, MATH_LINEAR)
+                   GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, GEMM_WS, GEMM_DEQ, MATH_DEFAULT, MATH_EXACT, MATH_LINEAR, MATH_GROUPSCALE)
 
 GROUP = 128
 
@@ -432,6 +432,11 @@ def linear(x, qn, mn, bits, mode, N, K, bias=None):
 # Default launch options of the grouped GEMV (None = the library's defaults: exact math, auto geometry).  Only tools/
 # set this (explicitly, from their own command lines) to run whole-model A/B experiments; no environment variable does.
 DEFAULT_GEMV_OPTS = None
+
+
+def default_gemv_math():
+    """the arithmetic an ``opts=None`` GEMV launch runs in this build of the library (MATH_EXACT or MATH_GROUPSCALE)"""
+    return int(_lib.load().amq_default_gemv_math())
 
 
 def gemv_max_rows(K):

@@ -45,7 +45,8 @@
 extern "C" {
 #endif
 
-#define AMQ_VERSION 300            /* 0.3.0 */
+#define AMQ_VERSION 500            /* 0.5.0: amq_gemv_opts.math renumbered (0 = the build's default), amq_default_gemv_math added; the decode-engine and
+                                    * fused q/k/v-attention entry points live in libamq_hip_ab.so (include/amq_hip_ab.h) since 0.4 */
 
 #define AMQ_OK            0
 #define AMQ_EINVAL       -1        /* bad argument (null pointer, bits, mode ...) */
@@ -70,17 +71,28 @@ extern "C" {
 int amq_version(void);
 const char* amq_last_error(void);
 
-/* GEMV arithmetic.  EXACT reproduces the reference's dequantized fp16 weights (two fp16 roundings per
- * weight) and accumulates x*w in fp32.  LINEAR skips the per-weight roundings: y = sum_g s_g*(sum_k x_k q_k
- * - z_g sum_k x_k) in fp32 (scale / zero applied once per 128-group) -- the real-valued dequant; it is
- * ~3x cheaper in VALU work and lands within ~1e-3 of the output rms of the reference result (tests). */
-#define AMQ_MATH_EXACT  0
-#define AMQ_MATH_LINEAR 1
+/* GEMV arithmetic (MODE_HQQ buffers, whose reference dequant has two fp16 roundings per weight: quantize.py:198).
+ *   EXACT      both roundings per weight, bit-identical weights to Quantizer.dequantize; x*w accumulated in fp32.
+ *   GROUPSCALE (opt-in) the first rounding exactly as EXACT, d = fp16((q - z) * 2^-9); the scale is applied once per (row, 128-group) in fp32
+ *              after the tile's MFMAs: y += (s * 2^9) * sum_k x_k d_k.  One fp16 rounding per weight is not taken (<= 2^-11 relative per weight):
+ *              measured 3.2e-4 of rms(y) rms from the reference result, worst element 0.93 of the parity bar |dy| <= 1e-3 |y| + 1e-3 rms(y), and
+ *              2 fp16 ulps -- past the bar -- on a few elements per 10^4 when a bias add rounds a second time (profiles/r05_gemv_groupscale.txt):
+ *              not the default for that reason.  6.5 instead of 12 VALU cycles per weight pair: +5 % decode tokens/s on Llama-2-7B, +13 % on 70B.
+ *              The reference's own CUDA kernels round once per weight too (auto_gptq_kernel.cu:206-218).  Buffers in AMQ_MODE_FMA / _FMA1 (one
+ *              rounding by definition) and groups of 64 / 32 run their exact forms under it.
+ *   LINEAR     no per-weight roundings at all: y = sum_g s_g * (sum_k x_k q_k - z_g sum_k x_k) in fp32 -- the real-valued dequant (opt-in;
+ *              ~3.6e-4 of rms(y) rms, beyond the parity bar at its worst elements).
+ *   DEFAULT    what amq_default_gemv_math() returns for this build of the library. */
+#define AMQ_MATH_DEFAULT    0
+#define AMQ_MATH_LINEAR     1
+#define AMQ_MATH_GROUPSCALE 2
+#define AMQ_MATH_EXACT      3
+int amq_default_gemv_math(void);   /* AMQ_MATH_EXACT or AMQ_MATH_GROUPSCALE */
 
 /* Per-call launch options of amq_gemv_grouped_f16 (host struct; NULL or all-zero = defaults).  There is no
  * process-wide option state in the library: what a call computes depends on its arguments only. */
 typedef struct amq_gemv_opts {
-    int math;    /* AMQ_MATH_EXACT (default) or AMQ_MATH_LINEAR */
+    int math;    /* AMQ_MATH_DEFAULT (0), _EXACT, _GROUPSCALE or _LINEAR */
     int waves;   /* A/B: waves per workgroup, 0 = auto, 4, 8 or 16 */
     int depth;   /* A/B: tile loads in flight per wave, 0 = auto, 2 or 4 */
     int rpt;     /* A/B: row-tiles walked by one workgroup, 0 = auto, 1..64 */

@@ -38,7 +38,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_version_sizes_and_validation():
     lib = _lib.load()
-    assert lib.amq_version() == 300
+    assert lib.amq_version() == 500 == _lib.ABI_VERSION
     # native sizes: N*K*bits/8 payload, 4 B of (scale, zero) per (row, group)
     for bits in (2, 3, 4):
         assert lib.amq_native_qweight_bytes(bits, 4096, 4096) == 4096 * 4096 * bits // 8
@@ -55,7 +55,7 @@ def test_version_sizes_and_validation():
     assert rc == -2 and b"amq_gemm_f16" in lib.amq_last_error()
     # per-call options are validated too (host struct; the library holds no option state)
     seg = (_lib.Segment * 1)(_lib.Segment(16, 16, None, None, 16, 4096, 4, 0, 0))
-    for bad in (_lib.GemvOpts(math=2), _lib.GemvOpts(waves=5), _lib.GemvOpts(depth=3), _lib.GemvOpts(rpt=65)):
+    for bad in (_lib.GemvOpts(math=4), _lib.GemvOpts(math=-1), _lib.GemvOpts(waves=5), _lib.GemvOpts(depth=3), _lib.GemvOpts(rpt=65)):
         rc = lib.amq_gemv_grouped_f16(seg, 1, one, None, None, 0.0, 0, 1, 4096, 128, 0, ctypes.byref(bad), None)
         assert rc == -1 and b"opts." in lib.amq_last_error()
     assert not hasattr(lib, "amq_set_option")

@@ -18,6 +18,16 @@ def _dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def _exact_math():
+    """the A/B kernels of this module carry the EXACT two-rounding bodies only: the step they are compared with bit for bit runs the same arithmetic"""
+    from amq_amd import ops
+    old = ops.DEFAULT_GEMV_OPTS
+    ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(math=ops.MATH_EXACT)
+    yield
+    ops.DEFAULT_GEMV_OPTS = old
+
+
 def _pair(cfg, al, max_seq, seed, grid=0):
     """(engine runner, five-launch runner) over the same synthetic weights"""
     from amq_amd.llama import QuantLlama
@@ -36,7 +46,7 @@ def _step_ref(mr, use_graph):
     """the five-launch step with 16-wave GEMV workgroups (what the engine's stages are)"""
     from amq_amd import ops
     old = ops.DEFAULT_GEMV_OPTS
-    ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(waves=16)
+    ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(waves=16, math=ops.MATH_EXACT)
     try:
         mr.decode_step(use_graph=use_graph)
     finally:

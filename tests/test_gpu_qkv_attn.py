@@ -13,6 +13,16 @@ def _dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def _exact_math():
+    """the A/B kernels of this module carry the EXACT two-rounding bodies only: the step they are compared with bit for bit runs the same arithmetic"""
+    from amq_amd import ops
+    old = ops.DEFAULT_GEMV_OPTS
+    ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(math=ops.MATH_EXACT)
+    yield
+    ops.DEFAULT_GEMV_OPTS = old
+
+
 def _pair(cfg, al, max_seq, seed):
     from amq_amd.llama import QuantLlama
     mf = QuantLlama(cfg, al, device="cuda:0", max_seq=max_seq, seed=seed, engine=False)
