@@ -70,7 +70,7 @@ int amq_query(int K, int* out, int cap) {
     int vals[4];
     int maxm = 0;
     for (int m = 1; m <= amq::GEMV_MAX_M; ++m)
-        if (amq::gemv_lds_bytes(m, K, 1) <= LDS_LIMIT) maxm = m;
+        if (amq::gemv_min_lds_bytes(m, K, true) <= LDS_LIMIT) maxm = m;
     vals[0] = maxm;                 // largest M amq_gemv_f16 accepts for this K
     vals[1] = (int)LDS_LIMIT;
     vals[2] = amq::TILE_N;
@@ -142,7 +142,8 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     if (o.waves != 0 && o.waves != 4 && o.waves != 8 && o.waves != 16) return fail(AMQ_EINVAL, "opts.waves must be 0, 4, 8 or 16");
     if (o.depth != 0 && o.depth != 2 && o.depth != 4) return fail(AMQ_EINVAL, "opts.depth must be 0, 2 or 4");
     if (o.rpt < 0 || o.rpt > 64) return fail(AMQ_EINVAL, "opts.rpt (row-tiles per workgroup) must be 0..64");
-    if (M > amq::GEMV_MAX_M || amq::gemv_lds_bytes(M, K, 1) > LDS_LIMIT)
+    const bool plain_form = !o.dot && o.math != AMQ_MATH_LINEAR && o.depth != 4 && amq::meta_pairs(group) == 1 && o.waves != 4;
+    if (M > amq::GEMV_MAX_M || amq::gemv_min_lds_bytes(M, K, plain_form) > LDS_LIMIT)
         return fail(AMQ_ESHAPE, "M=%d rows of K=%d do not fit LDS for the GEMV path; use amq_gemm_f16", M, K);
     amq::GemvArgs a{};
     for (int i = 0; i < nseg; ++i) {

@@ -19,6 +19,17 @@ size_t gemv_lds_bytes(int M, int K, int nw) {
     return xbytes + xg + red;
 }
 
+// the <= 8-row kernels (RS = 128): half the cross-wave sum buffer, no per-group sums
+size_t gemv_lds_bytes_rows(int M, int K, int nw) {
+    const size_t xbytes = (((size_t)M * (K + XPAD) * 2) + 15) & ~(size_t)15;
+    return xbytes + (size_t)2 * nw * (M <= 4 ? 64 : 128) * 4;
+}
+// smallest LDS allocation some launch form of an M-row GEMV needs (plain: default arithmetic and geometry, groups of 128)
+size_t gemv_min_lds_bytes(int M, int K, bool plain) {
+    if (plain && M > 1 && M <= 8) return gemv_lds_bytes_rows(M, K, 16);
+    return gemv_lds_bytes(M, K, 1);
+}
+
 int gemv_pick_waves(int total_rt, int K) {
     // measured on MI355X (tools/sweep1.sh, profiles/r01b_gemv_sweep.txt): 8 waves x 2 tiles in flight is the best or
     // within 3% of it whenever a wave gets >= 4 tiles of a row-tile or there is more than one workgroup per CU; one
@@ -58,12 +69,17 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     const int gp = a.gp > 1 ? a.gp : 1;                    // meta pairs per tile (groups of 64 / 32: 2 / 4)
     if (gp != 1 && gp != 2 && gp != 4) return hipErrorInvalidValue;
     if (gp > 1 && ((a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) || a.force_depth == 4)) return hipErrorInvalidValue;   // (the C ABI says so first)
-    bool rs128 = false;
-    if (!a.force_waves && a.M > 1 && nw == 8) {
-        const bool plain = !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4 && gp == 1;
-        const size_t lds128 = gemv_lds_bytes(a.M, a.K, 8) - 2 * 8 * 128 * 4;
-        if (plain && a.M <= 8 && 3 * lds128 <= 160 * 1024) rs128 = true;
-        else if (3 * gemv_lds_bytes(a.M, a.K, 8) > 160 * 1024) nw = 16;
+    // launches of 2 .. 8 rows (sequences decoded together) take the kernels with the half-size cross-wave sum buffer (RS = 128) and the
+    // register-held row staging (x_issue_rows): three 8-wave workgroups per CU while their LDS fits (K = 4096: up to 5 rows), else one 16-wave
+    // workgroup (TWO 8-wave workgroups measured slower at 6 - 8 rows: profiles/r02_decode_batch.txt, r05_decode_batch.txt)
+    bool rs128 = false, rs64 = false;
+    const bool plain = !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4 && gp == 1;
+    if (a.M > 1 && a.M <= 8 && plain && nw != 4) {
+        rs128 = a.M > 4;
+        rs64 = !rs128;
+        if (!a.force_waves && nw == 8 && 2 * gemv_lds_bytes_rows(a.M, a.K, 8) > 160 * 1024) nw = 16;
+    } else if (!a.force_waves && a.M > 1 && nw == 8 && 3 * gemv_lds_bytes(a.M, a.K, 8) > 160 * 1024) {
+        nw = 16;
     }
     // 4096 < K <= 8192 at one row (13B / 70B hidden sizes): 8-wave workgroups staging two x chunks per thread, two per CU
     // (~90 VGPRs), instead of one 16-wave workgroup -- 13B 464 -> 485 tokens/s, 70B 126.5 -> 133.  The same trade for
@@ -77,7 +93,8 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     // `rpt` row-tiles
     int rpt = a.force_rpt;
     if (rpt <= 0) {
-        const int target = mid_k ? 512 : nw == 16 ? 256 : 256 * 24 / nw;
+        const bool two_per_cu = (rs128 || rs64) && nw == 8 && 3 * gemv_lds_bytes_rows(a.M, a.K, 8) > 160 * 1024;       // (forced 8-wave workgroups whose rows leave room for two)
+        const int target = (mid_k || two_per_cu) ? 512 : nw == 16 ? 256 : 256 * 24 / nw;
         rpt = (total_rt + target - 1) / target;
         if (rpt < 1) rpt = 1;
     }
@@ -90,7 +107,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     }
     const bool lin = (a.flags & GEMV_FLAG_LINEAR) && !((a.flags & GEMV_FLAG_DOT) && a.M == 1);
     (void)lin; (void)mask;
-    const size_t lds = gemv_lds_bytes(a.M, a.K, a.M > 1 ? nw : 16) - (rs128 ? 2 * 8 * 128 * 4 : 0);     // (one-row launches keep the allocation they were tuned with)
+    const size_t lds = (rs128 || rs64) ? gemv_lds_bytes_rows(a.M, a.K, nw) : gemv_lds_bytes(a.M, a.K, a.M > 1 ? nw : 16);     // (one-row launches keep the allocation they were tuned with)
     GemvKArgs k{};
     k.x = a.x; k.x2 = a.x2; k.gamma = a.gamma;
     k.M = a.M; k.K = a.K; k.x_stride = a.x_stride; k.nseg = a.nseg;
@@ -121,9 +138,9 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
         }
     }
     switch (a.prologue) {
-        case PRO_NONE: return launch_pro<PRO_NONE>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0), a.force_depth, nw, wg, lds, st);
-        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0), a.force_depth, nw, wg, lds, st);
-        default: return launch_pro<PRO_SILU_MUL>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0), a.force_depth, nw, wg, lds, st);
+        case PRO_NONE: return launch_pro<PRO_NONE>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0), a.force_depth, nw, wg, lds, st);
+        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0), a.force_depth, nw, wg, lds, st);
+        default: return launch_pro<PRO_SILU_MUL>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0), a.force_depth, nw, wg, lds, st);
     }
 }
 

@@ -293,6 +293,152 @@ __device__ __forceinline__ void x_finish(const GemvHot& a, const XRegs& xr, _Flo
     // (the caller's barrier publishes xl; red[] is next written only after that barrier)
 }
 
+// rows a kernel's cross-wave sum buffer (RS floats per wave = rows x 16 columns) is laid out for: 256 -> any M <= 16 (generic staging beyond one
+// row), 128 -> the 5 .. 8-row kernels, 64 -> the 2 .. 4-row kernels (the last two take their rows by LDS-DMA)
+template <int RS> struct RowsCfg { static constexpr int MRMAX = RS == 64 ? 4 : RS == 128 ? 8 : 1; };
+
+// Several rows (2 .. 8 sequences decoded together): the rows go from global memory STRAIGHT INTO LDS (global_load_lds_dwordx4, 1 KB per wave
+// instruction, no registers), issued before the weight ring is primed like the one-row path's loads -- all of a launch's activation reads are
+// independent and the oldest entries of the vector-memory queue.  After the ring is primed a wave waits for exactly its own transfers (counted
+// vmcnt: the ring's loads are the only younger operations), reads ITS chunks back from LDS -- thread t owns column chunk t (+ i * THREADS) of every
+// row, the bytes its own wave transferred, so no barrier is needed before the read-back -- applies the fused transform in place and the caller's
+// barrier publishes x.  (The generic stage_x walks its chunks in dependent load -> use iterations BEHIND the primed ring and passes over x twice:
+// +2.6 / +4.5 / +9 us per launch at 2 / 4 / 8 rows; holding the rows in registers instead costs 16 - 64 VGPRs across the ring's priming and pushes
+// the kernel out of its three-workgroups-per-CU budget: profiles/r05_decode_batch.txt.)  Per row the sums run in the one-row path's order: a
+// sequence's RMSNorm is the same bits alone or in a batch.  SiLU*mul: the gate rows are transferred, the up rows are plain loads issued behind the
+// primed ring (they arrive with the first weight tiles) four rows at a time.
+// (inline asm, not __builtin_amdgcn_global_load_lds: see amq_gemm_ring.hip)
+__device__ __forceinline__ void gv_glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+
+template <int PRO, int NW, int XCH>
+__device__ __forceinline__ void x_dma_rows(const GemvHot& a, _Float16* xl, int xs, XRegs& xr) {
+    constexpr int THREADS = NW * 64;
+    const int chunks = a.K >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)xl;
+    for (int m = 0; m < a.M; ++m) {
+        const _Float16* row = (const _Float16*)a.x + (size_t)m * a.x_stride;
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int c = (int)threadIdx.x + i * THREADS;
+            if (c < chunks) gv_glds16(row, 16u * (unsigned)c, lds0 + (unsigned)(m * xs) * 2u + (unsigned)(i * THREADS + wave * 64) * 16u);
+        }
+    }
+    if (PRO == PRO_RMSNORM) {
+        const int last = chunks - 1;
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            int c = (int)threadIdx.x + i * THREADS;
+            c = c < last ? c : last;
+            xr.w[i] = *(const h8*)((const _Float16*)a.gamma + 8 * c);
+        }
+    }
+}
+
+// NRING: vector-memory operations the wave has issued since x_dma_rows (the primed ring's loads)
+template <int PRO, int NW, int XCH, int NRING, int MR>
+__device__ __forceinline__ void x_finish_dma(const GemvHot& a, const XRegs& xr, _Float16* xl, float* red, int xs) {
+    constexpr int THREADS = NW * 64;
+    static_assert(NRING >= 0 && NRING <= 15, "counted wait");
+    const int tid = threadIdx.x;
+    const int chunks = a.K >> 3;
+    if (PRO == PRO_RMSNORM) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRING) : "memory");      // (gamma's loads are older than the ring too)
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRING) : "memory");
+    if (PRO == PRO_NONE) return;
+    if (PRO == PRO_RMSNORM) {
+        // all rows side by side (MR = the kernel's row bound, rows >= M predicated off by uniform branches): the rows' LDS reads, square sums and
+        // wave reductions are independent chains; one row at a time they cost ~0.35 us each (profiles/r05_decode_batch.txt)
+        h8 v[MR * XCH];
+        float ss[MR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            ss[m] = 0.f;
+            if (m < a.M) {
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) {
+                    const int c = tid + i * THREADS;
+                    if (c < chunks) v[m * XCH + i] = *(const h8*)(xl + (size_t)m * xs + 8 * c);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < a.M) {
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) {
+                    if (tid + i * THREADS < chunks) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { float f = (float)v[m * XCH + i][e]; ss[m] += f * f; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < a.M) {
+                ss[m] = wave_sum(ss[m]);
+                if ((tid & 63) == 0) red[m * NW + (tid >> 6)] = ss[m];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < a.M) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tot += red[m * NW + w];
+                const float rstd = rsqrtf(tot / (float)a.K + a.eps);
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) {
+                    const int c = tid + i * THREADS;
+                    if (c < chunks) {
+                        h8 r;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { _Float16 nrm = (_Float16)((float)v[m * XCH + i][e] * rstd); r[e] = xr.w[i][e] * nrm; }
+                        *(h8*)(xl + (size_t)m * xs + 8 * c) = r;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // SiLU * mul: x = fp16(fp16(silu(gate)) * up)
+    const int last = chunks - 1;
+    for (int m0 = 0; m0 < a.M; m0 += 4) {
+        h8 up[4 * XCH];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mm = m0 + j < a.M ? m0 + j : a.M - 1;
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                int c = tid + i * THREADS;
+                c = c < last ? c : last;
+                up[j * XCH + i] = *(const h8*)((const _Float16*)a.x2 + (size_t)mm * a.x_stride + 8 * c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (m0 + j < a.M) {
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) {
+                    const int c = tid + i * THREADS;
+                    if (c < chunks) {
+                        _Float16* p = xl + (size_t)(m0 + j) * xs + 8 * c;
+                        const h8 g = *(const h8*)p;
+                        h8 r;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { _Float16 sg = (_Float16)silu_f((float)g[e]); r[e] = sg * up[j * XCH + i][e]; }
+                        *(h8*)p = r;
+                    }
+                }
+            }
+        }
+    }
+    // (the caller's barrier publishes xl; red[] is next written only after that barrier)
+}
+
 // ---------------------------------------------------------------- epilogue
 __device__ __forceinline__ void store_out(const SegOut& s, int m, int n, float acc) {
     _Float16 y = (_Float16)acc;                                   // fp16(matmul)
@@ -356,7 +502,7 @@ __device__ __forceinline__ void unpack_lane_sub(const uint32_t* w, h2* out) {
 template <int BITS, int MODE, int PRO, int NW, int U, int MATH, int XCH, int RS = 256, bool SC1 = false, int GP = 1>
 __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk, int sidx, const void* qweight, const void* meta_base,
                                           int seg_n_rt, int local, _Float16* lds_x, const _Float16* xl, float* xg,
-                                          float* red, int xs, bool fastx, const XRegs& xr) {
+                                          float* red, int xs, int xmode, const XRegs& xr) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = a.K >> 7;
@@ -428,7 +574,15 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     so.y = (_Float16*)blk.y[sidx];
     so.y_stride = blk.y_stride[sidx];
 #ifndef AMQ_ABL_NOSTAGE
-    if (fastx) x_finish<PRO, NW, XCH, MATH == MATH_LINEAR>(a, xr, lds_x, xg, red);
+    // xmode: 1 = one row held in registers (x_issue ran), 2 = rows on their way into LDS (x_dma_rows ran; the <= 8-row kernels, RS != 256), 0 = generic
+    if (xmode == 1) x_finish<PRO, NW, XCH, MATH == MATH_LINEAR>(a, xr, lds_x, xg, red);
+    else if (RS != 256 && xmode == 2) {
+#ifdef AMQ_ABL_NOLOAD
+        x_finish_dma<PRO, NW, XCH, 0, RowsCfg<RS>::MRMAX>(a, xr, lds_x, red, xs);
+#else
+        if constexpr (U * ((BITS == 3 ? 3 : 1) + 1) <= 15) x_finish_dma<PRO, NW, XCH, U * ((BITS == 3 ? 3 : 1) + 1), RowsCfg<RS>::MRMAX>(a, xr, lds_x, red, xs);
+#endif
+    }
     else stage_x<PRO, NW, MATH == MATH_LINEAR>(a, lds_x, xg, red, xs);
 #endif
     __syncthreads();
@@ -677,8 +831,16 @@ struct GemvPre {            // not a kernel parameter type: just names the 14 dw
 #ifndef AMQ_LB_WAVES_M
 #define AMQ_LB_WAVES_M(NW_, GP_, MATH_, XCH_) (((MATH_) == MATH_GS && (NW_) == 8 && (GP_) == 1 && (XCH_) == 1) ? 6 : AMQ_LB_WAVES_G(NW_, GP_))
 #endif
+// (the 2 .. 4-row kernels on 8 waves: three workgroups per CU as at one row, rows held in registers during the prologue included;
+//  the 5 .. 8-row kernels run two 8-wave workgroups or one 16-wave workgroup per CU: 128 registers)
+#ifndef AMQ_RS64_WAVES
+#define AMQ_RS64_WAVES 6
+#endif
+#ifndef AMQ_LB_WAVES_R
+#define AMQ_LB_WAVES_R(NW_, GP_, MATH_, XCH_, RS_) (((RS_) == 64 && (NW_) == 8) ? AMQ_RS64_WAVES : ((RS_) == 128 && (NW_) == 8) ? 4 : (RS_) == 128 ? 1 : AMQ_LB_WAVES_M(NW_, GP_, MATH_, XCH_))
+#endif
 template <int PRO, int NW, int U, int MATH, int XCH, int RS = 256, int GP = 1>
-__global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_M(NW, GP, MATH, XCH)) void gemv_kernel(const void* p_x, const void* p_xw, const void* p_qw0,
+__global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_R(NW, GP, MATH, XCH, RS)) void gemv_kernel(const void* p_x, const void* p_xw, const void* p_qw0,
                                                                      const void* p_mt0, int p_K, int p_m_nseg, int p_rpt,
                                                                      int p_n_rt0, int p_key0, float p_eps, GemvKArgs blk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -687,9 +849,13 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_M(NW, GP, MATH, XCH)) void ge
 #endif
     GemvHot a;
     a.x = p_x; a.x2 = p_xw; a.gamma = p_xw;
-    a.K = p_K; a.M = p_m_nseg & 0xFFFF; a.rpt = p_rpt; a.eps = p_eps;
+    a.K = p_K; a.M = p_m_nseg & 0xFF; a.rpt = p_rpt; a.eps = p_eps;
     const int nseg = p_m_nseg >> 16;
-    const bool slow_x = a.M != 1 || (a.K >> 3) > XCH * NW * 64;   // generic staging path
+    const bool dense = (p_m_nseg >> 8) & 1;                       // x rows are K apart: the register-held paths need no argument-block fetch for the stride
+    const bool fits = (a.K >> 3) <= XCH * NW * 64;
+    int xmode = (a.M == 1 && fits) ? 1 : 0;
+    if (RS != 256 && MATH != MATH_LINEAR && U == 2 && fits && dense && a.M >= 2 && a.M <= RowsCfg<RS>::MRMAX) xmode = 2;
+    const bool slow_x = xmode == 0;                               // generic staging path
     a.x_stride = slow_x ? blk.x_stride : a.K;
     const int xs = a.K + XPAD;
     _Float16* xl = (_Float16*)smem;
@@ -702,8 +868,8 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_M(NW, GP, MATH, XCH)) void ge
     // kernarg round trip below (everything they need arrives preloaded): staging x -- arrival, norm, LDS, barrier -- is the critical path of a
     // launch's prologue (issuing the first weight tile ahead of them instead measured 2-3 % slower)
     XRegs xr;
-    const bool fastx = !slow_x;
-    if (fastx) x_issue<PRO, NW, XCH>(a, xr);
+    if (xmode == 1) x_issue<PRO, NW, XCH>(a, xr);
+    else if (RS != 256 && xmode == 2) x_dma_rows<PRO, NW, XCH>(a, xl, xs, xr);
 
     const int bid = (int)blockIdx.x;
     int sidx = 0;
@@ -743,17 +909,17 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_M(NW, GP, MATH, XCH)) void ge
     constexpr bool HAS_FMA1 = (MATH == MATH_EXACT || MATH == MATH_GS) && GP == 1;      // (launch_gemv maps MODE_FMA1 to MODE_FMA for the kernels without those bodies)
     bool done = false;
     if constexpr (HAS_FMA1) {
-        if (key == 4 * 4 + MODE_FMA1) { gemv_body<4, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); done = true; }
-        else if (key == 3 * 4 + MODE_FMA1) { gemv_body<3, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); done = true; }
-        else if (key == 2 * 4 + MODE_FMA1) { gemv_body<2, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); done = true; }
+        if (key == 4 * 4 + MODE_FMA1) { gemv_body<4, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); done = true; }
+        else if (key == 3 * 4 + MODE_FMA1) { gemv_body<3, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); done = true; }
+        else if (key == 2 * 4 + MODE_FMA1) { gemv_body<2, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); done = true; }
     }
     if (!done) switch (key) {
-        case 4 * 4 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 4 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 2 * 4 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 4 * 4 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        case 3 * 4 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
-        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, fastx, xr); break;
+        case 4 * 4 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        case 3 * 4 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        case 2 * 4 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        case 4 * 4 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        case 3 * 4 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
     }
     if (threadIdx.x < 64) AMQ_STAMP_AT(blk, 4);
 #ifdef AMQ_STAMP
@@ -771,14 +937,17 @@ inline hipError_t launch_one(const GemvKArgs& a, int total_wg, size_t lds, hipSt
     }
     const void* xw = PRO == PRO_SILU_MUL ? a.x2 : a.gamma;
     hipLaunchKernelGGL(kern, dim3(total_wg), dim3(NW * 64), lds, st, a.x, xw, a.qweight[0], a.meta[0], a.K,
-                       a.M | (a.nseg << 16), a.rpt, a.n_rt[0], a.key[0], a.eps, a);
+                       a.M | ((a.x_stride == a.K ? 1 : 0) << 8) | (a.nseg << 16), a.rpt, a.n_rt[0], a.key[0], a.eps, a);
     return hipGetLastError();
 }
 
 // the default geometry (two tile loads in flight per wave) in one of the two product arithmetics
 template <int PRO, int NW, int MATH>
 inline hipError_t launch_std(const GemvKArgs& a, int flags, int total_wg, size_t lds, hipStream_t st) {
+    if (NW == 8 && (flags & GEMV_FLAG_RS64)) return launch_one<PRO, 8, 2, MATH, XCfg<8>::XC, 64>(a, total_wg, lds, st);
     if (NW == 8 && (flags & GEMV_FLAG_RS128)) return launch_one<PRO, 8, 2, MATH, XCfg<8>::XC, 128>(a, total_wg, lds, st);
+    if (NW == 16 && (flags & GEMV_FLAG_RS64)) return launch_one<PRO, 16, 2, MATH, XCfg<16>::XC, 64>(a, total_wg, lds, st);
+    if (NW == 16 && (flags & GEMV_FLAG_RS128)) return launch_one<PRO, 16, 2, MATH, XCfg<16>::XC, 128>(a, total_wg, lds, st);
     if (NW == 16 && a.M == 1 && (a.K >> 3) > XCfg<16>::XC * 1024 && (a.K >> 3) <= 4 * 1024)
         return launch_one<PRO, 16, 2, MATH, 4>(a, total_wg, lds, st);        // 16384 < K <= 32768 (70B down_proj)
     if (NW == 8 && a.M == 1 && (a.K >> 3) > 512 && (a.K >> 3) <= 1024)

@@ -242,12 +242,12 @@ __global__ __launch_bounds__(512, 6) void gemv_qkv_attn_kernel(const void* p_x, 
     XRegs xr;
     x_issue<PRO, NW, XCH>(a, xr);
     switch (key) {
-        case 4 * 4 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
-        case 3 * 4 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
-        case 2 * 4 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
-        case 4 * 4 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
-        case 3 * 4 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
-        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, true, xr); break;
+        case 4 * 4 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, 1, xr); break;
+        case 3 * 4 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, 1, xr); break;
+        case 2 * 4 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, 1, xr); break;
+        case 4 * 4 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, 1, xr); break;
+        case 3 * 4 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, 1, xr); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, 256, true>(a, blk, sidx, qwp, mtp, nrt, local, xl, xl, xg, red, xs, 1, xr); break;
     }
     // ---- publish this workgroup's row-tiles: drain (the storing threads sit in wave 0), barrier, one lane adds to the tickets
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -2,7 +2,9 @@
 """Per-workgroup phase timeline of one GEMV launch (diagnostic build only).
 
     make -C amq_amd/csrc variant TAG=stamp EXTRA=-DAMQ_STAMP
-    python tools/with_variant.py stamp tools/stamp_gemv.py N K bits [pro] -> gpurun_out/stamps_<N>x<K>_b<bits>.npz
+    python tools/with_variant.py stamp tools/stamp_gemv.py N K bits [M [pro]] -> gpurun_out/stamps_<N>x<K>_b<bits>.npz
+    (M: x rows, default 1; pro: 0 none / 1 RMSNorm / 2 SiLU*mul prologue through amq_gemv_grouped_f16, default 0; build the variant with
+     `make -C amq_amd/csrc gemvvariant TAG=stamp EXTRA=-DAMQ_STAMP`)
 
 Runs a rotation of launches over distinct weight buffers (cold weights), stamps the
 last few, and prints phase statistics in us relative to the earliest workgroup entry."""
@@ -20,6 +22,8 @@ from amq_amd.hqq_format import random_hqq  # noqa: E402
 
 def main():
     n, k, bits = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    M = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    pro = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     dev = torch.device("cuda:0")
     lib = _lib.load()
     setst = ctypes.CDLL(_lib.LIB_PATH).amq_debug_set_stamps
@@ -29,20 +33,25 @@ def main():
     per = qn0.numel() * 4 + mn0.numel() * 2
     copies = max(2, min(64, (768 << 20) // per + 1))
     bufs = [(qn0.clone(), mn0.clone()) for _ in range(copies)]
-    x = torch.randn(1, k, device=dev).half()
-    y = torch.empty(1, n, device=dev, dtype=torch.float16)
+    x = torch.randn(M, k, device=dev).half()
+    x2 = torch.randn(M, k, device=dev).half()
+    gamma = torch.ones(k, device=dev, dtype=torch.float16)
+    y = torch.empty(M, n, device=dev, dtype=torch.float16)
+
+    def launch(q, mt):
+        ops.gemv_grouped(x, [dict(qn=q, mn=mt, bits=bits, mode=ops.MODE_HQQ, N=n, y=y)], k, prologue=pro, x2=x2, gamma=gamma, eps=1e-5)
     nstamp = 4
     stamps = torch.zeros(nstamp, 4096, 128, dtype=torch.int64, device=dev)
     for rep in range(3):
         for i in range(copies):
-            ops.gemv(x, bufs[i][0], bufs[i][1], bits, ops.MODE_HQQ, n, k, out=y)
+            launch(bufs[i][0], bufs[i][1])
     torch.cuda.synchronize()
     def seq():
         for j in range(nstamp):
             for i in range(8):
-                ops.gemv(x, bufs[(j * 9 + i) % copies][0], bufs[(j * 9 + i) % copies][1], bits, ops.MODE_HQQ, n, k, out=y)
+                launch(*bufs[(j * 9 + i) % copies])
             setst(ctypes.c_void_p(stamps[j].data_ptr()))
-            ops.gemv(x, bufs[(j * 9 + 8) % copies][0], bufs[(j * 9 + 8) % copies][1], bits, ops.MODE_HQQ, n, k, out=y)
+            launch(*bufs[(j * 9 + 8) % copies])
             setst(None)
     if os.environ.get("STAMP_GRAPH", "0") == "1":
         graph = torch.cuda.CUDAGraph()
