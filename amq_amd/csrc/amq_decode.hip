@@ -562,6 +562,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
 struct AttnSplit { float* ws; int* tickets; int n_splits; };
 constexpr int ATT_WS_STRIDE = ATT_D + 4;       // floats per (head, chunk): O[128], m, l, pad
 
+// cached K / V rows are read once per token: non-temporal, so that 2 x 33 MB per layer at 2048 keys do not displace what the step re-reads
+#ifndef AMQ_ATT_NT
+#define AMQ_ATT_NT 1
+#endif
+#if AMQ_ATT_NT
+#define ATT_KV_LOAD(p) __builtin_nontemporal_load((const h8*)(p))
+#else
+#define ATT_KV_LOAD(p) (*(const h8*)(p))
+#endif
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_kc, void* p_vc, const void* p_state, int p_heads,
                                                                          int p_max_seq, const void* p_q, const void* p_k,
                                                                          const void* p_v, AttnRest rest, AttnSplit sp) {
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_
         if (ATT_GROUPS * i < Tl) {
             int t = t0 + grp + ATT_GROUPS * i;
             t = t < last_old ? t : last_old;
-            krow[i] = *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
+            krow[i] = ATT_KV_LOAD(kc + (size_t)t * ATT_D + 8 * l16);
         }
     }
 #pragma unroll
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_
         if (ATT_GROUPS * i < Tl) {
             int t = t0 + grp + ATT_GROUPS * i;
             t = t < last_old ? t : last_old;
-            vrow[i] = *(const h8*)(vc + (size_t)t * ATT_D + 8 * l16);
+            vrow[i] = ATT_KV_LOAD(vc + (size_t)t * ATT_D + 8 * l16);
         }
     }
     if (tid < 64) {
@@ -766,6 +775,52 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_
     }
     __syncthreads();
     if (!last_flag) return;
+    // The combine's loads are all issued side by side: every (m_c, l_c) pair in ONE round trip into LDS, then the O_c rows eight chunks at a time.
+    // One dependent agent-scope load after the other (the first form: a load -> max loop, then a three-load loop, per chunk) cost the last
+    // arriver ~2 L2 round trips per chunk -- at 6 - 16 chunks as long as the chunk's own stream (profiles/r05_attn_decode_long.txt).
+    // Same expressions in the same chunk order as before: bit-identical results.
+    float* const ml = sc;                            // [n_act][2] (the score array is free by now; 2 * n_act <= chunk checked below)
+    if (2 * n_act <= chunk) {
+        // (the first eight chunks' O rows leave together with the (m, l) pairs: up to eight chunks combine in ONE round trip)
+        float ov[8];
+        if (tid < ATT_D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int cc = j < n_act ? j : n_act - 1;
+                ov[j] = __hip_atomic_load(wsh + (size_t)cc * ATT_WS_STRIDE + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        for (int c = tid; c < n_act; c += ATT_THREADS) {
+            const float* const wc = wsh + (size_t)c * ATT_WS_STRIDE;
+            ml[2 * c] = __hip_atomic_load(wc + ATT_D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ml[2 * c + 1] = __hip_atomic_load(wc + ATT_D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid < ATT_D) {
+            float M = -INFINITY;
+            for (int c = 0; c < n_act; ++c) M = fmaxf(M, ml[2 * c]);
+            float L = 0.f, O = 0.f;
+            for (int c0 = 0; c0 < n_act; c0 += 8) {
+                if (c0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int cc = c0 + j < n_act ? c0 + j : n_act - 1;
+                        ov[j] = __hip_atomic_load(wsh + (size_t)cc * ATT_WS_STRIDE + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (c0 + j < n_act) {           // chunk order: deterministic whatever the arrival order
+                        const float f = __expf(ml[2 * (c0 + j)] - M);
+                        L += ml[2 * (c0 + j) + 1] * f;
+                        O += ov[j] * f;
+                    }
+                }
+            }
+            out[tid] = (_Float16)(O / L);
+        }
+        return;
+    }
     if (tid < ATT_D) {
         float M = -INFINITY;
         for (int c = 0; c < n_act; ++c)

@@ -93,7 +93,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     // `rpt` row-tiles
     int rpt = a.force_rpt;
     if (rpt <= 0) {
-        const bool two_per_cu = (rs128 || rs64) && nw == 8 && 3 * gemv_lds_bytes_rows(a.M, a.K, 8) > 160 * 1024;       // (forced 8-wave workgroups whose rows leave room for two)
+        const bool two_per_cu = nw == 8 && (rs128 || (rs64 && 3 * gemv_lds_bytes_rows(a.M, a.K, 8) > 160 * 1024));     // (the 5 .. 8-row kernels hold 105 - 128 VGPRs: two 8-wave workgroups per CU)
         const int target = (mid_k || two_per_cu) ? 512 : nw == 16 ? 256 : 256 * 24 / nw;
         rpt = (total_rt + target - 1) / target;
         if (rpt < 1) rpt = 1;

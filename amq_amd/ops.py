@@ -788,12 +788,22 @@ class _ZeroedPool:
 _ATTN_WS = _ScratchPool(torch.float32)
 _ATTN_TICKETS = _ZeroedPool()
 ATTN_SPLIT_FROM = 512      # caches longer than this use the split kernel (n_splits = 0 / auto)
-ATTN_CHUNK = 384           # keys per workgroup at a full cache: the kernel's register-prefetch depth
+ATTN_CHUNK = 272           # keys per workgroup aimed at for a full cache (the kernel holds up to 384 in registers; its smallest chunk is 256)
+ATTN_CUS = 256             # workgroups per round of the chip (MI355X: 256 CUs)
 
 
-def attn_decode_splits(max_seq):
-    """workgroups per head the auto policy gives a cache of ``max_seq`` rows (1: the single-workgroup kernel)"""
-    return 1 if max_seq <= ATTN_SPLIT_FROM else (max_seq + ATTN_CHUNK - 1) // ATTN_CHUNK
+def attn_decode_splits(max_seq, n_heads=32, batch=1):
+    """workgroups per head the auto policy gives a cache of ``max_seq`` rows (1: the single-workgroup kernel): about ATTN_CHUNK keys each, and --
+    where the heads divide the CU count -- a whole number of rounds of the chip (7B at 2048 keys: 8 x 32 = 256 workgroups of 264 keys ran the launch
+    in 14.0 us, 6 x 32 of 352 keys in 14.1, 16 x 32 in 14.7; at 4000 keys 16 x 32 in 22.1 against 11 x 32 in 24.7: profiles/r05_attn_decode_long.txt)"""
+    if max_seq <= ATTN_SPLIT_FROM:
+        return 1
+    s = max(1, round(max_seq / ATTN_CHUNK))
+    wg = max(1, n_heads * batch)
+    if ATTN_CUS % wg == 0:
+        step = ATTN_CUS // wg              # splits per round of the chip
+        s = max(step, round(s / step) * step) if s >= step else s
+    return s
 
 
 def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_theta=10000.0, table=None, cur=None, n_splits=0):
@@ -805,7 +815,7 @@ def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_the
     B = kcache.shape[0]
     max_seq = kcache.shape[2]
     if n_splits == 0:
-        n_splits = attn_decode_splits(max_seq)
+        n_splits = attn_decode_splits(max_seq, n_heads, B)
     _need(q, torch.float16, "q", B * n_heads * 128)
     _need(k, torch.float16, "k", B * n_kv_heads * 128)
     _need(v, torch.float16, "v", B * n_kv_heads * 128)

@@ -142,7 +142,8 @@ def test_attn_decode_sequence(nh, nkv):
     (256, 2048, 8, 2, 1, 0),          # T = 257: second chunk holds only the new token
     (511, 2048, 4, 4, 3, 0), (1500, 2048, 8, 2, 2, 0), (2047, 2048, 8, 4, 1, 0),
     (1500, 2048, 16, 8, 1, 0),        # 8 kv heads: the kv-group -> XCD head mapping
-    (4000, 4096, 4, 1, 1, 0),         # 11 chunks of 384
+    (4000, 4096, 4, 1, 1, 0),         # 15 chunks: the last arriver combines them in two batches of O rows
+    (4000, 4096, 32, 32, 1, 0),       # the auto policy's whole rounds of the chip: 16 x 32 workgroups
     (3000, 4096, 4, 2, 1, 4)])        # chunks of 768 keys: beyond the register prefetch, remainder loop per chunk
 def test_attn_decode_split_context(pos, max_seq, nh, nkv, batch, n_splits):
     """amq_attn_decode_split_f16 (several workgroups per head, last-arriver combine) against the single-workgroup kernel and
@@ -177,7 +178,7 @@ def test_attn_decode_split_context(pos, max_seq, nh, nkv, batch, n_splits):
     got, kc2, vc2 = run(n_splits, False)
     assert torch.isfinite(got.float()).all()
     assert torch.equal(kc2[:, :, :pos + 1], kc1[:, :, :pos + 1]) and torch.equal(vc2[:, :, :pos + 1], vc1[:, :, :pos + 1])   # appended once, same row
-    ns = n_splits or ops.attn_decode_splits(max_seq)
+    ns = n_splits or ops.attn_decode_splits(max_seq, nh, batch)
     chunk = max(256, (((pos + 1 + ns - 1) // ns) + 31) // 32 * 32)
     if pos + 1 <= chunk:
         assert torch.equal(got, one)                       # one active chunk: the single-workgroup kernel's bits
