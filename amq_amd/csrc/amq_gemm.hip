@@ -672,6 +672,7 @@ bool gemm_gate_fused(const GemmArgs& a, int route) {
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route) {
+    StreamDevice sd_(st);                                  // ONE guard for the plan (CU counts), the kernel attributes and the launch itself
     if (!a.gate) return launch_gemm_nogate(a, st, route);
     if (gemm_gate_fused(a, route)) return launch_gemm_nogate(a, st, route);
     GemmArgs b = a;

@@ -144,6 +144,14 @@ class QuantLlama:
         self.fine = any(blk[n].mn.numel() != ops.native_sizes(blk[n].bits, blk[n].N, blk[n].K)[1] // 2 for blk in self.blocks for n in config["linear"])
         if self.fine and engine:
             raise ValueError("the decode engine serves groups of 128")
+        # q/k/v and gate/up run as segments of ONE launch, which takes one group size: refuse a model that mixes them inside a sibling set here, at
+        # build time (amq_gemv_grouped_f16 would refuse it at the first decode step; patching._same_group keeps such siblings apart on the HF side)
+        for bi, blk in enumerate(self.blocks):
+            for sibs in (("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), ("mlp.gate_proj", "mlp.up_proj")):
+                pairs = {blk[n].mn.numel() * 128 // (2 * blk[n].N * blk[n].K) for n in sibs}      # (scale, zero) pairs per 128 columns: 1 / 2 / 4
+                if len(pairs) != 1:
+                    raise ValueError(f"block {bi}: {', '.join(sibs)} mix group sizes ({sorted(128 // p for p in pairs)}); the runner issues them as "
+                                     "one grouped launch, which needs one group size per sibling set")
 
         f16 = dict(dtype=torch.float16, device=dev)
         B = self.B

@@ -855,3 +855,31 @@ def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_the
                                                _lib.ptr(out), pos_dev, pos_i, B, n_heads, n_kv_heads, 128, max_seq,
                                                ctypes.c_float(rope_theta), _lib.ptr(table), _lib.current_stream()))
     return out
+
+
+# ---------------------------------------------------------------- the device of a launch
+# Every launch goes to the CURRENT device's stream (``_lib.current_stream()``), kernel attributes and CU counts are the current device's too.  A
+# process that keeps its weights on cuda:1 while cuda:0 is current (HF device_map, no set_device) must therefore have cuda:1 made current around
+# the call -- the library's own guard cannot help when the stream it is handed is the null stream.  Done here, once, for every
+# public entry point that takes tensors: the first CUDA tensor argument names the device; one comparison when it already is the current one.
+def _on_tensor_device(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        for v in args:
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                if v.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(v.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapped
+
+
+for _name in ("repack_from_hqq", "repack_from_gptq", "repack_from_awq", "dequantize", "dequantize_hqq", "gemv", "gemm", "gemm_f16w", "xfrag",
+              "rmsnorm_xfrag", "gemm_xfrag", "gemm_xfrag_grouped", "linear", "gemv_grouped", "rmsnorm", "gemv_f16w", "decode_tail", "rope_cache",
+              "attn_prefill", "rope_rows", "silu_mul", "gemv_qkv_attn", "attn_decode"):
+    globals()[_name] = _on_tensor_device(globals()[_name])
+del _name
+

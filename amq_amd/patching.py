@@ -288,7 +288,8 @@ def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False
                           fuse_norms=True, fuse_layers=True, kernel_arithmetic=False):
     """patching.py:143-223 for the HIP backend.  ``kernel_arithmetic`` (default off): the swapped linears dequantize like the reference's GPTQ /
     FT CUDA kernels -- w = fma(q, s, -fp16(z s)), one rounding, what its own ``backend='gptq'`` / ``'ft'`` paths compute -- instead of like HQQ's
-    ``dequantize()`` (two roundings, the default here: bit-identical to ``W_deq``); <= 1 fp16 ulp per weight apart, 5-8 % faster decode
+    ``dequantize()`` (two roundings, the default here: bit-identical to ``W_deq``).  The two differ by the rounding of c = fp16(z s): |dw| <= ~ulp(z s),
+    i.e. relative to |z s|, not to |w| (several ulps of a weight with |q - z| << z) -- exactly the reference's ``backend='gptq'`` numerics; 5-8 % faster decode
     (HIPQuantLinear.to_kernel_arithmetic).  The cache file always holds the HQQ form.  ``group_siblings`` (default on; not in the reference): q/k/v and gate/up
     siblings are additionally tied into grouped launches (group_sibling_linears); ``fuse_mlp`` / ``fuse_norms``: SiLU-gated MLPs
     and the decoder layers' RMSNorms are fused into those launches (fuse_llama_mlps, fuse_llama_norms); ``fuse_layers``: the decoder

@@ -76,13 +76,17 @@ class LinearGroup:
         member's buffers were replaced (.to(), load_state_dict); None when the group cannot take the grouped launch"""
         ms = self.members
         h = self._h
-        if h is not None and all(m._buffers["qweight"] is q and m._buffers["meta"] is t for m, q, t in zip(ms, h[1], h[2])):
+        # (valid while the members still hold the buffer OBJECTS and the modes it was built over: load_state_dict copies INTO the same buffers and
+        #  may change a member's mode -- meta would then be read as the wrong pair, ADVICE r4)
+        if h is not None and all(m._buffers["qweight"] is q and m._buffers["meta"] is t for m, q, t in zip(ms, h[1], h[2])) \
+                and h[3] == tuple(m.mode for m in ms):
             return h[0]
         if any(m.bias is not None for m in ms) or len({m.qweight.device for m in ms}) != 1:
             self._h = None
             return None
         qw, mt = [m.qweight for m in ms], [m.meta for m in ms]
-        self._h = (ext.Group(qw, mt, [m.outfeatures for m in ms], [m.bits for m in ms], [m.mode for m in ms], ms[0].infeatures), qw, mt)
+        self._h = (ext.Group(qw, mt, [m.outfeatures for m in ms], [m.bits for m in ms], [m.mode for m in ms], ms[0].infeatures), qw, mt,
+                   tuple(m.mode for m in ms))
         return self._h[0]
 
     def take(self, idx, x):
@@ -312,7 +316,9 @@ class HIPQuantLinear(nn.Module):
         """Switch the module from HQQ's dequant arithmetic, w = fp16(fp16(q - z) * s) (Quantizer.dequantize, quantize.py:198: what ``backend='hip'``
         keeps), to the arithmetic of the reference's GPTQ / FT kernels, w = fp16(fma(q, s, -fp16(z * s))) -- what ``patch_hqq_to_gptq`` stores
         (``scale_zeros = zeros * scales``, autogptq.py:112-114) and ``vecquant*matmul`` / ``gemv_4bit`` compute (auto_gptq_kernel.cu:206,
-        gemv_cuda.cu:151): one rounding per weight instead of two, at most one fp16 ulp from ``W_deq``.  The GEMV kernel then unpacks a weight pair
+        gemv_cuda.cu:151): one rounding per weight instead of two.  Distance from ``W_deq``: the rounding of c = fp16(z * s) carries over to every weight of
+        the group, |dw| <= ~ulp(z * s) -- relative to |z * s|, so several ulps of a small weight (z ~ 7.5, q - z = 0.5: ~7) -- which IS the reference's
+        ``backend='gptq'`` arithmetic, bit for bit (tests/test_gpu_hf.py).  The GEMV kernel then unpacks a weight pair
         with one packed op where the layer's scales allow it (``AMQ_MODE_FMA1``): ~5-8 % more decode tokens/s.  Idempotent; returns self."""
         if self.mode != ops.MODE_HQQ:
             return self
@@ -398,9 +404,9 @@ class HIPQuantLinear(nn.Module):
                 or not residual.is_contiguous()):
             return None
         h = _LIN_HANDLES.get(self)
-        if h is None or h[1] is not self._buffers["qweight"] or h[2] is not self._buffers["meta"]:
+        if h is None or h[1] is not self._buffers["qweight"] or h[2] is not self._buffers["meta"] or h[3] != self.mode:
             h = _LIN_HANDLES[self] = (ext.Group([self.qweight], [self.meta], [self.outfeatures], [self.bits], [self.mode], self.infeatures),
-                                      self.qweight, self.meta)
+                                      self.qweight, self.meta, self.mode)
         return h[0].run(x if x.is_contiguous() else x.contiguous(), 0, None, 0.0, residual)[0]
 
     def dequantize(self):
@@ -453,10 +459,12 @@ class HIPLlamaMLP(nn.Module):
             pro, gamma, eps = _claim_norm(self, x)
             if ext is not None:
                 h = _MLP_HANDLES.get(self)       # (C++ launch handles: weights checked once; rebuilt when a buffer was replaced)
-                if h is None or any(m._buffers["qweight"] is not q or m._buffers["meta"] is not t for m, q, t in zip((g_, u_, d_), h[2], h[3])):
+                if h is None or any(m._buffers["qweight"] is not q or m._buffers["meta"] is not t for m, q, t in zip((g_, u_, d_), h[2], h[3])) \
+                        or h[4] != (g_.mode, u_.mode, d_.mode):
                     qw, mt = [g_.qweight, u_.qweight, d_.qweight], [g_.meta, u_.meta, d_.meta]
                     h = _MLP_HANDLES[self] = (ext.Group(qw[:2], mt[:2], [g_.outfeatures, u_.outfeatures], [g_.bits, u_.bits], [g_.mode, u_.mode], K),
-                                              ext.Group(qw[2:], mt[2:], [d_.outfeatures], [d_.bits], [d_.mode], d_.infeatures), qw, mt)
+                                              ext.Group(qw[2:], mt[2:], [d_.outfeatures], [d_.bits], [d_.mode], d_.infeatures), qw, mt,
+                                              (g_.mode, u_.mode, d_.mode))
                 g, u = h[0].run(x2, pro, gamma, eps)
                 return h[1].run(g, 2, u, 0.0, residual)[0]
             I = g_.outfeatures

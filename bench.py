@@ -678,6 +678,11 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
 
+    if world > 1:
+        # ranks started by torch.distributed.run are not placed by anyone: bind this one to its GPU's NUMA node (its share of those cores)
+        # before the first GPU call creates the runtime's threads (launch_local's children arrive already bound: this then narrows nothing)
+        from amq_amd.replicas import pin_rank_cpus
+        pin_rank_cpus()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -284,3 +284,30 @@ def test_module_edge_shapes():
     assert not xt.is_contiguous() and torch.equal(mod(xt), mod(xt.contiguous()))
     with pytest.raises(ValueError):
         mod(torch.zeros(2, k + 128, dtype=torch.float16, device=dev))
+
+
+def test_second_gpu_while_the_first_is_current():
+    """weights and activations on cuda:1 while cuda:0 stays the current device (HF device_map without set_device): every launch, its kernel
+    attributes and its CU counts belong to cuda:1 -- through the ctypes path (ops) and through the C++ extension (module forward).  Needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from amq_amd import ops
+    from amq_amd.hqq_format import random_hqq
+    from amq_amd.quant_linear import HIPQuantLinear
+    torch.cuda.set_device(0)
+    d1 = torch.device("cuda:1")
+    n, k, bits = 512, 1024, 3
+    h = random_hqq(n, k, bits, seed=3)
+    h0, h1 = h.to("cuda:0"), h.to(d1)
+    q0, m0 = ops.repack_from_hqq(h0.W_q, h0.scale.reshape(-1), h0.zero.reshape(-1), bits, n, k)
+    q1, m1 = ops.repack_from_hqq(h1.W_q, h1.scale.reshape(-1), h1.zero.reshape(-1), bits, n, k)
+    assert q1.device == d1 and torch.equal(q1.cpu(), q0.cpu()) and torch.equal(m1.cpu(), m0.cpu())
+    for rows in (1, 5, 200):
+        x = torch.randn(rows, k, generator=torch.Generator().manual_seed(rows)).half()
+        y0 = ops.linear(x.to("cuda:0"), q0, m0, bits, ops.MODE_HQQ, n, k)
+        y1 = ops.linear(x.to(d1), q1, m1, bits, ops.MODE_HQQ, n, k)
+        assert torch.cuda.current_device() == 0 and y1.device == d1 and torch.equal(y1.cpu(), y0.cpu())
+    lin = HIPQuantLinear.from_hqq(h, device=d1)
+    x = torch.randn(3, k, generator=torch.Generator().manual_seed(9)).half()
+    assert torch.equal(lin(x.to(d1)).cpu(), ops.linear(x.to("cuda:0"), q0, m0, bits, ops.MODE_HQQ, n, k).cpu())
+    assert torch.cuda.current_device() == 0

@@ -122,3 +122,82 @@ def test_synthetic_tokenizer_round_trip():
     assert back.shape == (1, 64) and torch.equal(back[0], ids)
     assert tok(text, max_length=10).input_ids.shape == (1, 10)
     assert tok.decode([123]) == "t123"
+
+
+def _fake_sysfs(root, gpu_nodes, node_cpus):
+    """a /sys tree with amdgpu cards (PCI order = list order) on the given NUMA nodes and nodes with the given cpulists"""
+    for i, node in enumerate(gpu_nodes):
+        pci = root / "devices" / f"pci0000:{i:02x}" / f"0000:{i:02x}:00.0"
+        pci.mkdir(parents=True)
+        (pci / "numa_node").write_text(f"{node}\n")
+        drv = root / "bus" / "pci" / "drivers" / "amdgpu"
+        drv.mkdir(parents=True, exist_ok=True)
+        (pci / "driver").symlink_to(drv)
+        card = root / "class" / "drm" / f"card{7 - i}"          # card numbers need not follow PCI order
+        card.mkdir(parents=True)
+        (card / "device").symlink_to(pci)
+    for node, cpus in node_cpus.items():
+        d = root / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+
+
+def test_rank_cpu_sets_follow_the_gpus_numa_nodes(tmp_path):
+    """8 GPUs on two sockets: rank r gets an even share of the cores of GPU r's node; shares are disjoint, inside the allowed mask, and
+    fall back to an even split of the allowed cores when sysfs has no topology"""
+    from amq_amd.replicas import gpu_numa_nodes, rank_cpu_set
+    _fake_sysfs(tmp_path, [0, 0, 0, 0, 1, 1, 1, 1], {0: "0-63,128-191", 1: "64-127,192-255"})
+    assert gpu_numa_nodes(str(tmp_path)) == [0, 0, 0, 0, 1, 1, 1, 1]
+    allowed = set(range(256))
+    sets = [rank_cpu_set(r, 8, allowed, str(tmp_path)) for r in range(8)]
+    node0 = set(range(0, 64)) | set(range(128, 192))
+    for r, s in enumerate(sets):
+        assert len(s) == 32 and s < allowed
+        assert (s <= node0) == (r < 4)                       # ranks 0-3 on node 0's cores, 4-7 on node 1's
+    assert len(set().union(*sets)) == 256                    # disjoint, nothing left over
+    # a restricted mask (a container's cpuset) is respected
+    few = set(range(0, 16)) | set(range(64, 80))
+    sets = [rank_cpu_set(r, 8, few, str(tmp_path)) for r in range(8)]
+    assert all(len(s) == 4 and s < few for s in sets) and len(set().union(*sets)) == 32
+    # no topology: even split of what is allowed
+    empty = tmp_path / "none"
+    empty.mkdir()
+    sets = [rank_cpu_set(r, 4, set(range(8)), str(empty)) for r in range(4)]
+    assert sets == [{0, 1}, {2, 3}, {4, 5}, {6, 7}]
+    assert rank_cpu_set(0, 4, {5}, str(empty)) == {5}        # fewer cores than ranks: everyone keeps the mask
+
+
+def test_launch_local_pins_each_rank(tmp_path):
+    """launch_local binds every child before its interpreter starts: masks are disjoint strict subsets of the launcher's"""
+    import json, subprocess, sys
+    host = sorted(os.sched_getaffinity(0))
+    if len(host) < 2:
+        import pytest
+        pytest.skip("needs two cores")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "aff.py"
+    script.write_text("import json, os\nprint(json.dumps({'rank': int(os.environ['RANK']), 'cpus': sorted(os.sched_getaffinity(0))}), flush=True)\n")
+    drv = tmp_path / "drv.py"
+    drv.write_text(f"import sys; sys.path.insert(0, {root!r})\nfrom amq_amd.replicas import launch_local\n"
+                   f"sys.exit(launch_local(2, [sys.executable, {str(script)!r}], timeout=60))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(drv)], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr
+    got = {d["rank"]: set(d["cpus"]) for d in map(json.loads, [l for l in out.stdout.splitlines() if l.startswith("{")])}
+    assert set(got) == {0, 1}
+    assert got[0] < set(host) and got[1] < set(host) and not (got[0] & got[1])
+
+
+def test_bench_extras_run_after_the_timed_region():
+    """rank 0's CPU-baseline / parity / extras legs start only after `rep.timed` has closed its barrier on every rank (they would share cores and
+    HBM with the other ranks' timed steps otherwise): in bench.run_decode nothing but the timed call sits between warm-up and `rep.gather`"""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "run_decode")
+    src = ast.get_source_segment(open(os.path.join(root, "bench.py")).read(), fn)
+    timed = src.index("rep.timed(")
+    for leg in ("gemv_layer_table(", "beyond_the_metric(", "mfma_roofline(", "parity_gate(", "cpu_baseline()", "gemv_roofline("):
+        assert src.index(leg) > timed, leg
+    # ... and only rank 0 at N = 1 runs them
+    assert "if rank != 0:\n        return" in src and src.count("n_gpus == 1") >= 3
