@@ -67,15 +67,18 @@ int amq_version(void) { return AMQ_VERSION; }
 const char* amq_last_error(void) { return g_err; }
 
 int amq_query(int K, int* out, int cap) {
-    int vals[4];
-    int maxm = 0;
-    for (int m = 1; m <= amq::GEMV_MAX_M; ++m)
-        if (amq::gemv_min_lds_bytes(m, K, true) <= LDS_LIMIT) maxm = m;
-    vals[0] = maxm;                 // largest M amq_gemv_f16 accepts for this K
+    int vals[5];
+    int maxm = 0, maxm_plain = 0;
+    for (int m = 1; m <= amq::GEMV_MAX_M; ++m) {
+        if (amq::gemv_min_lds_bytes(m, K, false) <= LDS_LIMIT) maxm = m;
+        if (amq::gemv_min_lds_bytes(m, K, true) <= LDS_LIMIT) maxm_plain = m;
+    }
+    vals[0] = maxm;                 // largest M amq_gemv_f16 / amq_gemv_grouped_f16 accept for this K whatever the options and group size
     vals[1] = (int)LDS_LIMIT;
     vals[2] = amq::TILE_N;
     vals[3] = amq::TILE_K;
-    int n = cap < 4 ? cap : 4;
+    vals[4] = maxm_plain;           // ... with default options over groups of 128 (2 .. 8 rows run kernels with a smaller cross-wave sum buffer)
+    int n = cap < 5 ? cap : 5;
     for (int i = 0; i < n; ++i) out[i] = vals[i];
     return n;
 }

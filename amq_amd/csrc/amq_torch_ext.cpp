@@ -10,7 +10,7 @@
 // torch headers alone (no HIP compiler, __graft_entry__.build()).  Every function raises (never falls back) on a bad argument
 // or a non-zero library status.
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>     // (ROCm torch tensors carry DeviceType cuda: the masquerading guard is the one that accepts them)
 #include <c10/hip/HIPStream.h>
 #include <dlfcn.h>
 
@@ -89,7 +89,7 @@ at::Tensor linear(const at::Tensor& x, const at::Tensor& qweight, const at::Tens
     auto sizes = x.sizes().vec();
     sizes.back() = N;
     at::Tensor y = at::empty(sizes, x.options());
-    const c10::hip::HIPGuard dev_guard_(x.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
+    const c10::hip::HIPGuardMasqueradingAsCUDA dev_guard_(x.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
     check_rc(g_linear((int)bits, (int)mode, x.data_ptr(), qweight.data_ptr(), meta.data_ptr(), bias ? bias->data_ptr() : nullptr,
                       y.data_ptr(), (int)M, (int)N, (int)K, group, stream_of(x)), "amq_linear_f16");
     return y;
@@ -131,7 +131,7 @@ std::vector<at::Tensor> grouped(const at::Tensor& x, const std::vector<at::Tenso
     } else {
         TORCH_CHECK(prologue == 0, "unknown prologue");
     }
-    const c10::hip::HIPGuard dev_guard_(x.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
+    const c10::hip::HIPGuardMasqueradingAsCUDA dev_guard_(x.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
     check_rc(g_grouped(segs, (int)n, x.data_ptr(), x2, gamma, (float)eps, (int)prologue, (int)M, (int)K, group, 0, nullptr, stream_of(x)),
              "amq_gemv_grouped_f16");
     return ys;
@@ -195,7 +195,7 @@ struct Group {
         } else {
             TORCH_CHECK(prologue == 0, "unknown prologue");
         }
-        const c10::hip::HIPGuard dev_guard_(x.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
+        const c10::hip::HIPGuardMasqueradingAsCUDA dev_guard_(x.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
         check_rc(g_grouped(local, (int)segs.size(), x.data_ptr(), x2, gamma, (float)eps, (int)prologue, (int)M, (int)K, group, 0, nullptr, stream_of(x)),
                  "amq_gemv_grouped_f16");
         return ys;
@@ -215,7 +215,7 @@ at::Tensor attn_decode_cur(const at::Tensor& q, const at::Tensor& k, const at::T
     TORCH_CHECK(q.numel() == B * n_heads * 128 && k.numel() == B * n_kv_heads * 128 && v.numel() == k.numel() && cur.numel() == 128,
                 "attn_decode_cur: q [B, n_heads*128], k / v [B, n_kv_heads*128], cur [128]");
     at::Tensor out = at::empty_like(q);
-    const c10::hip::HIPGuard dev_guard_(q.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
+    const c10::hip::HIPGuardMasqueradingAsCUDA dev_guard_(q.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
     check_rc(g_attn_cur(q.data_ptr(), k.data_ptr(), v.data_ptr(), kcache.data_ptr(), vcache.data_ptr(), out.data_ptr(), cur.data_ptr(), (int)B,
                         (int)n_heads, (int)n_kv_heads, 128, (int)max_seq, stream_of(q)), "amq_attn_decode_cur_f16");
     return out;
@@ -227,7 +227,7 @@ at::Tensor rmsnorm(const at::Tensor& x, const at::Tensor& gamma, double eps) {
     check_x(x, K);
     TORCH_CHECK(gamma.scalar_type() == at::kHalf && gamma.numel() == K && gamma.device() == x.device(), "gamma: fp16 [K] on x's device");
     at::Tensor y = at::empty_like(x);
-    const c10::hip::HIPGuard dev_guard_(x.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
+    const c10::hip::HIPGuardMasqueradingAsCUDA dev_guard_(x.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
     check_rc(g_rmsnorm(x.data_ptr(), gamma.data_ptr(), y.data_ptr(), (int)(x.numel() / K), (int)K, (float)eps, stream_of(x)), "amq_rmsnorm_f16");
     return y;
 }
@@ -238,7 +238,7 @@ at::Tensor silu_mul(const at::Tensor& gate, const at::Tensor& up) {
                     up.numel() == gate.numel() && up.device() == gate.device() && gate.numel() % 8 == 0,
                 "silu_mul: two contiguous fp16 tensors of one size (a multiple of 8) on one device");
     at::Tensor y = at::empty_like(gate);
-    const c10::hip::HIPGuard dev_guard_(gate.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
+    const c10::hip::HIPGuardMasqueradingAsCUDA dev_guard_(gate.device());      // the tensors' device is current for the launch (attributes, CU count, null stream)
     check_rc(g_silu_mul(gate.data_ptr(), up.data_ptr(), y.data_ptr(), (size_t)gate.numel(), stream_of(gate)), "amq_silu_mul_f16");
     return y;
 }

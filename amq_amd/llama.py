@@ -171,7 +171,7 @@ class QuantLlama:
         self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
         self.host_pos = 0          # host mirror of self.pos (decode_step refuses to run past the cache without a device sync)
-        self._down_rows_fit = self.B <= ops.gemv_max_rows(self.I)
+        self._down_rows_fit = self.B <= ops.gemv_max_rows(self.I, plain=not self.fine)
         self.can_fuse_qkv_attn = self.B == 1 and max_seq <= ops.ATTN_SPLIT_FROM and self.H <= 8192 and not self.fine
         self.fuse_qkv_attn = self.FUSE_QKV_ATTN and self.can_fuse_qkv_attn
         self._tickets = torch.zeros(max(self.nh, 64), dtype=torch.int32, device=dev)

@@ -110,7 +110,8 @@ typedef struct amq_gemv_opts {
                                       unpack in its loop -- GPTQLinear.forward's own split from 128 rows on (hqq/backends/autogptq.py:245-283), hand-written.
                                       AUTO takes it for MFMA-bound launches when the workspace is passed. */
 
-/* capabilities: writes up to `cap` ints {max_gemv_rows_for_K, lds_bytes, ...}; returns the count */
+/* capabilities: writes up to `cap` ints {max GEMV rows for K (any options / group size), LDS limit, tile rows, tile columns, max GEMV rows for K
+ * with default options over groups of 128}; returns the count */
 int amq_query(int K, int* out, int cap);
 
 /* ---- native buffer sizes ------------------------------------------------ */
