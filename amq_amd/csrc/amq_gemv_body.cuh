@@ -341,7 +341,7 @@ __device__ __forceinline__ void x_dma_rows(const GemvHot& a, _Float16* xl, int x
 template <int PRO, int NW, int XCH, int NRING, int MR>
 __device__ __forceinline__ void x_finish_dma(const GemvHot& a, const XRegs& xr, _Float16* xl, float* red, int xs) {
     constexpr int THREADS = NW * 64;
-    static_assert(NRING >= 0 && NRING <= 15, "counted wait");
+    static_assert(NRING >= 0 && NRING <= 63, "counted wait (vmcnt is six bits on gfx9)");
     const int tid = threadIdx.x;
     const int chunks = a.K >> 3;
     if (PRO == PRO_RMSNORM) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRING) : "memory");      // (gamma's loads are older than the ring too)
@@ -580,7 +580,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
 #ifdef AMQ_ABL_NOLOAD
         x_finish_dma<PRO, NW, XCH, 0, RowsCfg<RS>::MRMAX>(a, xr, lds_x, red, xs);
 #else
-        if constexpr (U * ((BITS == 3 ? 3 : 1) + 1) <= 15) x_finish_dma<PRO, NW, XCH, U * ((BITS == 3 ? 3 : 1) + 1), RowsCfg<RS>::MRMAX>(a, xr, lds_x, red, xs);
+        if constexpr (U * ((BITS == 3 ? 3 : 1) + 1) <= 63) x_finish_dma<PRO, NW, XCH, U * ((BITS == 3 ? 3 : 1) + 1), RowsCfg<RS>::MRMAX>(a, xr, lds_x, red, xs);
 #endif
     }
     else stage_x<PRO, NW, MATH == MATH_LINEAR>(a, lds_x, xg, red, xs);
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_R(NW, GP, MATH, XCH, RS)) voi
     const bool dense = (p_m_nseg >> 8) & 1;                       // x rows are K apart: the register-held paths need no argument-block fetch for the stride
     const bool fits = (a.K >> 3) <= XCH * NW * 64;
     int xmode = (a.M == 1 && fits) ? 1 : 0;
-    if (RS != 256 && MATH != MATH_LINEAR && U == 2 && fits && dense && a.M >= 2 && a.M <= RowsCfg<RS>::MRMAX) xmode = 2;
+    if (RS != 256 && MATH != MATH_LINEAR && fits && dense && a.M >= 2 && a.M <= RowsCfg<RS>::MRMAX) xmode = 2;
     const bool slow_x = xmode == 0;                               // generic staging path
     a.x_stride = slow_x ? blk.x_stride : a.K;
     const int xs = a.K + XPAD;
