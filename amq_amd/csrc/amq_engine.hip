@@ -5,7 +5,7 @@
 // whose seven linears per block are the 2/3/4-bit modules of amq_speed_benchmark.py:231-256.
 //
 // Why: the five-launch-per-block step (amq_gemv.hip + amq_decode.hip under a hipGraph) spends ~3.7-4.4 us of FIXED cost per
-// dependent launch (boundary, prologue, first weight data, tail; DESIGN.md 4) -- two thirds of a 7B token.  Here the stages
+// dependent launch (boundary, prologue, first weight data, tail; DESIGN.md 5) -- two thirds of a 7B token.  Here the stages
 // of a block are phases of one kernel separated by a device-wide barrier, and every wave keeps its share of the weight
 // stream running ACROSS those barriers: weights do not depend on activations, so the first tiles of stage s+1 are already
 // in registers when the barrier of stage s opens.

@@ -7,7 +7,7 @@
 //   gemv_kernel<2,Batch,256,128>          (amq/kernel/ft/quantization_new/gemv/gemv_cuda.cu:73-204)
 // with one kernel family over the native AMQ-T16 layout (amq_common.cuh).
 //
-// Structure (every byte of W is read exactly once; see DESIGN.md for the measurements behind each choice):
+// Structure (every byte of W is read exactly once; see DESIGN.md 3.2 and HISTORY.md for the measurements behind each choice):
 //   * a workgroup owns whole row-tiles (16 output rows x all of K, one contiguous
 //     byte range each) and walks rt = first, first + stride, ...; x is staged
 //     (RMSNorm / SiLU*mul fused) ONCE per workgroup, not once per row-tile.

@@ -67,7 +67,7 @@ class QuantLlama:
     # instead of 5.  Built, bit-identical (tests/test_gpu_qkv_attn.py) and SLOWER -- 15.7 us per fused launch against 9.2 + 5.1,
     # 755 vs 830 tokens/s (profiles/r03_qkv_attn_fused_negative.txt) -- so it is off unless a caller sets fuse_qkv_attn.
     FUSE_QKV_ATTN = False
-    ENGINE_DEFAULT = False      # what engine=None means (the engine is opt-in until it beats the five-launch step: DESIGN.md 4)
+    ENGINE_DEFAULT = False      # what engine=None means (the engine is opt-in until it beats the five-launch step: HISTORY.md 3.2b)
     fine = False                # any layer with groups of 64 / 32 (set by __init__)
 
     def __init__(self, config, arch_linear=None, device="cuda:0", max_seq=256, seed=0, synthetic=True,

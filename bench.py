@@ -112,7 +112,7 @@ def beyond_the_metric(dev):
     try:
         # the same model with its weights in the REFERENCE's kernel arithmetic, w = fma(q, s, c) with c = -(z s) (one rounding: what its GPTQ / AWQ
         # cache files decode to, auto_gptq_kernel.cu:206, gemv_cuda.cu:151), as a swapped model loaded from those files runs: AMQ_MODE_FMA1, one packed
-        # fma per weight pair in the GEMV kernel (bit-identical to AMQ_MODE_FMA).  NOT `value`: the headline is the HQQ arithmetic
+        # fma per weight pair in the GEMV kernel (bit-identical to AMQ_MODE_FMA; HISTORY.md 7 item 5).  NOT `value`: the headline is the HQQ arithmetic
         # (two roundings) that the parity gate's W_deq is
         from amq_amd import ops
         m, _, _ = build_model(dev, seed=0, max_seq=PROMPT + 96)

@@ -2,7 +2,7 @@
  * libamq_hip.so.  `make -C amq_amd/csrc ab` builds libamq_hip_ab.so = the product library's sources + these routes
  * (-DAMQ_AB_ROUTES); amq_amd loads it only for ops.DecodeEngine / ops.gemv_qkv_attn (QuantLlama(engine=True), fuse_qkv_attn,
  * bench.py --engine / --fuse-qkv-attn) and fails loudly when it has not been built.  Same conventions as amq_hip.h (status codes,
- * caller-owned buffers, stream argument, no option state).  Measurements: DESIGN.md 3.2b / 3.2c, profiles/r03_engine_timeline.txt,
+ * caller-owned buffers, stream argument, no option state).  Measurements: HISTORY.md 3.2b / 3.2c, profiles/r03_engine_timeline.txt,
  * profiles/r03_qkv_attn_fused_negative.txt. */
 #ifndef AMQ_HIP_AB_H
 #define AMQ_HIP_AB_H
