@@ -424,11 +424,34 @@ static hipError_t skinny_grouped_launch(const void* xf, int M, int K, SkinnySegs
     return hipGetLastError();
 }
 
+#ifndef AMQ_FEWROW_STREAM
+#define AMQ_FEWROW_STREAM 1
+#endif
 hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg* segs, int nseg, hipStream_t st) {
     long blocks = 0;
     for (int i = 0; i < nseg; ++i) blocks += segs[i].N >> 4;
     blocks *= (M + 63) / 64;
     const int nsub = blocks <= 320 ? 1 : blocks <= 640 ? 2 : 4;          // as skinny_launch_xf
+#if AMQ_FEWROW_STREAM
+    // The streaming form (amq_gemm_fewrow.hip: same results bit for bit, up to six column blocks per workgroup) where it saves a ROUND of the chip:
+    // a workgroup of either kernel is bound by taking its rows' whole x in through one CU (~25-30 GB/s per CU of L1 misses: 512 KB = 16-23 us,
+    // profiles/r05_prompt64.txt), so a launch costs about one workgroup time per round.  7B gate/up at 64 rows: 344 workgroups of four blocks = two
+    // rounds (30 us) against 230 of six = one (23 us); q/k/v: 192 of four (16 us) against 256 of three (23 us, every CU pulling x at once) -- kept.
+    {
+        StreamDevice sd_(st);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int ny = (M + 63) / 64;
+        long wg_old = 0, wg_new = 0;
+        const int nsub_new = fewrow_stream_nsub(blocks / ny, ny, cus);
+        for (int i = 0; i < nseg; ++i) {
+            wg_old += ((segs[i].N >> 4) + nsub - 1) / nsub;
+            wg_new += ((segs[i].N >> 4) + nsub_new - 1) / nsub_new;
+        }
+        const long rounds_old = (wg_old * ny + cus - 1) / cus, rounds_new = (wg_new * ny + cus - 1) / cus;
+        if (rounds_new < rounds_old) return launch_gemm_fewrow_stream_grouped(xf, M, K, segs, nseg, st);
+    }
+#endif
     SkinnySegs sg{};
     sg.nseg = nseg;
     int wg = 0;
