@@ -479,8 +479,8 @@ def gemv_math_name():
 
 def load_traffic():
     """HBM bytes per GEMV launch from this round's committed rocprofv3 PMC pass over the CURRENT kernels
-    (profiles/r04_gemv_pmc.json, tools/collect_round.sh r04), or None -- never a stale constant."""
-    p = os.path.join(ROOT, "profiles", "r04_gemv_pmc.json")
+    (profiles/r05_gemv_pmc.json, tools/collect_round.sh r05), or None -- never a stale constant."""
+    p = os.path.join(ROOT, "profiles", "r05_gemv_pmc.json")
     if os.path.exists(p):
         try:
             return json.load(open(p)).get("hbm_bytes_per_launch")

@@ -17,5 +17,6 @@ CMD="tools/prof_decode.py 4"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $CMD > $out/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $CMD > $out/pmc_write.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_sq -- python3 $CMD > $out/pmc_sq.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_sq_gs -- python3 $CMD gs > $out/pmc_sq_gs.log 2>&1 || exit 1
 python3 tools/make_profile_summary.py $R $out/profiles
 cut -c1-600 $out/bench.json; echo; cut -c1-900 $out/bench_config4.json

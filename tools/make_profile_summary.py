@@ -60,6 +60,10 @@ if len(per_pro) == 3:
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/prof_decode.py "
                      "(eager launches of the bench workload, current kernels: symbols listed); (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                      "per dispatch, averaged per symbol and weighted 64/32/32 per token"}
+    # VALU instructions per wave of every GEMV symbol seen in the SQ passes (the default arithmetic's kernels and -- second pass, `prof_decode.py 4 gs`
+    # -- the opt-in group-scale kernels: fourth template argument 3)
+    out["valu_insts_per_wave"] = {k: round(v["SQ_INSTS_VALU"] / v["SQ_WAVES"], 1) for k, v in summary.items()
+                                  if "gemv_kernel<" in k and v.get("SQ_WAVES") and "SQ_INSTS_VALU" in v}
     with open(os.path.join(dst, f"{R}_gemv_pmc.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1)[:1200])
