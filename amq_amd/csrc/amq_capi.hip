@@ -67,18 +67,20 @@ int amq_version(void) { return AMQ_VERSION; }
 const char* amq_last_error(void) { return g_err; }
 
 int amq_query(int K, int* out, int cap) {
-    int vals[5];
-    int maxm = 0, maxm_plain = 0;
+    int vals[6];
+    int maxm = 0, maxm_plain = 0, maxm_plain_nonorm = 0;
     for (int m = 1; m <= amq::GEMV_MAX_M; ++m) {
         if (amq::gemv_min_lds_bytes(m, K, false) <= LDS_LIMIT) maxm = m;
-        if (amq::gemv_min_lds_bytes(m, K, true) <= LDS_LIMIT) maxm_plain = m;
+        if (amq::gemv_min_lds_bytes(m, K, true, true) <= LDS_LIMIT) maxm_plain = m;
+        if (amq::gemv_min_lds_bytes(m, K, true, false) <= LDS_LIMIT) maxm_plain_nonorm = m;
     }
     vals[0] = maxm;                 // largest M amq_gemv_f16 / amq_gemv_grouped_f16 accept for this K whatever the options and group size
     vals[1] = (int)LDS_LIMIT;
     vals[2] = amq::TILE_N;
     vals[3] = amq::TILE_K;
     vals[4] = maxm_plain;           // ... with default options over groups of 128 (2 .. 8 rows run kernels with a smaller cross-wave sum buffer)
-    int n = cap < 5 ? cap : 5;
+    vals[5] = maxm_plain_nonorm;    // ... and no RMSNorm prologue (x may then be staged in two K phases: 8 rows at K = 11008)
+    int n = cap < 6 ? cap : 6;
     for (int i = 0; i < n; ++i) out[i] = vals[i];
     return n;
 }
@@ -146,7 +148,7 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     if (o.depth != 0 && o.depth != 2 && o.depth != 4) return fail(AMQ_EINVAL, "opts.depth must be 0, 2 or 4");
     if (o.rpt < 0 || o.rpt > 64) return fail(AMQ_EINVAL, "opts.rpt (row-tiles per workgroup) must be 0..64");
     const bool plain_form = !o.dot && o.math != AMQ_MATH_LINEAR && o.depth != 4 && amq::meta_pairs(group) == 1 && o.waves != 4;
-    if (M > amq::GEMV_MAX_M || amq::gemv_min_lds_bytes(M, K, plain_form) > LDS_LIMIT)
+    if (M > amq::GEMV_MAX_M || amq::gemv_min_lds_bytes(M, K, plain_form && o.waves == 0 && o.rpt == 0, prologue == AMQ_PRO_RMSNORM) > LDS_LIMIT)
         return fail(AMQ_ESHAPE, "M=%d rows of K=%d do not fit LDS for the GEMV path; use amq_gemm_f16", M, K);
     amq::GemvArgs a{};
     for (int i = 0; i < nseg; ++i) {

@@ -431,10 +431,11 @@ __device__ __forceinline__ LanePayload<BITS> load_payload(const uint32_t* tile_b
         u2 v = AMQ_STREAM_LOAD((const u2*)tile_base + lane);
         r.w[0] = v.x; r.w[1] = v.y;
     } else {
-        const uint32_t* p = tile_base + 3 * lane;
-        r.w[0] = AMQ_STREAM_LOAD(p);
-        r.w[1] = AMQ_STREAM_LOAD(p + 1);
-        r.w[2] = AMQ_STREAM_LOAD(p + 2);
+        // ONE 12-byte load (global_load_dwordx3; 4-byte alignment is enough on gfx950).  Written as one access rather than left to the compiler's
+        // merging of three dword loads: the GEMV's counted waits (x_finish_dma) rely on a tile being two vector-memory operations at every bit-width.
+        typedef uint32_t u3a __attribute__((ext_vector_type(3), aligned(4)));
+        const u3a v = AMQ_STREAM_LOAD((const u3a*)(tile_base + 3 * lane));
+        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z;
     }
     return r;
 }

@@ -24,8 +24,17 @@ size_t gemv_lds_bytes_rows(int M, int K, int nw) {
     const size_t xbytes = (((size_t)M * (K + XPAD) * 2) + 15) & ~(size_t)15;
     return xbytes + (size_t)2 * nw * (M <= 4 ? 64 : 128) * 4;
 }
+// 5 .. 8 rows whose x does not fit LDS whole (the 7B down_proj at 7 - 8 rows: 8 x 11008 halves = 172 KB): x in two K phases, one 16-wave workgroup
+// per row-tile.  Needs no full-row statistic in the prologue (norm = false), an even tile count, >= 2 tiles per wave and phase (the restage's counted
+// wait assumes a full weight ring), one chunk per thread and phase.
+bool gemv_rows_phased(int M, int K, bool plain, bool norm) {
+    const int G = K >> 7;
+    return plain && !norm && M > 4 && M <= 8 && (G & 1) == 0 && G / 2 >= 2 * 16 && (K / 2 >> 3) <= 1024 &&
+           gemv_lds_bytes_rows(M, K, 16) > 160 * 1024 && gemv_lds_bytes_rows(M, K / 2, 16) <= 160 * 1024;
+}
 // smallest LDS allocation some launch form of an M-row GEMV needs (plain: default arithmetic and geometry, groups of 128)
-size_t gemv_min_lds_bytes(int M, int K, bool plain) {
+size_t gemv_min_lds_bytes(int M, int K, bool plain, bool norm) {
+    if (gemv_rows_phased(M, K, plain, norm)) return gemv_lds_bytes_rows(M, K / 2, 16);
     if (plain && M > 1 && M <= 8) return gemv_lds_bytes_rows(M, K, 16);
     return gemv_lds_bytes(M, K, 1);
 }
@@ -74,7 +83,11 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     // workgroup (TWO 8-wave workgroups measured slower at 6 - 8 rows: profiles/r02_decode_batch.txt, r05_decode_batch.txt)
     bool rs128 = false, rs64 = false;
     const bool plain = !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4 && gp == 1;
-    if (a.M > 1 && a.M <= 8 && plain && nw != 4) {
+    const bool ph2 = !a.force_waves && a.force_rpt <= 0 && gemv_rows_phased(a.M, a.K, plain, a.prologue == PRO_RMSNORM);
+    if (ph2) {
+        rs128 = true;
+        nw = 16;
+    } else if (a.M > 1 && a.M <= 8 && plain && nw != 4) {
         rs128 = a.M > 4;
         rs64 = !rs128;
         if (!a.force_waves && nw == 8 && 2 * gemv_lds_bytes_rows(a.M, a.K, 8) > 160 * 1024) nw = 16;
@@ -91,7 +104,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     // persistent-style grid: about 24 waves per CU (256 CUs) -- three 8-wave workgroups, but ONE 16-wave workgroup (two do
     // not fit the register file at 78 VGPRs, a second round of workgroups would run on an empty chip); a workgroup walks
     // `rpt` row-tiles
-    int rpt = a.force_rpt;
+    int rpt = ph2 ? 1 : a.force_rpt;                       // (K phases: one row-tile per workgroup -- its accumulators live across the phases)
     if (rpt <= 0) {
         const bool two_per_cu = nw == 8 && (rs128 || (rs64 && 3 * gemv_lds_bytes_rows(a.M, a.K, 8) > 160 * 1024));     // (the 5 .. 8-row kernels hold 105 - 128 VGPRs: two 8-wave workgroups per CU)
         const int target = (mid_k || two_per_cu) ? 512 : nw == 16 ? 256 : 256 * 24 / nw;
@@ -107,7 +120,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     }
     const bool lin = (a.flags & GEMV_FLAG_LINEAR) && !((a.flags & GEMV_FLAG_DOT) && a.M == 1);
     (void)lin; (void)mask;
-    const size_t lds = (rs128 || rs64) ? gemv_lds_bytes_rows(a.M, a.K, nw) : gemv_lds_bytes(a.M, a.K, a.M > 1 ? nw : 16);     // (one-row launches keep the allocation they were tuned with)
+    const size_t lds = ph2 ? gemv_lds_bytes_rows(a.M, a.K / 2, 16) : (rs128 || rs64) ? gemv_lds_bytes_rows(a.M, a.K, nw) : gemv_lds_bytes(a.M, a.K, a.M > 1 ? nw : 16);     // (one-row launches keep the allocation they were tuned with)
     GemvKArgs k{};
     k.x = a.x; k.x2 = a.x2; k.gamma = a.gamma;
     k.M = a.M; k.K = a.K; k.x_stride = a.x_stride; k.nseg = a.nseg;
@@ -138,9 +151,9 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
         }
     }
     switch (a.prologue) {
-        case PRO_NONE: return launch_pro<PRO_NONE>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0), a.force_depth, nw, wg, lds, st);
-        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0), a.force_depth, nw, wg, lds, st);
-        default: return launch_pro<PRO_SILU_MUL>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0), a.force_depth, nw, wg, lds, st);
+        case PRO_NONE: return launch_pro<PRO_NONE>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0) | (ph2 ? GEMV_FLAG_PH2 : 0), a.force_depth, nw, wg, lds, st);
+        case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0) | (ph2 ? GEMV_FLAG_PH2 : 0), a.force_depth, nw, wg, lds, st);
+        default: return launch_pro<PRO_SILU_MUL>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0) | (ph2 ? GEMV_FLAG_PH2 : 0), a.force_depth, nw, wg, lds, st);
     }
 }
 

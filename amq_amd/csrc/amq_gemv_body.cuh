@@ -312,14 +312,15 @@ __device__ __forceinline__ void gv_glds16(const void* sbase, unsigned voff, unsi
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
+// (k0, Ks: the columns staged -- all of K, or one K phase of a launch whose rows do not fit LDS whole: gemv_body's PH)
 template <int PRO, int NW, int XCH>
-__device__ __forceinline__ void x_dma_rows(const GemvHot& a, _Float16* xl, int xs, XRegs& xr) {
+__device__ __forceinline__ void x_dma_rows(const GemvHot& a, _Float16* xl, int xs, XRegs& xr, int k0, int Ks) {
     constexpr int THREADS = NW * 64;
-    const int chunks = a.K >> 3;
+    const int chunks = Ks >> 3;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)xl;
     for (int m = 0; m < a.M; ++m) {
-        const _Float16* row = (const _Float16*)a.x + (size_t)m * a.x_stride;
+        const _Float16* row = (const _Float16*)a.x + (size_t)m * a.x_stride + k0;
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int c = (int)threadIdx.x + i * THREADS;
@@ -337,13 +338,13 @@ __device__ __forceinline__ void x_dma_rows(const GemvHot& a, _Float16* xl, int x
     }
 }
 
-// NRING: vector-memory operations the wave has issued since x_dma_rows (the primed ring's loads)
+// NRING: vector-memory operations the wave has issued since x_dma_rows (the primed ring's loads: payload + meta per tile, amq_common.cuh load_payload)
 template <int PRO, int NW, int XCH, int NRING, int MR>
-__device__ __forceinline__ void x_finish_dma(const GemvHot& a, const XRegs& xr, _Float16* xl, float* red, int xs) {
+__device__ __forceinline__ void x_finish_dma(const GemvHot& a, const XRegs& xr, _Float16* xl, float* red, int xs, int k0, int Ks) {
     constexpr int THREADS = NW * 64;
     static_assert(NRING >= 0 && NRING <= 63, "counted wait (vmcnt is six bits on gfx9)");
     const int tid = threadIdx.x;
-    const int chunks = a.K >> 3;
+    const int chunks = Ks >> 3;
     if (PRO == PRO_RMSNORM) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRING) : "memory");      // (gamma's loads are older than the ring too)
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRING) : "memory");
     if (PRO == PRO_NONE) return;
@@ -415,7 +416,7 @@ __device__ __forceinline__ void x_finish_dma(const GemvHot& a, const XRegs& xr, 
             for (int i = 0; i < XCH; ++i) {
                 int c = tid + i * THREADS;
                 c = c < last ? c : last;
-                up[j * XCH + i] = *(const h8*)((const _Float16*)a.x2 + (size_t)mm * a.x_stride + 8 * c);
+                up[j * XCH + i] = *(const h8*)((const _Float16*)a.x2 + (size_t)mm * a.x_stride + k0 + 8 * c);
             }
         }
 #pragma unroll
@@ -499,7 +500,10 @@ __device__ __forceinline__ void unpack_lane_sub(const uint32_t* w, h2* out) {
 // (several sequences decoded together), whose staged x is what limits the workgroups per CU
 // SC1: the outputs are agent-scope (write-through) stores -- for a consumer INSIDE the same launch (gemv_qkv_attn_kernel)
 // GP: (scale, zero) pairs per (row, tile) = 128 / group (amq_common.cuh); 2 / 4 are served by the exact-math body only
-template <int BITS, int MODE, int PRO, int NW, int U, int MATH, int XCH, int RS = 256, bool SC1 = false, int GP = 1>
+// PH: K phases (1, or 2 for launches of 7 - 8 rows whose x does not fit LDS whole -- the 7B down_proj, K = 11008): x is staged one K slice at a
+//     time; a row-tile's tiles run slice by slice ("virtual row-tiles" of nt tiles each), its accumulators live across the slices, and between two
+//     slices the workgroup restages (barrier, LDS-DMA of the next slice behind the still-full weight ring, transform, barrier)
+template <int BITS, int MODE, int PRO, int NW, int U, int MATH, int XCH, int RS = 256, bool SC1 = false, int GP = 1, int PH = 1>
 __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk, int sidx, const void* qweight, const void* meta_base,
                                           int seg_n_rt, int local, _Float16* lds_x, const _Float16* xl, float* xg,
                                           float* red, int xs, int xmode, const XRegs& xr) {
@@ -507,10 +511,12 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = a.K >> 7;
     const int r = lane & 15, o = lane >> 4;
-    const int nt = (G - wave + NW - 1) / NW;                      // tiles of one row-tile owned by this wave: g = wave + i*NW
+    static_assert(PH == 1 || (RS != 256 && PRO != PRO_RMSNORM && MATH != MATH_LINEAR && MATH != MATH_DOT), "K phases: the row kernels, no full-row statistic");
+    const int Gp = G / PH;                                        // tiles of one K phase of a row-tile
+    const int nt = (Gp - wave + NW - 1) / NW;                     // tiles of one (row-tile, phase) owned by this wave: g = phase * Gp + wave + i*NW
     const int rt0 = local * a.rpt;                                // this workgroup's row-tiles: rt0 .. rt0 + n_my - 1 (contiguous bytes)
     const int n_my = (seg_n_rt - rt0) < a.rpt ? (seg_n_rt - rt0) : a.rpt;
-    const int total = n_my * nt;
+    const int total = n_my * PH * nt;
     const uint32_t* qw = (const uint32_t*)qweight;
     static_assert(GP == 1 || MATH == MATH_EXACT || MATH == MATH_GS, "groups finer than 128: exact math only");
     // group-scale arithmetic (amq_common.cuh) serves the two-rounding (HQQ) buffers at groups of 128; the one-rounding modes (reference-format
@@ -546,7 +552,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
 #else
 #define AMQ_ISSUE_AT(slot, clamp_)                                                               \
     do {                                                                                         \
-        size_t tile_ = (size_t)(rt0 + ij) * G + (wave + ii * NW);                                \
+        size_t tile_ = (size_t)(rt0 + ij / PH) * G + (ij % PH) * Gp + (wave + ii * NW);           \
         if (clamp_) tile_ = tile_ < last_tile ? tile_ : last_tile;                               \
         pay[slot] = load_payload<BITS>(qw + tile_ * (64 * BITS), lane);                           \
         AMQ_META_LOAD(slot, tile_);                                                              \
@@ -578,9 +584,9 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     if (xmode == 1) x_finish<PRO, NW, XCH, MATH == MATH_LINEAR>(a, xr, lds_x, xg, red);
     else if (RS != 256 && xmode == 2) {
 #ifdef AMQ_ABL_NOLOAD
-        x_finish_dma<PRO, NW, XCH, 0, RowsCfg<RS>::MRMAX>(a, xr, lds_x, red, xs);
+        x_finish_dma<PRO, NW, XCH, 0, RowsCfg<RS>::MRMAX>(a, xr, lds_x, red, xs, 0, a.K / PH);
 #else
-        if constexpr (U * ((BITS == 3 ? 3 : 1) + 1) <= 63) x_finish_dma<PRO, NW, XCH, U * ((BITS == 3 ? 3 : 1) + 1), RowsCfg<RS>::MRMAX>(a, xr, lds_x, red, xs);
+        if constexpr (U * 2 <= 63) x_finish_dma<PRO, NW, XCH, U * 2, RowsCfg<RS>::MRMAX>(a, xr, lds_x, red, xs, 0, a.K / PH);
 #endif
     }
     else stage_x<PRO, NW, MATH == MATH_LINEAR>(a, lds_x, xg, red, xs);
@@ -632,7 +638,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
             accm = (f4){0.f, 0.f, 0.f, 0.f};                                                     \
         }                                                                                        \
         __syncthreads();                                                                         \
-        const int rt_ = rt0 + cj;                                                                \
+        const int rt_ = rt0 + cj / PH;                                                           \
         if (e_on) {                                           /* M * 16 <= 256 <= threads */     \
             float tot_ = 0.f;                                                                    \
             _Pragma("unroll") for (int w_ = 0; w_ < NW; ++w_) tot_ += rp_[w_ * RS + threadIdx.x];  \
@@ -643,7 +649,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
                                         __builtin_bit_cast(unsigned short, y_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
             else so.y[(size_t)e_m * so.y_stride + rt_ * 16 + e_c] = y_;                          \
         }                                                                                        \
-        if (cj + 1 < n_my) AMQ_EPI_PREFETCH(rt_ + 1);                                            \
+        if (cj / PH + 1 < n_my) AMQ_EPI_PREFETCH(rt_ + 1);                                       \
         par ^= 1;                                                                                \
     } while (0)
 
@@ -710,12 +716,30 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
 #else
 #define AMQ_ROWEND()                                                                             \
     do {                                                                                         \
-        if (++ci == nt) { AMQ_FINISH(); ci = 0; ++cj; }                                          \
+        if (++ci == nt) {                                                                        \
+            if (PH == 1 || cj % PH == PH - 1) AMQ_FINISH();                                      \
+            if constexpr (PH > 1) { if (cj + 1 < n_my * PH) AMQ_RESTAGE((cj + 1) % PH); }        \
+            ci = 0; ++cj;                                                                        \
+        }                                                                                        \
     } while (0)
 #endif
+    // next K slice of x (PH > 1).  Runs where the weight ring is full (a virtual row-tile of >= U tiles follows: launch_gemv checks), so the counted
+    // wait inside x_finish_dma -- everything older than the ring's U tiles -- covers exactly this wave's transfers.
+#ifdef AMQ_ABL_NOLOAD
+#define AMQ_RESTAGE_NRING 0
+#else
+#define AMQ_RESTAGE_NRING (U * 2)
+#endif
+#define AMQ_RESTAGE(ph_)                                                                         \
+    do {                                                                                         \
+        __syncthreads();                                      /* every wave is done reading the slice in LDS */ \
+        x_dma_rows<PRO, NW, XCH>(a, lds_x, xs, const_cast<XRegs&>(xr), (ph_) * (a.K / PH), a.K / PH);          \
+        x_finish_dma<PRO, NW, XCH, AMQ_RESTAGE_NRING, RowsCfg<RS>::MRMAX>(a, xr, lds_x, red, xs, (ph_) * (a.K / PH), a.K / PH); \
+        __syncthreads();                                                                         \
+    } while (0)
 
-    if (nt == 0) {                                                // K < 128 * NW: this wave owns no tile
-        for (int j = 0; j < n_my; ++j) { AMQ_FINISH(); ++cj; }
+    if (nt == 0) {                                                // K < 128 * NW: this wave owns no tile (never with PH > 1: launch_gemv)
+        for (int j = 0; j < n_my; ++j) { AMQ_FINISH(); cj += PH; }
         return;
     }
 
@@ -728,7 +752,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     // diagnostic build: shader-clock cycles this wave spends (a) waiting for its next tile, (b) in unpack + MFMA,
     // (c) in the row-tile epilogue incl. its barrier.  The explicit wait is the one the compiler would insert itself.
     unsigned long long c_wait = 0, c_math = 0, c_row = 0;
-    constexpr int OPS_PER_TILE = (BITS == 3) ? 4 : 2;
+    constexpr int OPS_PER_TILE = 2;                                // payload (one load at every bit-width) + meta
 #define AMQ_T() __builtin_amdgcn_s_memtime()
     AMQ_STAMP_AT(blk, 96 + wave);                                  // realtime: about to wait for the first tile
     bool first_ = true;
@@ -800,6 +824,8 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
 #undef AMQ_ISSUE_AT
 #undef AMQ_COMPUTE
 #undef AMQ_ROWEND
+#undef AMQ_RESTAGE
+#undef AMQ_RESTAGE_NRING
 #undef AMQ_EPI_PREFETCH
 #undef AMQ_SETPRIO_LEVEL
 #undef AMQ_FINISH
@@ -839,7 +865,7 @@ struct GemvPre {            // not a kernel parameter type: just names the 14 dw
 #ifndef AMQ_LB_WAVES_R
 #define AMQ_LB_WAVES_R(NW_, GP_, MATH_, XCH_, RS_) (((RS_) == 64 && (NW_) == 8) ? AMQ_RS64_WAVES : ((RS_) == 128 && (NW_) == 8) ? 4 : (RS_) == 128 ? 1 : AMQ_LB_WAVES_M(NW_, GP_, MATH_, XCH_))
 #endif
-template <int PRO, int NW, int U, int MATH, int XCH, int RS = 256, int GP = 1>
+template <int PRO, int NW, int U, int MATH, int XCH, int RS = 256, int GP = 1, int PH = 1>
 __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_R(NW, GP, MATH, XCH, RS)) void gemv_kernel(const void* p_x, const void* p_xw, const void* p_qw0,
                                                                      const void* p_mt0, int p_K, int p_m_nseg, int p_rpt,
                                                                      int p_n_rt0, int p_key0, float p_eps, GemvKArgs blk) {
@@ -852,12 +878,14 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_R(NW, GP, MATH, XCH, RS)) voi
     a.K = p_K; a.M = p_m_nseg & 0xFF; a.rpt = p_rpt; a.eps = p_eps;
     const int nseg = p_m_nseg >> 16;
     const bool dense = (p_m_nseg >> 8) & 1;                       // x rows are K apart: the register-held paths need no argument-block fetch for the stride
-    const bool fits = (a.K >> 3) <= XCH * NW * 64;
-    int xmode = (a.M == 1 && fits) ? 1 : 0;
+    const int Kst = a.K / PH;                                     // columns of x in LDS at a time
+    const bool fits = (Kst >> 3) <= XCH * NW * 64;
+    int xmode = (a.M == 1 && fits && PH == 1) ? 1 : 0;
     if (RS != 256 && MATH != MATH_LINEAR && fits && dense && a.M >= 2 && a.M <= RowsCfg<RS>::MRMAX) xmode = 2;
+    if (PH > 1 && xmode != 2) return;                             // (launch_gemv only sends what the phased form takes)
     const bool slow_x = xmode == 0;                               // generic staging path
     a.x_stride = slow_x ? blk.x_stride : a.K;
-    const int xs = a.K + XPAD;
+    const int xs = Kst + XPAD;
     _Float16* xl = (_Float16*)smem;
     const size_t xbytes = ((size_t)a.M * xs * 2 + 15) & ~(size_t)15;
     float* xg = (float*)(smem + xbytes);                                        // [G][16] (linear math only)
@@ -869,7 +897,7 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_R(NW, GP, MATH, XCH, RS)) voi
     // launch's prologue (issuing the first weight tile ahead of them instead measured 2-3 % slower)
     XRegs xr;
     if (xmode == 1) x_issue<PRO, NW, XCH>(a, xr);
-    else if (RS != 256 && xmode == 2) x_dma_rows<PRO, NW, XCH>(a, xl, xs, xr);
+    else if (RS != 256 && xmode == 2) x_dma_rows<PRO, NW, XCH>(a, xl, xs, xr, 0, Kst);
 
     const int bid = (int)blockIdx.x;
     int sidx = 0;
@@ -909,17 +937,17 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_R(NW, GP, MATH, XCH, RS)) voi
     constexpr bool HAS_FMA1 = (MATH == MATH_EXACT || MATH == MATH_GS) && GP == 1;      // (launch_gemv maps MODE_FMA1 to MODE_FMA for the kernels without those bodies)
     bool done = false;
     if constexpr (HAS_FMA1) {
-        if (key == 4 * 4 + MODE_FMA1) { gemv_body<4, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); done = true; }
-        else if (key == 3 * 4 + MODE_FMA1) { gemv_body<3, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); done = true; }
-        else if (key == 2 * 4 + MODE_FMA1) { gemv_body<2, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); done = true; }
+        if (key == 4 * 4 + MODE_FMA1) { gemv_body<4, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP, PH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); done = true; }
+        else if (key == 3 * 4 + MODE_FMA1) { gemv_body<3, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP, PH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); done = true; }
+        else if (key == 2 * 4 + MODE_FMA1) { gemv_body<2, MODE_FMA1, PRO, NW, U, MATH, XCH, RS, false, GP, PH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); done = true; }
     }
     if (!done) switch (key) {
-        case 4 * 4 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
-        case 3 * 4 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
-        case 2 * 4 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
-        case 4 * 4 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
-        case 3 * 4 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
-        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        case 4 * 4 + MODE_HQQ: gemv_body<4, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP, PH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        case 3 * 4 + MODE_HQQ: gemv_body<3, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP, PH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        case 2 * 4 + MODE_HQQ: gemv_body<2, MODE_HQQ, PRO, NW, U, MATH, XCH, RS, false, GP, PH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        case 4 * 4 + MODE_FMA: gemv_body<4, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP, PH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        case 3 * 4 + MODE_FMA: gemv_body<3, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP, PH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
+        default:               gemv_body<2, MODE_FMA, PRO, NW, U, MATH, XCH, RS, false, GP, PH>(a, blk, sidx, qwp, mtp, nrt, local, xl, xuse, xg, red, xs, xmode, xr); break;
     }
     if (threadIdx.x < 64) AMQ_STAMP_AT(blk, 4);
 #ifdef AMQ_STAMP
@@ -928,9 +956,9 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_R(NW, GP, MATH, XCH, RS)) voi
 }
 
 
-template <int PRO, int NW, int U, int MATH, int XCH = XCfg<NW>::XC, int RS = 256, int GP = 1>
+template <int PRO, int NW, int U, int MATH, int XCH = XCfg<NW>::XC, int RS = 256, int GP = 1, int PH = 1>
 inline hipError_t launch_one(const GemvKArgs& a, int total_wg, size_t lds, hipStream_t st) {
-    auto kern = gemv_kernel<PRO, NW, U, MATH, XCH, RS, GP>;
+    auto kern = gemv_kernel<PRO, NW, U, MATH, XCH, RS, GP, PH>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -947,6 +975,9 @@ inline hipError_t launch_std(const GemvKArgs& a, int flags, int total_wg, size_t
     if (NW == 8 && (flags & GEMV_FLAG_RS64)) return launch_one<PRO, 8, 2, MATH, XCfg<8>::XC, 64>(a, total_wg, lds, st);
     if (NW == 8 && (flags & GEMV_FLAG_RS128)) return launch_one<PRO, 8, 2, MATH, XCfg<8>::XC, 128>(a, total_wg, lds, st);
     if (NW == 16 && (flags & GEMV_FLAG_RS64)) return launch_one<PRO, 16, 2, MATH, XCfg<16>::XC, 64>(a, total_wg, lds, st);
+    if constexpr (NW == 16 && PRO != PRO_RMSNORM) {
+        if (flags & GEMV_FLAG_PH2) return launch_one<PRO, 16, 2, MATH, 1, 128, 1, 2>(a, total_wg, lds, st);      // 7 - 8 rows of a long K: two K phases
+    }
     if (NW == 16 && (flags & GEMV_FLAG_RS128)) return launch_one<PRO, 16, 2, MATH, XCfg<16>::XC, 128>(a, total_wg, lds, st);
     if (NW == 16 && a.M == 1 && (a.K >> 3) > XCfg<16>::XC * 1024 && (a.K >> 3) <= 4 * 1024)
         return launch_one<PRO, 16, 2, MATH, 4>(a, total_wg, lds, st);        // 16384 < K <= 32768 (70B down_proj)

@@ -75,12 +75,14 @@ struct GemvArgs {
 };
 enum { GEMV_FLAG_DOT = 1, GEMV_FLAG_LINEAR = 2, GEMV_FLAG_RS128 = 4 /* internal: half-size cross-wave sum buffer (<= 8 rows) */,
        GEMV_FLAG_GS = 8 /* group-scale arithmetic for the two-rounding (HQQ) segments */,
-       GEMV_FLAG_RS64 = 16 /* internal: the 2 .. 4-row kernels */ };
+       GEMV_FLAG_RS64 = 16 /* internal: the 2 .. 4-row kernels */,
+       GEMV_FLAG_PH2 = 32 /* internal: x staged in two K phases (5 .. 8 rows of a K whose rows do not fit LDS whole) */ };
 constexpr int GEMV_MAX_M = 16;
 
 size_t gemv_lds_bytes(int M, int K, int copies);
 size_t gemv_lds_bytes_rows(int M, int K, int nw);                   // the 2 .. 8-row kernels
-size_t gemv_min_lds_bytes(int M, int K, bool plain);               // what the C ABI checks against the LDS limit
+size_t gemv_min_lds_bytes(int M, int K, bool plain, bool norm = true);   // what the C ABI checks against the LDS limit (norm: an RMSNorm prologue, which cannot stage x in K phases)
+bool gemv_rows_phased(int M, int K, bool plain, bool norm);      // the launch stages x in two K phases
 hipError_t launch_gemv(GemvArgs& a, hipStream_t st);
 
 // y[M,N] = x[M,K] . W^T for any M (MFMA, LDS-staged x tiles)

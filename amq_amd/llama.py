@@ -63,6 +63,11 @@ class QuantLlama:
     # single-workgroup-per-head attention regime (the same bound as ops.ATTN_SPLIT_FROM); otherwise, and with engine=False, as
     # five launches per block
     ENGINE_MAX_SEQ = 512
+    # rows up to which down_proj's SiLU*mul stays fused into its GEMV's prologue (beyond: one silu_mul launch + the GEMV without a prologue -- every
+    # workgroup of a fused launch takes in gate AND up, which at 5+ rows costs more than the extra launch: profiles/r05_decode_batch.txt)
+    DOWN_FUSED_ROWS = 1
+    # rows up to which the two RMSNorms stay fused into the q/k/v and gate/up launches (beyond: one rmsnorm launch + the grouped GEMV without a prologue)
+    NORM_FUSED_ROWS = 4
     # q/k/v + attention of a block as ONE launch (ops.gemv_qkv_attn; batch 1, short cache, hidden <= 8192): 4 launches per block
     # instead of 5.  Built, bit-identical (tests/test_gpu_qkv_attn.py) and SLOWER -- 15.7 us per fused launch against 9.2 + 5.1,
     # 755 vs 830 tokens/s (profiles/r03_qkv_attn_fused_negative.txt) -- so it is off unless a caller sets fuse_qkv_attn.
@@ -156,6 +161,7 @@ class QuantLlama:
         f16 = dict(dtype=torch.float16, device=dev)
         B = self.B
         self.x = torch.zeros(B, self.H, **f16)
+        self.xn = torch.zeros(B, self.H, **f16)          # normed rows (launches of more than NORM_FUSED_ROWS rows)
         self.q = torch.zeros(B, self.H, **f16)
         self.k = torch.zeros(B, self.kvd, **f16)
         self.v = torch.zeros(B, self.kvd, **f16)
@@ -171,7 +177,11 @@ class QuantLlama:
         self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
         self.host_pos = 0          # host mirror of self.pos (decode_step refuses to run past the cache without a device sync)
-        self._down_rows_fit = self.B <= ops.gemv_max_rows(self.I, plain=not self.fine)
+        # down_proj's launch: the GEMV with the fused SiLU*mul prologue while the rows' x fits LDS whole; past that (7B: 7 - 8 rows of 11008) one
+        # silu_mul launch + the GEMV without a prologue, x staged in two K phases (fusing the prologue there would make every workgroup take in gate
+        # AND up -- 352 KB per CU at 8 rows: 23.9 us against 4.9 + ~11); past that too, the few-row MFMA kernel
+        self._down_rows_fit = self.B <= min(ops.gemv_max_rows(self.I, plain=not self.fine), self.DOWN_FUSED_ROWS)
+        self._down_rows_phased = not self._down_rows_fit and self.B <= ops.gemv_max_rows(self.I, plain=not self.fine, norm=False)
         self.can_fuse_qkv_attn = self.B == 1 and max_seq <= ops.ATTN_SPLIT_FROM and self.H <= 8192 and not self.fine
         self.fuse_qkv_attn = self.FUSE_QKV_ATTN and self.can_fuse_qkv_attn
         self._tickets = torch.zeros(max(self.nh, 64), dtype=torch.int32, device=dev)
@@ -248,18 +258,25 @@ class QuantLlama:
                                            blk["self_attn.v_proj"].seg(self.v.view(-1))], H, blk["ln1"], self.eps, blk["kc"], blk["vc"],
                                   self.att.view(-1), self.rope_cur, self.nh, self.nkv, self._tickets)
             else:
-                ops.gemv_grouped(self.x, [blk["self_attn.q_proj"].seg(self.q), blk["self_attn.k_proj"].seg(self.k),
-                                          blk["self_attn.v_proj"].seg(self.v)], H, prologue=ops.PRO_RMSNORM,
-                                 gamma=blk["ln1"], eps=self.eps)
+                qkv = [blk["self_attn.q_proj"].seg(self.q), blk["self_attn.k_proj"].seg(self.k), blk["self_attn.v_proj"].seg(self.v)]
+                if self.B > self.NORM_FUSED_ROWS:
+                    ops.gemv_grouped(ops.rmsnorm(self.x, blk["ln1"], self.eps, out=self.xn), qkv, H)
+                else:
+                    ops.gemv_grouped(self.x, qkv, H, prologue=ops.PRO_RMSNORM, gamma=blk["ln1"], eps=self.eps)
                 ops.attn_decode(self.q, self.k, self.v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, self.theta,
                                 cur=self.rope_cur)
             ops.gemv_grouped(self.att, [blk["self_attn.o_proj"].seg(self.x, residual=self.x)], H)
-            ops.gemv_grouped(self.x, [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H,
-                             prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=self.eps)
+            if self.B > self.NORM_FUSED_ROWS:
+                ops.gemv_grouped(ops.rmsnorm(self.x, blk["ln2"], self.eps, out=self.xn), [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H)
+            else:
+                ops.gemv_grouped(self.x, [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H,
+                                 prologue=ops.PRO_RMSNORM, gamma=blk["ln2"], eps=self.eps)
             if self._down_rows_fit:
                 ops.gemv_grouped(self.gate, [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I,
                                  prologue=ops.PRO_SILU_MUL, x2=self.up)
-            else:       # batch x intermediate size past the GEMV kernel's LDS stage (7B: 8 rows of 11008): few-row MFMA kernel
+            elif self._down_rows_phased:
+                ops.gemv_grouped(ops.silu_mul(self.gate, self.up, out=self.gate), [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I)
+            else:       # batch x intermediate size past the GEMV kernel's LDS stage: few-row MFMA kernel
                 d = blk["mlp.down_proj"]
                 ops.gemm(ops.silu_mul(self.gate, self.up, out=self.gate), d.qn, d.mn, d.bits, d.mode, d.N, d.K, residual=self.x, out=self.x)
         ops.gemv_f16w(self.x.reshape(-1) if self.B == 1 else self.x, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)

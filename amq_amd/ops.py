@@ -439,12 +439,13 @@ def default_gemv_math():
     return int(_lib.load().amq_default_gemv_math())
 
 
-def gemv_max_rows(K, plain=False):
+def gemv_max_rows(K, plain=False, norm=True):
     """largest number of x rows the weight-streaming GEMV stages in LDS for this K (amq_query); ``plain``: with default options over groups of
-    128 (launches of 2 .. 8 rows then run kernels with a smaller cross-wave sum buffer: one row more at K = 11008)"""
-    out = (ctypes.c_int * 5)()
-    _lib.load().amq_query(int(K), out, 5)
-    return int(out[4] if plain else out[0])
+    128 (launches of 2 .. 8 rows then run kernels with a smaller cross-wave sum buffer: one row more at K = 11008); ``norm=False``: and without
+    an RMSNorm prologue (x may then be staged in two K phases: 8 rows at K = 11008, the 7B down_proj)"""
+    out = (ctypes.c_int * 6)()
+    _lib.load().amq_query(int(K), out, 6)
+    return int((out[4] if norm else out[5]) if plain else out[0])
 
 
 def gemv_grouped(x, segments, K, prologue=PRO_NONE, x2=None, gamma=None, eps=0.0, opts=None):

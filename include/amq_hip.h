@@ -111,7 +111,7 @@ typedef struct amq_gemv_opts {
                                       AUTO takes it for MFMA-bound launches when the workspace is passed. */
 
 /* capabilities: writes up to `cap` ints {max GEMV rows for K (any options / group size), LDS limit, tile rows, tile columns, max GEMV rows for K
- * with default options over groups of 128}; returns the count */
+ * with default options over groups of 128, the same without an RMSNorm prologue (x may then be staged in two K phases)}; returns the count */
 int amq_query(int K, int* out, int cap);
 
 /* ---- native buffer sizes ------------------------------------------------ */

@@ -601,6 +601,59 @@ def test_grouped_mixed_bits_with_prologues(m):
     _assert_close(y.cpu().numpy(), ref, "silu*mul + residual")
 
 
+@pytest.mark.parametrize("bits", [2, 3, 4])
+@pytest.mark.parametrize("m,k,n", [(2, 4096, 512), (4, 4096, 512), (5, 4096, 256), (8, 4096, 256), (3, 11008, 256), (6, 11008, 256),
+                                     (7, 11008, 512), (8, 11008, 4096), (8, 8192, 256)])
+def test_gemv_rows_staged_by_dma(bits, m, k, n):
+    """launches of 2 .. 8 rows (sequences decoded together): x goes into LDS by LDS-DMA ahead of the weight ring, the fused transform is applied in
+    place (kernels RS = 64 / 128); 7 - 8 rows of K = 11008 (the 7B down_proj at batch 7 - 8: 8 x 11008 halves do not fit LDS) stage x in two K
+    phases.  Every prologue against the oracle; every row bit-identical to the same row launched alone (a sequence's result does not depend
+    on its batch); strided x takes the generic path with the same bits."""
+    from amq_amd import ops
+    dev = _dev()
+    h, qn, mn, w_ref = _random_case(bits, n, k, seed=13 * bits + m)
+    gen = torch.Generator().manual_seed(m * 1000 + k)
+    x = torch.randn(m, k, generator=gen).to(torch.float16)
+    up = torch.randn(m, k, generator=gen).to(torch.float16)
+    gamma = (1.0 + 0.1 * torch.randn(k, generator=gen)).to(torch.float16)
+    res = torch.randn(m, n, generator=gen).to(torch.float16)
+    eps = 1e-5
+    seg = lambda y, r=None: [dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_HQQ, N=n, y=y, residual=r)]
+
+    def run(xx, pro, **kw):
+        y = torch.empty(xx.shape[0], n, dtype=torch.float16, device=dev)
+        r = kw.pop("res", None)
+        ops.gemv_grouped(xx, seg(y, r), k, prologue=pro, **kw)
+        return y
+
+    xd, upd, gd, rd = x.to(dev), up.to(dev), gamma.to(dev), res.to(dev)
+    max_rows_norm, max_rows = ops.gemv_max_rows(k, plain=True), ops.gemv_max_rows(k, plain=True, norm=False)
+    assert max_rows >= m, (m, k, max_rows)
+    # no prologue + residual
+    y0 = run(xd, ops.PRO_NONE, res=rd)
+    _assert_close(y0.cpu().numpy(), (res.numpy() + linear_ref.linear_f16(x.numpy(), w_ref)).astype(np.float16), "rows, no prologue")
+    # SiLU * mul
+    act = torch.nn.functional.silu(x.float()).to(torch.float16) * up
+    y2 = run(xd, ops.PRO_SILU_MUL, x2=upd)
+    _assert_close(y2.cpu().numpy(), linear_ref.linear_f16(act.numpy(), w_ref), "rows, silu*mul")
+    # RMSNorm (needs the whole row in LDS: as many rows as fit)
+    if m <= max_rows_norm:
+        y1 = run(xd, ops.PRO_RMSNORM, gamma=gd, eps=eps)
+        _assert_close(y1.cpu().numpy(), linear_ref.linear_f16(_rmsnorm_ref(x, gamma, eps).numpy(), w_ref), "rows, rmsnorm")
+    # a row alone == the row in the batch (K phases deal the tiles to the waves differently: same sums in another order, within fp32 rounding)
+    # (so does a launch geometry that differs between one row and several: 4096 < K <= 8192 runs 8-wave workgroups at one row, 16-wave at several)
+    phased = m > max_rows_norm or 4096 < k <= 8192
+    same = (lambda a_, b_: _assert_close(a_.cpu().numpy(), b_.cpu().numpy(), "row alone vs in a phased batch")) if phased else \
+           (lambda a_, b_: (_ for _ in ()).throw(AssertionError("row differs from its batch")) if not torch.equal(a_, b_) else None)
+    for i in (0, m - 1):
+        same(run(xd[i:i + 1], ops.PRO_NONE, res=rd[i:i + 1]), y0[i:i + 1])
+        same(run(xd[i:i + 1].contiguous(), ops.PRO_SILU_MUL, x2=upd[i:i + 1].contiguous()), y2[i:i + 1])
+        if m <= max_rows_norm:
+            same(run(xd[i:i + 1], ops.PRO_RMSNORM, gamma=gd, eps=eps), y1[i:i + 1])
+    # deterministic
+    assert torch.equal(run(xd, ops.PRO_SILU_MUL, x2=upd), y2)
+
+
 def test_error_paths_raise():
     from amq_amd import ops, _lib
     h, qn, mn, _ = _random_case(4, 64, 256, seed=1)
