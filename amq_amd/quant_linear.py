@@ -23,6 +23,9 @@ from . import _ext, _lib, ops
 from .hqq_format import GROUP, HQQWeights, from_hqq_layer, pack_rows
 
 GROUP_MAX_ROWS = 8          # few-row forwards of grouped siblings run as ONE grouped GEMV launch (more rows: each member's GEMM)
+# rows from which a fused MLP forms silu(gate) * up in its own launch instead of in down_proj's prologue: a fused prologue is redone by every
+# workgroup of the launch, on both operands (profiles/r05_decode_batch.txt; QuantLlama.DOWN_FUSED_ROWS is the runner's copy of this rule)
+DOWN_UNFUSED_FROM_ROWS = 2
 
 
 class LinearGroup:
@@ -466,6 +469,8 @@ class HIPLlamaMLP(nn.Module):
                                               ext.Group(qw[2:], mt[2:], [d_.outfeatures], [d_.bits], [d_.mode], d_.infeatures), qw, mt,
                                               (g_.mode, u_.mode, d_.mode))
                 g, u = h[0].run(x2, pro, gamma, eps)
+                if x2.numel() // K >= DOWN_UNFUSED_FROM_ROWS:      # (the same values: silu_mul_kernel's expression is the prologue's)
+                    return h[1].run(ext.silu_mul(g, u), 0, None, 0.0, residual)[0]
                 return h[1].run(g, 2, u, 0.0, residual)[0]
             I = g_.outfeatures
             g = torch.empty(x.shape[:-1] + (I,), dtype=torch.float16, device=x.device)
@@ -474,10 +479,12 @@ class HIPLlamaMLP(nn.Module):
                                   dict(qn=u_.qweight, mn=u_.meta, bits=u_.bits, mode=u_.mode, N=I, y=u.view(-1, I))], K,
                              prologue=pro, gamma=gamma, eps=eps)
             y = torch.empty(x.shape[:-1] + (d_.outfeatures,), dtype=torch.float16, device=x.device)
-            ops.gemv_grouped(g.view(-1, I), [dict(qn=d_.qweight, mn=d_.meta, bits=d_.bits, mode=d_.mode, N=d_.outfeatures,
-                                                  y=y.view(-1, d_.outfeatures),
-                                                  residual=None if residual is None else residual.view(-1, d_.outfeatures))],
-                             I, prologue=ops.PRO_SILU_MUL, x2=u.view(-1, I))
+            dseg = [dict(qn=d_.qweight, mn=d_.meta, bits=d_.bits, mode=d_.mode, N=d_.outfeatures, y=y.view(-1, d_.outfeatures),
+                         residual=None if residual is None else residual.view(-1, d_.outfeatures))]
+            if x2.numel() // K >= DOWN_UNFUSED_FROM_ROWS:
+                ops.gemv_grouped(ops.silu_mul(g.view(-1, I), u.view(-1, I), out=g.view(-1, I)), dseg, I)
+            else:
+                ops.gemv_grouped(g.view(-1, I), dseg, I, prologue=ops.PRO_SILU_MUL, x2=u.view(-1, I))
             return y
         if self.__dict__.get("_norm") is not None:
             raise RuntimeError("a deferred RMSNorm reached HIPLlamaMLP's unfused path")
