@@ -449,7 +449,7 @@ hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg
             wg_new += ((segs[i].N >> 4) + nsub_new - 1) / nsub_new;
         }
         const long rounds_old = (wg_old * ny + cus - 1) / cus, rounds_new = (wg_new * ny + cus - 1) / cus;
-        if (rounds_new < rounds_old) return launch_gemm_fewrow_stream_grouped(xf, M, K, segs, nseg, st);
+        if (rounds_new < rounds_old || AMQ_FEWROW_STREAM == 2) return launch_gemm_fewrow_stream_grouped(xf, M, K, segs, nseg, st);      // (2: A/B builds, always)
     }
 #endif
     SkinnySegs sg{};

@@ -22,7 +22,8 @@
 
 namespace amq {
 
-template <int BITS, int MODE, int NSUB>
+// XS: x steps in flight per wave (4 = one K tile ahead, 8 = two: what the registers allow up to four column blocks)
+template <int BITS, int MODE, int NSUB, int XS>
 __device__ __forceinline__ void fewrow_stream_body(const GemmArgs& a, int bx, unsigned char* smem) {
     constexpr int NWV = 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -44,14 +45,15 @@ __device__ __forceinline__ void fewrow_stream_body(const GemmArgs& a, int bx, un
 #pragma unroll
         for (int nb = 0; nb < NSUB; ++nb) acc[mb][nb] = (f4){0, 0, 0, 0};
 
-    h8 xr[4][4];                                   // [step t][row block mb]: the A operands of one MFMA step, refilled per step
+    static_assert(XS == 4 || XS == 8, "x ring: one or two K tiles of steps");
+    h8 xr[XS][4];                                  // [ring slot][row block mb]: the A operands of one MFMA step, refilled per step
     LanePayload<BITS> pay[2][NSUB];
     h2 meta[2][NSUB];
-    auto xload = [&](int t, int kt) {              // fragment j = mb * 4 + t of K tile kt (clamped: tiles past the end re-read the last one, unused)
+    auto xload = [&](int slot, int t, int kt) {    // fragment j = mb * 4 + t of K tile kt (clamped: tiles past the end re-read the last one, unused)
         const int ktc = kt < G ? kt : G - 1;
         const _Float16* xt = xg + (size_t)ktc * (64 * 128) + t * 512;
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) xr[t][mb] = *(const h8*)(xt + mb * 2048);
+        for (int mb = 0; mb < 4; ++mb) xr[slot][mb] = *(const h8*)(xt + mb * 2048);
     };
     auto wload = [&](int ws, int kt) {
         const bool valid = kt < G;
@@ -66,7 +68,7 @@ __device__ __forceinline__ void fewrow_stream_body(const GemmArgs& a, int bx, un
             meta[ws][nb] = valid ? mv : (h2){(_Float16)0.f, (_Float16)0.f};      // a tile past the end contributes exact zeros
         }
     };
-    auto step = [&](int ws, auto tc) {             // MFMA step t of the tile in weight slot ws
+    auto step = [&](int ws, int xs_, auto tc) {    // MFMA step t of the tile in weight slot ws, A operands in x slot xs_
         constexpr int t = decltype(tc)::value;
 #pragma unroll
         for (int nb = 0; nb < NSUB; ++nb) {
@@ -75,23 +77,26 @@ __device__ __forceinline__ void fewrow_stream_body(const GemmArgs& a, int bx, un
             const h2 w2 = dequant_pair_sd<BITS, MODE, 4 * t + 2>(pay[ws][nb].w, m), w3 = dequant_pair_sd<BITS, MODE, 4 * t + 3>(pay[ws][nb].w, m);
             const h8 b = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xr[t][mb], b, acc[mb][nb], 0, 0, 0);
+            for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xr[xs_][mb], b, acc[mb][nb], 0, 0, 0);
         }
     };
 
-    // prime: weights of this wave's first two tiles, x steps of the first
+    // prime: weights of this wave's first two tiles, x steps of the first (XS = 8: first two) tiles
+    constexpr int TA = XS / 4;                     // tiles of x the ring runs ahead
     wload(0, wave);
-    xload(0, wave); xload(1, wave); xload(2, wave); xload(3, wave);
+#pragma unroll
+    for (int s_ = 0; s_ < XS; ++s_) xload(s_, s_ & 3, wave + NWV * (s_ >> 2));
     wload(1, wave + NWV);
     const int nt = (G + NWV - 1) / NWV;            // K tiles of wave 0 (the other waves' extra tile carries zero meta)
     for (int i = 0; i < nt; i += 2) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-            const int kt_next = wave + NWV * (i + d + 1);
-            step(d, std::integral_constant<int, 0>{}); xload(0, kt_next);      // a step's slot is refilled as soon as its MFMAs have issued (they read their operands at issue)
-            step(d, std::integral_constant<int, 1>{}); xload(1, kt_next);
-            step(d, std::integral_constant<int, 2>{}); xload(2, kt_next);
-            step(d, std::integral_constant<int, 3>{}); xload(3, kt_next);
+            const int kt_next = wave + NWV * (i + d + TA);
+            const int s0 = (XS == 8 ? d * 4 : 0);  // this tile's first x slot (the loop is unrolled over d: compile-time)
+            step(d, s0 + 0, std::integral_constant<int, 0>{}); xload(s0 + 0, 0, kt_next);      // a slot is refilled as soon as its MFMAs have issued
+            step(d, s0 + 1, std::integral_constant<int, 1>{}); xload(s0 + 1, 1, kt_next);
+            step(d, s0 + 2, std::integral_constant<int, 2>{}); xload(s0 + 2, 2, kt_next);
+            step(d, s0 + 3, std::integral_constant<int, 3>{}); xload(s0 + 3, 3, kt_next);
             wload(d, wave + NWV * (i + d + 2));
         }
     }
@@ -145,6 +150,7 @@ struct FewrowSegs {
 template <int NSUB>
 __global__ __launch_bounds__(512, 2) void gemm_fewrow_stream_kernel(const void* xf, int M, int K, FewrowSegs sg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int XS = NSUB <= 3 ? 8 : 4;          // x steps in flight: two K tiles where the accumulators leave room (<= 256 VGPRs, no scratch)
     int seg = 0;
 #pragma unroll
     for (int i = 1; i < GEMV_MAX_SEG; ++i)
@@ -153,12 +159,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fewrow_stream_kernel(const void* 
                sg.y_stride[seg], nullptr, 1, sg.residual[seg], nullptr};
     const int bx = (int)blockIdx.x - sg.wg_begin[seg];
     switch (sg.key[seg]) {
-        case 4 * 2 + MODE_HQQ: fewrow_stream_body<4, MODE_HQQ, NSUB>(a, bx, smem); break;
-        case 3 * 2 + MODE_HQQ: fewrow_stream_body<3, MODE_HQQ, NSUB>(a, bx, smem); break;
-        case 2 * 2 + MODE_HQQ: fewrow_stream_body<2, MODE_HQQ, NSUB>(a, bx, smem); break;
-        case 4 * 2 + MODE_FMA: fewrow_stream_body<4, MODE_FMA, NSUB>(a, bx, smem); break;
-        case 3 * 2 + MODE_FMA: fewrow_stream_body<3, MODE_FMA, NSUB>(a, bx, smem); break;
-        default: fewrow_stream_body<2, MODE_FMA, NSUB>(a, bx, smem); break;
+        case 4 * 2 + MODE_HQQ: fewrow_stream_body<4, MODE_HQQ, NSUB, XS>(a, bx, smem); break;
+        case 3 * 2 + MODE_HQQ: fewrow_stream_body<3, MODE_HQQ, NSUB, XS>(a, bx, smem); break;
+        case 2 * 2 + MODE_HQQ: fewrow_stream_body<2, MODE_HQQ, NSUB, XS>(a, bx, smem); break;
+        case 4 * 2 + MODE_FMA: fewrow_stream_body<4, MODE_FMA, NSUB, XS>(a, bx, smem); break;
+        case 3 * 2 + MODE_FMA: fewrow_stream_body<3, MODE_FMA, NSUB, XS>(a, bx, smem); break;
+        default: fewrow_stream_body<2, MODE_FMA, NSUB, XS>(a, bx, smem); break;
     }
 }
 
