@@ -498,7 +498,10 @@ static hipError_t skinny_launch_xf(const GemmArgs& a, hipStream_t st) {
     const int nblk = a.N >> 4;
     const int ny = (a.M + 63) / 64;
     const long blocks = (long)nblk * ny;
-    if (blocks <= 320) {
+#ifndef AMQ_XF_NSUB1_MAX
+#define AMQ_XF_NSUB1_MAX 320
+#endif
+    if (blocks <= AMQ_XF_NSUB1_MAX) {
         hipLaunchKernelGGL((gemm_skinny_kernel<BITS, MODE, 4, 1, 2, 8, true>), dim3(nblk, ny), dim3(512), 8 * 4096, st, a);
     } else if (blocks <= 640) {
         hipLaunchKernelGGL((gemm_skinny_kernel<BITS, MODE, 4, 2, 2, 8, true>), dim3((nblk + 1) / 2, ny), dim3(512), 8 * 2 * 4096, st, a);
