@@ -345,8 +345,9 @@ __device__ __forceinline__ void x_finish_dma(const GemvHot& a, const XRegs& xr, 
     static_assert(NRING >= 0 && NRING <= 63, "counted wait (vmcnt is six bits on gfx9)");
     const int tid = threadIdx.x;
     const int chunks = Ks >> 3;
-    if (PRO == PRO_RMSNORM) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRING) : "memory");      // (gamma's loads are older than the ring too)
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRING) : "memory");
+    // everything this wave issued before the ring's NRING loads has landed: its LDS-DMA transfers (and, RMSNorm, gamma's loads, issued right behind them).
+    // Inline asm: the compiler neither sees the transfers nor may it move LDS reads above this wait ("memory").
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRING) : "memory");
     if (PRO == PRO_NONE) return;
     if (PRO == PRO_RMSNORM) {
         // all rows side by side (MR = the kernel's row bound, rows >= M predicated off by uniform branches): the rows' LDS reads, square sums and

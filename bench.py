@@ -67,54 +67,70 @@ def build_model(device, seed=0, max_seq=1024, model=MODEL, pinned=None, batch=1,
     return m, a, usage
 
 
+def _decode_rate(dev, m, prompt, warm, steps, recapture=False):
+    """decode steps per second of runner ``m`` after a ``prompt``-token prefill (None: keep its context): capture, ``warm`` replays, ``steps`` timed"""
+    if prompt is not None:
+        ids = torch.randint(0, m.vocab - 1, (m.B, prompt) if m.B > 1 else (prompt,), generator=torch.Generator().manual_seed(0)).to(dev)
+        m.prefill(ids, use_graph=False)
+    if recapture:
+        m.graph = None
+    m.capture()
+    for _ in range(warm):
+        m.decode_step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.decode_step()
+    torch.cuda.synchronize(dev)
+    rate = steps / (time.perf_counter() - t0)
+    m.check()
+    return rate
+
+
+class _gemv_math:
+    """run a block with the GEMV's opt-in arithmetic as the tools' default option (ops.DEFAULT_GEMV_OPTS; restored on exit)"""
+
+    def __init__(self, math):
+        self.math = math
+
+    def __enter__(self):
+        from amq_amd import ops
+        self.old = ops.DEFAULT_GEMV_OPTS
+        ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(math=self.math)
+
+    def __exit__(self, *exc):
+        from amq_amd import ops
+        ops.DEFAULT_GEMV_OPTS = self.old
+
+
 def beyond_the_metric(dev):
-    """Two figures next to the headline (NOT part of `value`; same workload and weights, rank 0 at N = 1 only): decode over a long
-    cache (2048 cached keys: the attention step split over several workgroups per head) and 8 sequences decoded together (one
-    pass over the weights per step).  Each is a short graph-replayed run; a failure is reported as a string, never raised."""
+    """Figures next to the headline (NOT part of `value`; rank 0 at N = 1 only), each a short graph-replayed run whose failure is reported as a
+    string, never raised: the headline workload over a long cache (2048 cached keys: the attention step split over several workgroups per head),
+    with 8 sequences decoded together (one pass over the weights per step), with its weights in the reference kernels' arithmetic, and under
+    the GEMV's opt-in arithmetic; one replica of BASELINE.json configs[4] (Llama-2-70B) and one prompt pass of configs[3] (Llama-2-13B, 16 x 2048)."""
+    from amq_amd import ops
     out = {}
-    try:
+
+    def leg(key, fn):
+        try:
+            out[key] = fn()
+        except Exception as e:      # noqa: BLE001
+            out[key] = "failed: %r" % (e,)
+        torch.cuda.empty_cache()
+
+    def long_cache():
         m, _, _ = build_model(dev, seed=0, max_seq=2048 + 64 + 16)
-        ids = torch.randint(0, m.vocab - 1, (2048,), generator=torch.Generator().manual_seed(0)).to(dev)
-        m.prefill(ids, use_graph=False)
-        m.capture()
-        for _ in range(8):
-            m.decode_step()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(48):
-            m.decode_step()
-        torch.cuda.synchronize(dev)
-        out["decode_tokens_per_s_at_2048_cached_keys"] = round(48 / (time.perf_counter() - t0), 1)
-        m.check()
-        del m
-        torch.cuda.empty_cache()
-    except Exception as e:      # noqa: BLE001
-        out["decode_tokens_per_s_at_2048_cached_keys"] = "failed: %r" % (e,)
-    try:
-        B = 8
-        m, _, _ = build_model(dev, seed=0, max_seq=PROMPT + 96, batch=B)
-        ids = torch.randint(0, m.vocab - 1, (B, PROMPT), generator=torch.Generator().manual_seed(0)).to(dev)
-        m.prefill(ids, use_graph=False)
-        m.capture()
-        for _ in range(8):
-            m.decode_step()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(64):
-            m.decode_step()
-        torch.cuda.synchronize(dev)
-        out["decode_tokens_per_s_8_sequences"] = round(B * 64 / (time.perf_counter() - t0), 1)
-        m.check()
-        del m
-        torch.cuda.empty_cache()
-    except Exception as e:      # noqa: BLE001
-        out["decode_tokens_per_s_8_sequences"] = "failed: %r" % (e,)
-    try:
+        return round(_decode_rate(dev, m, 2048, 8, 48), 1)
+
+    def eight_sequences():
+        m, _, _ = build_model(dev, seed=0, max_seq=PROMPT + 96, batch=8)
+        return round(8 * _decode_rate(dev, m, PROMPT, 8, 64), 1)
+
+    def reference_format():
         # the same model with its weights in the REFERENCE's kernel arithmetic, w = fma(q, s, c) with c = -(z s) (one rounding: what its GPTQ / AWQ
         # cache files decode to, auto_gptq_kernel.cu:206, gemv_cuda.cu:151), as a swapped model loaded from those files runs: AMQ_MODE_FMA1, one packed
         # fma per weight pair in the GEMV kernel (bit-identical to AMQ_MODE_FMA; HISTORY.md 7 item 5).  NOT `value`: the headline is the HQQ arithmetic
         # (two roundings) that the parity gate's W_deq is
-        from amq_amd import ops
         m, _, _ = build_model(dev, seed=0, max_seq=PROMPT + 96)
         modes = set()
         for blk in m.blocks:
@@ -124,94 +140,32 @@ def beyond_the_metric(dev):
                 mt[:, 1] = (-(mt[:, 1].float() * mt[:, 0].float())).to(torch.float16)
                 l.mode = ops.fma_mode_for(l.mn, l.bits)
                 modes.add(l.mode)
-        ids = torch.randint(0, m.vocab - 1, (PROMPT,), generator=torch.Generator().manual_seed(0)).to(dev)
-        m.prefill(ids, use_graph=False)
-        m.capture()
-        for _ in range(8):
-            m.decode_step()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(64):
-            m.decode_step()
-        torch.cuda.synchronize(dev)
-        out["decode_tokens_per_s_reference_format_weights"] = round(64 / (time.perf_counter() - t0), 1)
-        out["reference_format_modes"] = sorted(modes)
-        m.check()
+        rate = _decode_rate(dev, m, PROMPT, 8, 64)
         assert bool(torch.isfinite(m.logits.float()).all().item())
-        del m
-        torch.cuda.empty_cache()
-    except Exception as e:      # noqa: BLE001
-        out["decode_tokens_per_s_reference_format_weights"] = "failed: %r" % (e,)
-    try:
-        # the headline workload under the opt-in GROUPSCALE arithmetic (include/amq_hip.h AMQ_MATH_GROUPSCALE: the first fp16 rounding per weight exact, the
-        # scale applied per 128-group in fp32 after the MFMAs; 3.2e-4 rms(y) from the oracle, up to 0.93 of the parity bar -- and past it behind a bias
-        # add: why it is not the default).  NOT `value`.
-        from amq_amd import ops
-        old = ops.DEFAULT_GEMV_OPTS
-        ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(math=ops.MATH_GROUPSCALE)
-        try:
+        out["reference_format_modes"] = sorted(modes)
+        return round(rate, 1)
+
+    def groupscale():
+        # the headline workload under the opt-in GROUPSCALE arithmetic (include/amq_hip.h AMQ_MATH_GROUPSCALE: the first fp16 rounding per weight exact,
+        # the scale applied per 128-group in fp32 after the MFMAs; 3.2e-4 rms(y) from the oracle, up to 0.93 of the parity bar -- and past it behind a
+        # bias add: why it is not the default)
+        with _gemv_math(ops.MATH_GROUPSCALE):
             m, _, _ = build_model(dev, seed=0, max_seq=PROMPT + 96)
-            ids = torch.randint(0, m.vocab - 1, (PROMPT,), generator=torch.Generator().manual_seed(0)).to(dev)
-            m.prefill(ids, use_graph=False)
-            m.capture()
-            for _ in range(8):
-                m.decode_step()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(64):
-                m.decode_step()
-            torch.cuda.synchronize(dev)
-            out["decode_tokens_per_s_groupscale_math"] = round(64 / (time.perf_counter() - t0), 1)
-            m.check()
-            del m
-        finally:
-            ops.DEFAULT_GEMV_OPTS = old
-        torch.cuda.empty_cache()
-    except Exception as e:      # noqa: BLE001
-        out["decode_tokens_per_s_groupscale_math"] = "failed: %r" % (e,)
-    try:
+            return round(_decode_rate(dev, m, PROMPT, 8, 64), 1)
+
+    def llama70b():
         # BASELINE.json configs[4], one replica (what `--config 5 --gpus 1` prints as its own line): Llama-2-70B shapes, avg-3-bit arch, batch-1 decode
         m, _, usage = build_model(dev, seed=0, max_seq=PROMPT + 72, model="Llama-2-70b-hf", pinned=())
-        ids = torch.randint(0, m.vocab - 1, (PROMPT,), generator=torch.Generator().manual_seed(0)).to(dev)
-        m.prefill(ids)
-        m.capture()
-        for _ in range(8):
-            m.decode_step()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(24):
-            m.decode_step()
-        torch.cuda.synchronize(dev)
-        tps = 24 / (time.perf_counter() - t0)
-        m.check()
+        tps = _decode_rate(dev, m, PROMPT, 8, 24)
         roof = gemv_roofline(m, reps=5)
-        from amq_amd import ops
-        old = ops.DEFAULT_GEMV_OPTS
-        ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(math=ops.MATH_GROUPSCALE)
-        try:                                            # (the same replica under the opt-in arithmetic: a fresh capture of the same buffers)
-            m.graph = None
-            m.capture()
-            for _ in range(4):
-                m.decode_step()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(16):
-                m.decode_step()
-            torch.cuda.synchronize(dev)
-            tps_gs = 16 / (time.perf_counter() - t0)
-            m.check()
-        finally:
-            ops.DEFAULT_GEMV_OPTS = old
-        out["llama70b_one_replica"] = {"tokens_per_s": round(tps, 2), "roofline_frac": round(roof["gbps"] / HBM_PEAK_GBPS, 3),
-                                       "tokens_per_s_groupscale_math": round(tps_gs, 2),
-                                       "us_per_launch": round(roof["us_per_launch"], 2), "gbps": round(roof["gbps"], 1),
-                                       "linear_gb_per_token": round(m.linear_bytes_per_token() / 1e9, 2), "bits_usage": round(usage, 3),
-                                       "steps": 24, "warmup": 8, "config": "BASELINE.json configs[4], one of its 8 independent streams"}
-        del m
-        torch.cuda.empty_cache()
-    except Exception as e:      # noqa: BLE001
-        out["llama70b_one_replica"] = "failed: %r" % (e,)
-    try:
+        with _gemv_math(ops.MATH_GROUPSCALE):           # (the same replica under the opt-in arithmetic: a fresh capture over the same buffers)
+            tps_gs = _decode_rate(dev, m, None, 4, 16, recapture=True)
+        return {"tokens_per_s": round(tps, 2), "roofline_frac": round(roof["gbps"] / HBM_PEAK_GBPS, 3),
+                "tokens_per_s_groupscale_math": round(tps_gs, 2), "us_per_launch": round(roof["us_per_launch"], 2),
+                "gbps": round(roof["gbps"], 1), "linear_gb_per_token": round(m.linear_bytes_per_token() / 1e9, 2), "bits_usage": round(usage, 3),
+                "steps": 24, "warmup": 8, "config": "BASELINE.json configs[4], one of its 8 independent streams"}
+
+    def llama13b():
         # BASELINE.json configs[3] end to end (what `--config 4` prints as its own line): Llama-2-13B, one batched prompt pass of 16 x 2048 rows
         B, S = 16, 2048
         m, _, usage = build_model(dev, seed=0, max_seq=S, model="Llama-2-13b-hf", pinned=())
@@ -225,14 +179,17 @@ def beyond_the_metric(dev):
             torch.cuda.synchronize(dev)
             dt = (time.perf_counter() - t0) / 2
         total_flops = sum(2.0 * B * S * blk[name].N * blk[name].K for blk in m.blocks for name in m.cfg["linear"])
-        out["llama13b_prompt_pass"] = {"passes_per_s": round(1 / dt, 3), "ms_per_pass": round(dt * 1e3, 1),
-                                       "whole_pass_tflops": round(total_flops / dt / 1e12, 1), "prompt_tokens_per_s": round(B * S / dt),
-                                       "finite_logits": bool(torch.isfinite(logits.float()).all().item()), "bits_usage": round(usage, 3),
-                                       "config": "BASELINE.json configs[3]: 16 x 2048 rows, whole model (linears + attention + norms + lm_head)"}
-        del m, logits
-        torch.cuda.empty_cache()
-    except Exception as e:      # noqa: BLE001
-        out["llama13b_prompt_pass"] = "failed: %r" % (e,)
+        return {"passes_per_s": round(1 / dt, 3), "ms_per_pass": round(dt * 1e3, 1), "whole_pass_tflops": round(total_flops / dt / 1e12, 1),
+                "prompt_tokens_per_s": round(B * S / dt), "finite_logits": bool(torch.isfinite(logits.float()).all().item()),
+                "bits_usage": round(usage, 3),
+                "config": "BASELINE.json configs[3]: 16 x 2048 rows, whole model (linears + attention + norms + lm_head)"}
+
+    leg("decode_tokens_per_s_at_2048_cached_keys", long_cache)
+    leg("decode_tokens_per_s_8_sequences", eight_sequences)
+    leg("decode_tokens_per_s_reference_format_weights", reference_format)
+    leg("decode_tokens_per_s_groupscale_math", groupscale)
+    leg("llama70b_one_replica", llama70b)
+    leg("llama13b_prompt_pass", llama13b)
     return out
 
 
