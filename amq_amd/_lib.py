@@ -20,6 +20,7 @@ MODE_HQQ, MODE_FMA, MODE_FMA1 = 0, 1, 2
 PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
 MATH_DEFAULT, MATH_LINEAR, MATH_GROUPSCALE, MATH_EXACT = 0, 1, 2, 3
+FEWROW_AUTO, FEWROW_TILE, FEWROW_STREAM = 0, 1, 2      # kernel form of the grouped few-row launch (amq_gemm_xfrag_grouped_form_f16)
 ABI_VERSION = 500            # include/amq_hip.h AMQ_VERSION these bindings mirror (checked at load)
 GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, GEMM_WS, GEMM_DEQ = 0, 1, 2, 3, 4, 5, 6
 
@@ -87,6 +88,7 @@ SIGNATURES = {
     "amq_attn_decode_split_workspace_bytes": (_sz, [_i, _i, _i]),
     "amq_attn_decode_split_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _sz, _vp, _vp]),
     "amq_gemm_xfrag_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _i, _i, _i, _vp]),
+    "amq_gemm_xfrag_grouped_form_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "amq_attn_prefill_xfrag_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 5 + [_vp]),
     "amq_gemv_f16w_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp]),
     "amq_decode_tail_batch_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

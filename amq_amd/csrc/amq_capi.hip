@@ -365,6 +365,14 @@ int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qn, const
 }
 
 int amq_gemm_xfrag_grouped_f16(const amq_segment* segs, int nseg, const void* xf, int M, int K, int group, void* stream) {
+    return amq_gemm_xfrag_grouped_form_f16(segs, nseg, xf, M, K, group, AMQ_FEWROW_AUTO, 0, stream);
+}
+
+int amq_gemm_xfrag_grouped_form_f16(const amq_segment* segs, int nseg, const void* xf, int M, int K, int group, int form, int blocks_per_wg,
+                                    void* stream) {
+    if (form < AMQ_FEWROW_AUTO || form > AMQ_FEWROW_STREAM) return fail(AMQ_EINVAL, "unknown few-row form %d", form);
+    if (blocks_per_wg != 0 && (form != AMQ_FEWROW_STREAM || blocks_per_wg < 1 || blocks_per_wg > 6 || blocks_per_wg == 5))
+        return fail(AMQ_EINVAL, "blocks_per_wg is 0, or 1 / 2 / 3 / 4 / 6 with AMQ_FEWROW_STREAM (got %d)", blocks_per_wg);
     if (!segs || nseg < 1 || nseg > AMQ_MAX_SEGMENTS) return fail(AMQ_EINVAL, "nseg must be 1..%d (got %d)", AMQ_MAX_SEGMENTS, nseg);
     if (!xf) return fail(AMQ_EINVAL, "null xf");
     if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
@@ -380,7 +388,7 @@ int amq_gemm_xfrag_grouped_f16(const amq_segment* segs, int nseg, const void* xf
         d.N = s.N; d.bits = s.bits; d.mode = kernel_mode(s.mode);
         d.y_stride = s.y_stride ? s.y_stride : s.N;
     }
-    return check_hip(amq::launch_gemm_xfrag_grouped(xf, M, K, gs, nseg, (hipStream_t)stream), "gemm_xfrag_grouped");
+    return check_hip(amq::launch_gemm_xfrag_grouped(xf, M, K, gs, nseg, (hipStream_t)stream, form, blocks_per_wg), "gemm_xfrag_grouped");
 }
 
 #ifdef AMQ_AB_ROUTES     /* A/B routes: exported by libamq_hip_ab.so (make ab), declared in include/amq_hip_ab.h */

@@ -427,7 +427,8 @@ static hipError_t skinny_grouped_launch(const void* xf, int M, int K, SkinnySegs
 #ifndef AMQ_FEWROW_STREAM
 #define AMQ_FEWROW_STREAM 1
 #endif
-hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg* segs, int nseg, hipStream_t st) {
+hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg* segs, int nseg, hipStream_t st, int form, int nsub_forced) {
+    if (form == 2) return launch_gemm_fewrow_stream_grouped(xf, M, K, segs, nseg, st, nsub_forced);
     long blocks = 0;
     for (int i = 0; i < nseg; ++i) blocks += segs[i].N >> 4;
     blocks *= (M + 63) / 64;
@@ -449,7 +450,7 @@ hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg
             wg_new += ((segs[i].N >> 4) + nsub_new - 1) / nsub_new;
         }
         const long rounds_old = (wg_old * ny + cus - 1) / cus, rounds_new = (wg_new * ny + cus - 1) / cus;
-        if (rounds_new < rounds_old || AMQ_FEWROW_STREAM == 2) return launch_gemm_fewrow_stream_grouped(xf, M, K, segs, nseg, st);      // (2: A/B builds, always)
+        if (form == 0 && (rounds_new < rounds_old || AMQ_FEWROW_STREAM == 2)) return launch_gemm_fewrow_stream_grouped(xf, M, K, segs, nseg, st);      // (2: A/B builds, always)
     }
 #endif
     SkinnySegs sg{};

@@ -193,13 +193,13 @@ int fewrow_stream_nsub(long blocks, int row_groups, int cus) {
     return nsub > 6 ? 6 : nsub;
 }
 
-hipError_t launch_gemm_fewrow_stream_grouped(const void* xf, int M, int K, const GemvSeg* segs, int nseg, hipStream_t st) {
+hipError_t launch_gemm_fewrow_stream_grouped(const void* xf, int M, int K, const GemvSeg* segs, int nseg, hipStream_t st, int nsub_forced) {
     StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     long blocks = 0;
     for (int i = 0; i < nseg; ++i) blocks += segs[i].N >> 4;
-    const int nsub = fewrow_stream_nsub(blocks, (M + 63) / 64, cus);
+    const int nsub = nsub_forced > 0 ? nsub_forced : fewrow_stream_nsub(blocks, (M + 63) / 64, cus);
     FewrowSegs sg{};
     sg.nseg = nseg;
     int wg = 0;

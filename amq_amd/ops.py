@@ -385,10 +385,11 @@ def gemm_xfrag(xf, M, qn, mn, bits, mode, N, K, bias=None, out=None, residual=No
     return y
 
 
-def gemm_xfrag_grouped(xf, M, segments, K):
+def gemm_xfrag_grouped(xf, M, segments, K, form=0, blocks_per_wg=0):
     """One few-row launch for several linears over the same fragment-ordered x (q/k/v, gate/up of a prompt pass).
     segments: list of dicts {qn, mn, bits, mode, N, y, bias=None, residual=None} (y / residual: fp16 [M, N] contiguous).
-    Per segment the result is :func:`gemm_xfrag`'s, bit for bit."""
+    Per segment the result is :func:`gemm_xfrag`'s, bit for bit -- whatever the kernel form (``form``: _lib.FEWROW_AUTO / _TILE / _STREAM,
+    ``blocks_per_wg`` with _STREAM: tests and A/B tools)."""
     if not 1 <= len(segments) <= _lib.MAX_SEGMENTS:
         raise ValueError(f"1..{_lib.MAX_SEGMENTS} segments")
     lib = _lib.load()
@@ -404,7 +405,7 @@ def gemm_xfrag_grouped(xf, M, segments, K):
             _need(s["residual"], torch.float16, "residual", M * s["N"])
         arr[i] = Segment(_lib.ptr(s["qn"]), _lib.ptr(s["mn"]), _lib.ptr(s.get("bias")), _lib.ptr(s.get("residual")),
                          _lib.ptr(s["y"]), s["N"], s["bits"], s["mode"], 0)
-    _lib.check(lib.amq_gemm_xfrag_grouped_f16(arr, len(segments), _lib.ptr(xf), M, K, GROUP, _lib.current_stream()))
+    _lib.check(lib.amq_gemm_xfrag_grouped_form_f16(arr, len(segments), _lib.ptr(xf), M, K, GROUP, int(form), int(blocks_per_wg), _lib.current_stream()))
 
 
 def linear(x, qn, mn, bits, mode, N, K, bias=None):

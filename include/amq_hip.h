@@ -330,6 +330,15 @@ int amq_gemm_xfrag_f16(int bits, int mode, const void* xf, const void* qweight_n
  * y_i = x . W_i^T (+ bias_i) (+ residual_i).  Results are those of amq_gemm_xfrag_f16 per segment, bit for bit. */
 int amq_gemm_xfrag_grouped_f16(const amq_segment* segments /* host */, int nseg, const void* xf, int M, int K, int group,
                                void* stream);
+/* The same launch with its kernel form chosen by the caller (tests, A/B tools; the results do not depend on it, bit for bit):
+ * AMQ_FEWROW_AUTO = what amq_gemm_xfrag_grouped_f16 runs (the streaming form where it saves a round of the chip), AMQ_FEWROW_TILE = x fragments a
+ * whole K tile at a time (up to four 16-column blocks per workgroup), AMQ_FEWROW_STREAM = one MFMA step at a time through a register ring
+ * (amq_gemm_fewrow.hip; blocks_per_wg 1, 2, 3, 4 or 6; 0 = by the launch's size). */
+#define AMQ_FEWROW_AUTO   0
+#define AMQ_FEWROW_TILE   1
+#define AMQ_FEWROW_STREAM 2
+int amq_gemm_xfrag_grouped_form_f16(const amq_segment* segments /* host */, int nseg, const void* xf, int M, int K, int group,
+                                    int form, int blocks_per_wg, void* stream);
 /* Causal self-attention over a prompt: for every sequence b < batch, query row s < S (position pos0 + s) and head h,
  *     out[b, s, h, :] = softmax(q[b, s, h, :] . K[b, 0 .. pos0 + s, g, :]^T / sqrt(128)) . V[b, 0 .. pos0 + s, g, :],   g = h / (n_heads / n_kv_heads)
  * as one flash-style MFMA kernel (fp32 scores and softmax, fp16 probabilities, like the eager HF path).  q must already be

@@ -896,6 +896,28 @@ def test_gemm_xfrag_grouped_equals_single_launches(m, k, specs):
         assert torch.equal(s["y"], one)
         if res is None:
             _assert_close(s["y"].cpu().numpy(), linear_ref.linear_f16(x.numpy(), w_ref, b), "grouped few-row segment")
+    # every kernel form of the launch gives the same bits: x fragments a K tile at a time, and the streaming form (one MFMA step at a time,
+    # amq_gemm_fewrow.hip) at each of its block counts -- ragged last workgroups, segment boundaries inside the grid, several row groups
+    from amq_amd import _lib
+    for form, blocks in [(_lib.FEWROW_TILE, 0), (_lib.FEWROW_STREAM, 0)] + [(_lib.FEWROW_STREAM, b) for b in (1, 2, 3, 4, 6)]:
+        for s, (w_ref, b, res) in zip(segs, refs):
+            if res is not None:
+                s["y"].copy_(res)                          # (the residual segment accumulates in place)
+            else:
+                s["y"].zero_()
+        ops.gemm_xfrag_grouped(xf, m, segs, k, form=form, blocks_per_wg=blocks)
+        for s, one in zip(segs, singles):
+            assert torch.equal(s["y"], one), (form, blocks)
+    # ... and the one-rounding (reference-format) bodies: the first segment's buffers in MODE_FMA form, streaming form against the single launch
+    s0 = segs[0]
+    mt = s0["mn"].clone().view(-1, 2)
+    mt[:, 1] = -(mt[:, 1] * mt[:, 0])
+    fseg = dict(s0, mn=mt.reshape(-1), mode=ops.MODE_FMA, y=torch.empty_like(s0["y"]), residual=None)
+    one = ops.gemm_xfrag(xf, m, fseg["qn"], fseg["mn"], fseg["bits"], ops.MODE_FMA, fseg["N"], k, bias=fseg["bias"])
+    for blocks in (1, 3, 6):
+        fseg["y"].zero_()
+        ops.gemm_xfrag_grouped(xf, m, [fseg], k, form=_lib.FEWROW_STREAM, blocks_per_wg=blocks)
+        assert torch.equal(fseg["y"], one), blocks
 
 
 @pytest.mark.parametrize("bits", [2, 3, 4])
