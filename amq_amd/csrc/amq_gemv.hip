@@ -70,17 +70,14 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     int total_rt = 0;
     for (int i = 0; i < a.nseg; ++i) { a.seg[i].n_rt = a.seg[i].N / 16; total_rt += a.seg[i].n_rt; }
     int nw = a.force_waves ? a.force_waves : gemv_pick_waves(total_rt, a.K);
-    // several rows (batched decode): the staged x grows with M, and once fewer than three 8-wave workgroups fit a CU's LDS one
-    // 16-wave workgroup keeps more waves on the weight stream (7B, 8 sequences: 2.76 -> 2.15 ms a step; 4 sequences still fit three)
-    // with at most 8 rows the cross-wave sum needs half its buffer (RS = 128): at 5 rows three 8-wave workgroups fit a CU again
-    // (7B: 2.20 -> 2.01 ms a step); TWO 8-wave workgroups (6 - 8 rows) measured slower than one 16-wave workgroup (2.28 / 2.34 vs
-    // 2.10 / 2.19 ms), so those keep the 16-wave form (profiles/r02_decode_batch.txt)
     const int gp = a.gp > 1 ? a.gp : 1;                    // meta pairs per tile (groups of 64 / 32: 2 / 4)
     if (gp != 1 && gp != 2 && gp != 4) return hipErrorInvalidValue;
     if (gp > 1 && ((a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) || a.force_depth == 4)) return hipErrorInvalidValue;   // (the C ABI says so first)
-    // launches of 2 .. 8 rows (sequences decoded together) take the kernels with the half-size cross-wave sum buffer (RS = 128) and the
-    // register-held row staging (x_issue_rows): three 8-wave workgroups per CU while their LDS fits (K = 4096: up to 5 rows), else one 16-wave
-    // workgroup (TWO 8-wave workgroups measured slower at 6 - 8 rows: profiles/r02_decode_batch.txt, r05_decode_batch.txt)
+    // Launches of 2 .. 8 rows (sequences decoded together) take the row kernels: x by LDS-DMA ahead of the weight ring, cross-wave sum buffer sized
+    // for their rows (RS = 64: 2 .. 4 rows, 78 - 80 VGPRs, three 8-wave workgroups per CU while their LDS fits; RS = 128: 5 .. 8 rows, two per CU;
+    // one 16-wave workgroup where not even two fit, e.g. K = 11008).  7 - 8 rows of a K whose rows do not fit LDS whole: two K phases (ph2).
+    // Measured against these: rows held in registers, one 16-wave workgroup per CU throughout (profiles/r05_decode_batch.txt).  9 .. 16 rows,
+    // A/B options and groups of 64 / 32 keep the generic staging (RS = 256), 16 waves once three 8-wave workgroups no longer fit.
     bool rs128 = false, rs64 = false;
     const bool plain = !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4 && gp == 1;
     const bool ph2 = !a.force_waves && a.force_rpt <= 0 && gemv_rows_phased(a.M, a.K, plain, a.prologue == PRO_RMSNORM);
