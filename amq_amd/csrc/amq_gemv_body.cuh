@@ -23,11 +23,18 @@
 //                 dequant, 12 VALU cycles per weight pair (amq_common.cuh).
 //     MATH_DOT    (A/B only, M == 1): same weights, v_dot2c_f32_f16 + wavefront-shuffle
 //                 reduction instead of MFMA.
+//     MATH_GS     (opt-in, AMQ_MATH_GROUPSCALE): the first rounding exactly as MATH_EXACT at E = -9 -- a field is used where the packing left
+//                 it, one shift per dword -- the scale applied once per (row, group) in fp32 after the tile's four MFMAs; 6.5 cycles per
+//                 pair, ~3.2e-4 of the output rms from the reference result (amq_common.cuh dequant_lane_gs; one-rounding modes and the
+//                 finer groups run their exact bodies under it).
 //     MATH_LINEAR (opt-in): every field is shifted to one mantissa position and fed to the MFMA as the fp16
 //                 subnormal q*2^(SH-24) (gfx950 MFMA honours fp16 subnormals -- measured); scale / zero are applied
 //                 per group in fp32:  y += s*(2^(24-SH)*sum(x q) - z*sum_g(x)), with the group sums of x taken once in
 //                 the staging pass.  4 VALU cycles per pair; results are the real-valued dequant (no per-weight fp16
 //                 roundings), ~3e-4 of the output rms away from the reference's rounded-weight result.
+//   * x staging: one row -- its loads leave first and are held in registers across the ring's priming (x_issue / x_finish); 2 .. 8 rows -- the
+//     rows go straight into LDS by LDS-DMA ahead of the ring, transform applied in place (x_dma_rows / x_finish_dma; kernels RS = 64 / 128; PH = 2:
+//     two K phases for rows that do not fit LDS whole); otherwise the generic stage_x.
 //   * per row-tile, fixed-order cross-wave sum through double-buffered LDS and one
 //     barrier: deterministic, no atomics.
 //   * several linears that share x (q/k/v, gate/up) with different bit-widths
