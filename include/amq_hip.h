@@ -142,9 +142,11 @@ int amq_dequantize_hqq_f16(int bits, const void* W_q, const void* scale, const v
                            int N, int K, int group, void* W_out, void* stream);
 
 /* ---- the hot path: y[M,N] = x[M,K] . W^T (+ bias) ------------------------ */
-/* few rows (decode).  The unpacked weights are the MFMA B operand straight from registers (W never touches LDS).
- * M <= 16 and M * (K + 8) * 2 + 16 KiB <= 160 KiB of LDS, AMQ_ESHAPE beyond -- use amq_gemm_f16.
- * x_stride / y_stride in elements (0 = dense). */
+/* few rows (decode).  The unpacked weights are the MFMA B operand straight from registers (W never touches LDS); the x rows are staged in LDS.
+ * M <= 16 and the rows must fit LDS: M * (K + 8) * 2 bytes + the cross-wave sum buffer (4 - 32 KiB by row count) <= 160 KiB -- except that with
+ * default options, no RMSNorm prologue and 5 .. 8 rows a K whose rows do not fit whole is staged in two K phases (8 rows of K = 11008).
+ * amq_query(K) returns the row limits; AMQ_ESHAPE beyond -- use amq_gemm_f16.  x_stride / y_stride in elements (0 = dense; 2 .. 8 dense rows
+ * take the LDS-DMA staging path, strided rows the generic one: same results). */
 int amq_gemv_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
                  const void* bias, void* y, int M, int N, int K, int group,
                  int x_stride, int y_stride, void* stream);
