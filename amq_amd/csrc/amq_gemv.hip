@@ -108,10 +108,18 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
         rpt = (total_rt + target - 1) / target;
         if (rpt < 1) rpt = 1;
     }
+    // several workgroups per CU that each hold a large x (the 5 .. 8-row kernels: two per CU): the launch's 512 workgroups are dealt to the segments in
+    // proportion to their row-tiles, so that every CU ends up with the same load -- q/k/v of 7B at 8 rows: 3 x 170 workgroups of 2 or 1 row-tiles
+    // (3 per CU) instead of 3 x 128 of 2 (4 on half of the CUs, 2 on the others; profiles/r05_decode_batch.txt)
+    const bool deal = a.force_rpt <= 0 && !ph2 && rs128 && nw == 8 && total_rt > 512 && total_rt / 512 < 255;
     int wg = 0, mask = 0;
     for (int i = 0; i < a.nseg; ++i) {
         a.seg[i].wg_begin = wg;
         a.seg[i].wg_count = (a.seg[i].n_rt + rpt - 1) / rpt;
+        if (deal) {
+            const int share = (int)((long long)512 * a.seg[i].n_rt / total_rt);
+            a.seg[i].wg_count = share < 1 ? 1 : share > a.seg[i].n_rt ? a.seg[i].n_rt : share;
+        }
         wg += a.seg[i].wg_count;
         mask |= 1 << a.seg[i].bits;
     }
@@ -126,7 +134,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
         const GemvSeg& s = a.seg[i];
         // (the one-op unpack of MODE_FMA1 exists in the exact-math, group-128 bodies; elsewhere such buffers run as MODE_FMA: same results)
         const bool has_fma1 = gp == 1 && !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR));
-        k.wg_begin[i] = s.wg_begin; k.n_rt[i] = s.n_rt; k.key[i] = s.bits * 4 + (s.mode == MODE_FMA1 && !has_fma1 ? (int)MODE_FMA : s.mode);
+        k.wg_begin[i] = s.wg_begin; k.n_rt[i] = gemv_split(s.n_rt, s.wg_count); k.key[i] = s.bits * 4 + (s.mode == MODE_FMA1 && !has_fma1 ? (int)MODE_FMA : s.mode);
         k.qweight[i] = s.qweight; k.meta[i] = s.meta;
         k.bias[i] = s.bias; k.residual[i] = s.residual; k.y[i] = s.y; k.y_stride[i] = s.y_stride;
     }

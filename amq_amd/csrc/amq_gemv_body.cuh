@@ -56,7 +56,7 @@ struct GemvKArgs {
     int M, K, x_stride, nseg;
     float eps; int rpt, pad0_, pad1_;
     int wg_begin[GEMV_MAX_SEG];
-    int n_rt[GEMV_MAX_SEG];
+    int n_rt[GEMV_MAX_SEG];                // gemv_split(row-tiles, workgroups) of the segment
     int key[GEMV_MAX_SEG];                 // bits * 4 + mode
     const void* qweight[GEMV_MAX_SEG];
     const void* meta[GEMV_MAX_SEG];
@@ -513,7 +513,7 @@ __device__ __forceinline__ void unpack_lane_sub(const uint32_t* w, h2* out) {
 //     slices the workgroup restages (barrier, LDS-DMA of the next slice behind the still-full weight ring, transform, barrier)
 template <int BITS, int MODE, int PRO, int NW, int U, int MATH, int XCH, int RS = 256, bool SC1 = false, int GP = 1, int PH = 1>
 __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk, int sidx, const void* qweight, const void* meta_base,
-                                          int seg_n_rt, int local, _Float16* lds_x, const _Float16* xl, float* xg,
+                                          int seg_split, int local, _Float16* lds_x, const _Float16* xl, float* xg,
                                           float* red, int xs, int xmode, const XRegs& xr) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -522,8 +522,11 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     static_assert(PH == 1 || (RS != 256 && PRO != PRO_RMSNORM && MATH != MATH_LINEAR && MATH != MATH_DOT), "K phases: the row kernels, no full-row statistic");
     const int Gp = G / PH;                                        // tiles of one K phase of a row-tile
     const int nt = (Gp - wave + NW - 1) / NW;                     // tiles of one (row-tile, phase) owned by this wave: g = phase * Gp + wave + i*NW
-    const int rt0 = local * a.rpt;                                // this workgroup's row-tiles: rt0 .. rt0 + n_my - 1 (contiguous bytes)
-    const int n_my = (seg_n_rt - rt0) < a.rpt ? (seg_n_rt - rt0) : a.rpt;
+    // this workgroup's row-tiles: rt0 .. rt0 + n_my - 1 (contiguous bytes).  seg_split = gemv_split(): the segment's first `rem` workgroups walk
+    // base + 1 row-tiles, the others base -- no workgroup carries more than one row-tile more than any other
+    const int sp_base = seg_split & 0xFF, sp_rem = seg_split >> 8;
+    const int rt0 = local * sp_base + (local < sp_rem ? local : sp_rem);
+    const int n_my = sp_base + (local < sp_rem ? 1 : 0);
     const int total = n_my * PH * nt;
     const uint32_t* qw = (const uint32_t*)qweight;
     static_assert(GP == 1 || MATH == MATH_EXACT || MATH == MATH_GS, "groups finer than 128: exact math only");

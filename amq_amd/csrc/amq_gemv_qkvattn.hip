@@ -252,8 +252,9 @@ __global__ __launch_bounds__(512, 6) void gemv_qkv_attn_kernel(const void* p_x, 
     // ---- publish this workgroup's row-tiles: drain (the storing threads sit in wave 0), barrier, one lane adds to the tickets
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int rt0 = local * a.rpt;
-    const int n_my = (nrt - rt0) < a.rpt ? (nrt - rt0) : a.rpt;
+    const int sp_base = nrt & 0xFF, sp_rem = nrt >> 8;           // (nrt = gemv_split() of the segment: gemv_body's row-tile range)
+    const int rt0 = local * sp_base + (local < sp_rem ? local : sp_rem);
+    const int n_my = sp_base + (local < sp_rem ? 1 : 0);
     const int group = at.n_heads / at.n_kv_heads;
     if (threadIdx.x == 0) {
         for (int rt = rt0; rt < rt0 + n_my; ++rt) {
@@ -302,7 +303,7 @@ hipError_t launch_gemv_qkv_attn(GemvArgs& a, const AttnArgs& t, int* tickets, hi
     k.M = 1; k.K = a.K; k.x_stride = a.K; k.nseg = 3; k.eps = a.eps; k.rpt = rpt;
     for (int i = 0; i < 3; ++i) {
         const GemvSeg& s = a.seg[i];
-        k.wg_begin[i] = s.wg_begin; k.n_rt[i] = s.n_rt; k.key[i] = s.bits * 4 + (s.mode == MODE_FMA1 ? (int)MODE_FMA : s.mode);
+        k.wg_begin[i] = s.wg_begin; k.n_rt[i] = gemv_split(s.n_rt, s.wg_count); k.key[i] = s.bits * 4 + (s.mode == MODE_FMA1 ? (int)MODE_FMA : s.mode);
         k.qweight[i] = s.qweight; k.meta[i] = s.meta; k.bias[i] = nullptr; k.residual[i] = nullptr; k.y[i] = s.y; k.y_stride[i] = s.N;
     }
     k.wg_begin[3] = 0x7fffffff;

@@ -38,8 +38,10 @@ def main():
     gamma = torch.ones(k, device=dev, dtype=torch.float16)
     y = torch.empty(M, n, device=dev, dtype=torch.float16)
 
+    opts = ops.GemvOpts(waves=int(os.environ["GEMV_WAVES"])) if os.environ.get("GEMV_WAVES") else None      # A/B: e.g. 520 = WAVES_2X8
+
     def launch(q, mt):
-        ops.gemv_grouped(x, [dict(qn=q, mn=mt, bits=bits, mode=ops.MODE_HQQ, N=n, y=y)], k, prologue=pro, x2=x2, gamma=gamma, eps=1e-5)
+        ops.gemv_grouped(x, [dict(qn=q, mn=mt, bits=bits, mode=ops.MODE_HQQ, N=n, y=y)], k, prologue=pro, x2=x2, gamma=gamma, eps=1e-5, opts=opts)
     nstamp = 4
     stamps = torch.zeros(nstamp, 4096, 128, dtype=torch.int64, device=dev)
     for rep in range(3):
