@@ -18,9 +18,10 @@
 //   * staging units are cut by WHEN they are read, not by where they lie: AF = the a0 rows of both wave rows, AS = the a1 rows,
 //     BF = the b0 columns of all four wave columns, BS = the b1 columns (128 rows x 64 k = 16 KiB each).  AF, BF, BS are read in
 //     X only, AS in Y only, so a slot can be refilled from the next phase on and the stream of LDS-DMA runs seven units ahead of
-//     its consumption:  Y(t) issues AF, BF, BS(t + 2), X(t + 1) issues AS(t + 2), each followed by ONE counted wait, vmcnt(8) =
-//     the four youngest units stay in flight: behind X everything up to AS(t) has landed (read in Y), behind Y everything up to
-//     BS(t + 1) (read in the next X); every unit has two phases (>= 2048 matrix-pipe cycles) to land.  A unit is read one phase or
+//     its consumption:  Y(t) issues AF, BF and the first half of BS(t + 2), X(t + 1) the second half of BS(t + 2) and AS(t + 2) (5 / 3
+//     pieces per wave: 6 / 2 made the group behind Y the late arriver of its hand-over), each followed by ONE counted wait that
+//     leaves the youngest eight (X) / seven (Y) pieces in flight: behind X everything up to AS(t) has landed (read in Y), behind Y
+//     everything up to BS(t + 1) (read in the next X); every piece has a phase and a half or more (>= 1500 matrix-pipe cycles) to land.  A unit is read one phase or
 //     more after the wait + barrier that covers it and refilled one phase or more after a barrier that every reading wave reached
 //     with its reads retired (lgkmcnt(0) BEFORE the barrier): both orders hold by construction.
 //   * PERSISTENT: one workgroup per CU walks the tiles b, b + grid, ...; the DMA stream does not stop at a tile's end -- the last
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
     const pp_i4 xrsrc = pp_make_rsrc(a.x), wrsrc = pp_make_rsrc(a.w);
 
     // unit U of K-tile kt of the staged tile (kt >= T: the stream has moved on to the next tile, see the loop) into set `set`
-    auto issue = [&](int kt, int set, int U) {
+    auto issue = [&](int kt, int set, int U, int half = 3) {      // half: bit j = instruction j of the unit (BS is issued in two places)
 #ifdef AMQ_PP_ABL_NODMA            /* timing-only ablation: nothing is staged at all */
         return;
 #endif
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
             pp_blds16(xrsrc, aoff[s][1], (unsigned)kc * 128u, dst + 8192);
         } else {
             const int s = U == U_BS;
-            pp_blds16(wrsrc, boff[s][0], (unsigned)kc * 128u, dst);
-            pp_blds16(wrsrc, boff[s][1], (unsigned)kc * 128u, dst + 8192);
+            if (half & 1) { pp_blds16(wrsrc, boff[s][0], (unsigned)kc * 128u, dst); }
+            if (half & 2) { pp_blds16(wrsrc, boff[s][1], (unsigned)kc * 128u, dst + 8192); }
         }
     };
 
@@ -254,10 +255,13 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
         __builtin_amdgcn_sched_barrier(0);
         PP_STAMP(0);
         PP_TRACE_FLUSH();
-        if constexpr (P == 0) { read_b(set, U_BF, b0f); read_b(set, U_BS, b1f); read_a(set, U_AF); issue(kt + 1, set ^ 1, U_AS); }
-        if constexpr (P == 1) { read_a(set, U_AS); issue(kt + 2, set, U_AF); issue(kt + 2, set, U_BF); issue(kt + 2, set, U_BS); }
+        // (3 pieces behind X's 16 operand reads, 5 behind Y's 8 -- the second half of BS is issued one phase later: with 2 / 6 the four waves of a group queue
+        //  24 pieces at the texture addresser behind Y and arrive late at the hand-over; 4 / 4 is no better than 2 / 6: profiles/r05_gemm_f16pp.txt)
+        if constexpr (P == 0) { read_b(set, U_BF, b0f); read_b(set, U_BS, b1f); read_a(set, U_AF); issue(kt + 1, set ^ 1, U_BS, 2); issue(kt + 1, set ^ 1, U_AS); }
+        if constexpr (P == 1) { read_a(set, U_AS); issue(kt + 2, set, U_AF); issue(kt + 2, set, U_BF); issue(kt + 2, set, U_BS, 1); }
         PP_STAMP(1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (P == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // X's three and Y's five youngest stay in flight: AS(kt) has landed
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                       // Y's five and AS(kt + 1): AF, BF, BS(kt + 1) have landed
         PP_STAMP(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this phase's operands are in registers; the slots they came from may be refilled
         PP_STAMP(3);
@@ -285,8 +289,8 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
 
     // ---- prologue (once per workgroup): K-tile 0 complete, AF / BF / BS of K-tile 1 -- the seven units of lead the loop keeps
     issue(0, 0, U_AF); issue(0, 0, U_BF); issue(0, 0, U_BS); issue(0, 0, U_AS);
-    issue(1, 1, U_AF); issue(1, 1, U_BF); issue(1, 1, U_BS);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                    // K-tile 0 has landed (this wave's pieces)
+    issue(1, 1, U_AF); issue(1, 1, U_BF); issue(1, 1, U_BS, 1);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                    // K-tile 0 has landed (this wave's pieces)
     PP_BARRIER();                                                       // ... everybody's
     if (wr == 1) PP_BARRIER();                                          // the second wave of every SIMD runs one barrier behind
 
