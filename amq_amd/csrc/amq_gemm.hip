@@ -444,7 +444,9 @@ hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int ny = (M + 63) / 64;
         long wg_old = 0, wg_new = 0;
-        const int nsub_new = fewrow_stream_nsub(blocks / ny, ny, cus);
+        int seg_blocks[GEMV_MAX_SEG];
+        for (int i = 0; i < nseg; ++i) seg_blocks[i] = segs[i].N >> 4;
+        const int nsub_new = fewrow_stream_nsub(seg_blocks, nseg, ny, cus);
         for (int i = 0; i < nseg; ++i) {
             wg_old += ((segs[i].N >> 4) + nsub - 1) / nsub;
             wg_new += ((segs[i].N >> 4) + nsub_new - 1) / nsub_new;

@@ -115,7 +115,7 @@ hipError_t launch_xfrag(const void* src, void* xf, int M, int K, long stride_m, 
 // several linears over the same fragment-ordered x as segments of one few-row launch (uses qweight / meta / bias / residual / y / N / bits / mode / y_stride)
 hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg* segs, int nseg, hipStream_t st, int form = 0, int nsub_forced = 0);   // form: AMQ_FEWROW_*
 hipError_t launch_gemm_fewrow_stream_grouped(const void* xf, int M, int K, const GemvSeg* segs, int nseg, hipStream_t st, int nsub_forced = 0);   // amq_gemm_fewrow.hip
-int fewrow_stream_nsub(long blocks, int row_groups, int cus);      // column blocks per workgroup of that kernel
+int fewrow_stream_nsub(const int* seg_blocks, int nseg, int row_groups, int cus);      // column blocks per workgroup of that kernel
 int gemm_pick_splits(int M, int N, int K, int route = GEMM_ROUTE_AUTO);
 // amq_gemm_f16.hip: y = x . W^T with W as fp16 [N, K] (the dequantized weights, or any dense fp16 matrix): 256 x 256 tiles, two wave
 // groups in ping-pong, no VALU in the K loop; bias / residual / gate epilogues as GemmArgs
