@@ -434,10 +434,10 @@ hipError_t launch_gemm_xfrag_grouped(const void* xf, int M, int K, const GemvSeg
     blocks *= (M + 63) / 64;
     const int nsub = blocks <= 320 ? 1 : blocks <= 640 ? 2 : 4;          // as skinny_launch_xf
 #if AMQ_FEWROW_STREAM
-    // The streaming form (amq_gemm_fewrow.hip: same results bit for bit, up to six column blocks per workgroup) where it saves a ROUND of the chip:
-    // a workgroup of either kernel is bound by taking its rows' whole x in through one CU (~25-30 GB/s per CU of L1 misses: 512 KB = 16-23 us,
-    // profiles/r05_prompt64.txt), so a launch costs about one workgroup time per round.  7B gate/up at 64 rows: 344 workgroups of four blocks = two
-    // rounds (30 us) against 230 of six = one (23 us); q/k/v: 192 of four (16 us) against 256 of three (23 us, every CU pulling x at once) -- kept.
+    // The streaming form (amq_gemm_fewrow.hip: same results bit for bit, up to six column blocks per workgroup) where it saves a ROUND of the chip: a
+    // workgroup of either kernel pays a cold start (3 - 5 us) and a cross-wave sum (2 - 3 us) around an issue-bound loop, so a launch costs about one
+    // workgroup time per round (profiles/r05_prompt64.txt).  7B gate/up at 64 rows: 344 workgroups of four blocks = two rounds (30 us) against 230 of
+    // six = one (23 us); q/k/v: 192 of four in either form (17.7 / 18.2 us) -- the older kernel kept.
     {
         StreamDevice sd_(st);
         int dev = 0, cus = 256;

@@ -64,7 +64,8 @@ class QuantLlama:
     # five launches per block
     ENGINE_MAX_SEQ = 512
     # rows up to which down_proj's SiLU*mul stays fused into its GEMV's prologue (beyond: one silu_mul launch + the GEMV without a prologue -- every
-    # workgroup of a fused launch takes in gate AND up, which at 5+ rows costs more than the extra launch: profiles/r05_decode_batch.txt)
+    # workgroup of a fused launch takes in gate AND up and repeats the transform on all rows, which from 2 rows on costs more than the extra launch:
+    # profiles/r05_decode_batch.txt)
     DOWN_FUSED_ROWS = 1
     # rows up to which the two RMSNorms stay fused into the q/k/v and gate/up launches (beyond: one rmsnorm launch + the grouped GEMV without a prologue)
     NORM_FUSED_ROWS = 4
