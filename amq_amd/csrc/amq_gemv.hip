@@ -25,8 +25,8 @@ size_t gemv_lds_bytes_rows(int M, int K, int nw) {
     return xbytes + (size_t)2 * nw * (M <= 4 ? 64 : 128) * 4;
 }
 // 5 .. 8 rows whose x does not fit LDS whole (the 7B down_proj at 7 - 8 rows: 8 x 11008 halves = 172 KB): x in two K phases, one 16-wave workgroup
-// per row-tile.  Needs no full-row statistic in the prologue (norm = false), an even tile count, >= 2 tiles per wave and phase (the restage's counted
-// wait assumes a full weight ring), one chunk per thread and phase.
+// per row-tile.  Needs no full-row statistic in the prologue (norm = false), an even tile count, >= 2 tiles per wave and phase, one chunk per thread
+// and phase.
 bool gemv_rows_phased(int M, int K, bool plain, bool norm) {
     const int G = K >> 7;
     return plain && !norm && M > 4 && M <= 8 && (G & 1) == 0 && G / 2 >= 2 * 16 && (K / 2 >> 3) <= 1024 &&

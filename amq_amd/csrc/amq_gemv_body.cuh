@@ -734,13 +734,11 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
         }                                                                                        \
     } while (0)
 #endif
-    // next K slice of x (PH > 1).  Runs where the weight ring is full (a virtual row-tile of >= U tiles follows: launch_gemv checks), so the counted
-    // wait inside x_finish_dma -- everything older than the ring's U tiles -- covers exactly this wave's transfers.
-#ifdef AMQ_ABL_NOLOAD
+    // next K slice of x (PH > 1).  The slice's transfers are the YOUNGEST vector-memory operations of the wave here (the ring's loads were issued before
+    // them), and vmcnt retires in issue order: only vmcnt(0) says they have landed.  (A counted wait that left the ring's 2 U operations "in flight"
+    // -- the form of the initial staging, where the ring is primed AFTER the transfers -- let the last rows' transfers be the ones left in flight: a
+    // rare wrong row-tile at 8 rows of K = 11008, caught by test_gemv_rows_staged_by_dma on one box in many.)
 #define AMQ_RESTAGE_NRING 0
-#else
-#define AMQ_RESTAGE_NRING (U * 2)
-#endif
 #define AMQ_RESTAGE(ph_)                                                                         \
     do {                                                                                         \
         __syncthreads();                                      /* every wave is done reading the slice in LDS */ \
