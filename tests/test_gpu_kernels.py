@@ -652,6 +652,13 @@ def test_gemv_rows_staged_by_dma(bits, m, k, n):
             same(run(xd[i:i + 1], ops.PRO_RMSNORM, gamma=gd, eps=eps), y1[i:i + 1])
     # deterministic
     assert torch.equal(run(xd, ops.PRO_SILU_MUL, x2=upd), y2)
+    # ... also when x comes from HBM (a cache-flushing fill in front of the launch: the LDS-DMA transfers then take microseconds to land, and a wait
+    # that does not cover them -- the K-phased restage once used the initial staging's counted wait -- shows as a wrong row-tile)
+    junk = torch.empty(320 << 20, dtype=torch.uint8, device=dev)
+    for rep in range(4):
+        junk.fill_(rep)
+        assert torch.equal(run(xd, ops.PRO_NONE, res=rd), y0), "rows path: result changes with x cold"
+    del junk
 
 
 def test_error_paths_raise():
