@@ -186,6 +186,11 @@ def test_attn_decode_split_context(pos, max_seq, nh, nkv, batch, n_splits):
         assert (got.float() - one.float()).abs().max() <= 2e-3 * one.float().abs().max() + 1e-3
     again, _, _ = run(n_splits, False)
     assert torch.equal(again, got)                         # chunk-order combine: deterministic
+    junk = torch.empty(320 << 20, dtype=torch.uint8, device=dev)
+    junk.fill_(1)                                          # ... also with the cache rows and the workspace cold in HBM
+    cold, _, _ = run(n_splits, False)
+    assert torch.equal(cold, got)
+    del junk
     cur_out, _, _ = run(n_splits, True)
     assert torch.equal(cur_out, got)                       # step-state position / rotation source: same bits
     assert all(int(t.abs().sum().item()) == 0 for t in ops._ATTN_TICKETS._cur.values())

@@ -661,6 +661,59 @@ def test_gemv_rows_staged_by_dma(bits, m, k, n):
     del junk
 
 
+def test_results_do_not_depend_on_cache_state():
+    """every kernel that waits for its loads with COUNTED waits (register rings, LDS-DMA pieces) against operands that are cold in HBM: a cache-flushing
+    fill in front of each launch makes every transfer take microseconds to land, so a wait that does not cover what the next instruction reads shows
+    as a changed result (how the K-phased GEMV's restage wait was caught).  Results must equal the warm run's bit for bit."""
+    from amq_amd import ops
+    dev = _dev()
+    junk = torch.empty(320 << 20, dtype=torch.uint8, device=dev)
+    gen = torch.Generator().manual_seed(99)
+
+    def cold(fn, what, reps=3):
+        warm = fn()
+        for rep in range(reps):
+            junk.fill_(rep + 1)
+            got = fn()
+            assert torch.equal(got, warm), f"{what}: result changes with cold operands"
+
+    # GEMV: one row (register-held x), rows by LDS-DMA with each prologue, generic staging (9 rows, strided)
+    k, n = 4096, 2048
+    h, qn, mn, w_ref = _random_case(3, n, k, seed=5)
+    gamma = (1.0 + 0.1 * torch.randn(k, generator=gen)).to(torch.float16).to(dev)
+    for m in (1, 3, 8, 9):
+        x = torch.randn(m, k, generator=gen).to(torch.float16).to(dev)
+        up = torch.randn(m, k, generator=gen).to(torch.float16).to(dev)
+
+        def gv(pro, **kw):
+            y = torch.empty(m, n, dtype=torch.float16, device=dev)
+            ops.gemv_grouped(x, [dict(qn=qn, mn=mn, bits=3, mode=ops.MODE_HQQ, N=n, y=y)], k, prologue=pro, **kw)
+            return y
+        cold(lambda: gv(ops.PRO_NONE), f"gemv {m} rows")
+        cold(lambda: gv(ops.PRO_RMSNORM, gamma=gamma, eps=1e-5), f"gemv {m} rows, rmsnorm")
+        cold(lambda: gv(ops.PRO_SILU_MUL, x2=up), f"gemv {m} rows, silu*mul")
+    # GEMM: every hand-written route
+    n2, k2 = 2048, 4096
+    h2, qn2, mn2, _ = _random_case(4, n2, k2, seed=6)
+    for m, routes in ((64, (ops.GEMM_AUTO, ops.GEMM_SKINNY, ops.GEMM_TILED)), (1024, (ops.GEMM_TILED, ops.GEMM_RING, ops.GEMM_RING128, ops.GEMM_WS, ops.GEMM_DEQ))):
+        x = torch.randn(m, k2, generator=gen).to(torch.float16).to(dev)
+        for route in routes:
+            cold(lambda: ops.gemm(x, qn2, mn2, 4, ops.MODE_HQQ, n2, k2, route=route), f"gemm {m} rows route {route}", reps=2)
+    # grouped few-row launch over fragment-ordered x, both forms
+    x = torch.randn(64, k2, generator=gen).to(torch.float16).to(dev)
+    xf = ops.xfrag(x, 64, k2)
+    for form, blocks in ((1, 0), (2, 3), (2, 6)):
+        def grouped():
+            y = torch.empty(64, n2, dtype=torch.float16, device=dev)
+            ops.gemm_xfrag_grouped(xf, 64, [dict(qn=qn2, mn=mn2, bits=4, mode=ops.MODE_HQQ, N=n2, y=y)], k2, form=form, blocks_per_wg=blocks)
+            return y
+        cold(grouped, f"few-row grouped form {form}/{blocks}", reps=2)
+    # dense fp16 GEMM (the dequantize-once route's second half)
+    xd = (torch.randn(512, 1024, generator=gen) * 0.5).to(torch.float16).to(dev)
+    wd = (torch.randn(768, 1024, generator=gen) * 0.05).to(torch.float16).to(dev)
+    cold(lambda: ops.gemm_f16w(xd, wd), "gemm_f16w", reps=2)
+
+
 def test_error_paths_raise():
     from amq_amd import ops, _lib
     h, qn, mn, _ = _random_case(4, 64, 256, seed=1)
