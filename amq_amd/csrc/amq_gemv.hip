@@ -102,22 +102,28 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     // not fit the register file at 78 VGPRs, a second round of workgroups would run on an empty chip); a workgroup walks
     // `rpt` row-tiles
     int rpt = ph2 ? 1 : a.force_rpt;                       // (K phases: one row-tile per workgroup -- its accumulators live across the phases)
+    const bool two_per_cu = nw == 8 && (rs128 || (rs64 && 3 * gemv_lds_bytes_rows(a.M, a.K, 8) > 160 * 1024));     // (the 5 .. 8-row kernels hold 105 - 128 VGPRs: two 8-wave workgroups per CU)
+    const int target = (mid_k || two_per_cu) ? 512 : nw == 16 ? 256 : 256 * 24 / nw;
     if (rpt <= 0) {
-        const bool two_per_cu = nw == 8 && (rs128 || (rs64 && 3 * gemv_lds_bytes_rows(a.M, a.K, 8) > 160 * 1024));     // (the 5 .. 8-row kernels hold 105 - 128 VGPRs: two 8-wave workgroups per CU)
-        const int target = (mid_k || two_per_cu) ? 512 : nw == 16 ? 256 : 256 * 24 / nw;
         rpt = (total_rt + target - 1) / target;
         if (rpt < 1) rpt = 1;
     }
     // several workgroups per CU that each hold a large x (the 5 .. 8-row kernels: two per CU): the launch's 512 workgroups are dealt to the segments in
     // proportion to their row-tiles, so that every CU ends up with the same load -- q/k/v of 7B at 8 rows: 3 x 170 workgroups of 2 or 1 row-tiles
     // (3 per CU) instead of 3 x 128 of 2 (4 on half of the CUs, 2 on the others; profiles/r05_decode_batch.txt)
-    const bool deal = a.force_rpt <= 0 && !ph2 && rs128 && nw == 8 && total_rt > 512 && total_rt / 512 < 255;
+    // ... and the one-row launches of 4096 < K <= 8192 (two 8-wave workgroups per CU as well): 70B q/k/v = 640 row-tiles ran as 320 workgroups of 2 (4 on a
+    // quarter of the CUs), dealt 512 of 2 or 1: 13.4 -> 11.0 us per launch, 70B 135.0 -> 136.8 tokens/s.  Every launch dealt this way (A/B: scope 2): 7B -0.4 %.
+#ifndef AMQ_DEAL_SCOPE
+#define AMQ_DEAL_SCOPE 1
+#endif
+    const bool deal = a.force_rpt <= 0 && !ph2 && total_rt > target && total_rt / target < 255 &&
+                      ((rs128 && nw == 8) || (AMQ_DEAL_SCOPE >= 1 && mid_k) || AMQ_DEAL_SCOPE >= 2);
     int wg = 0, mask = 0;
     for (int i = 0; i < a.nseg; ++i) {
         a.seg[i].wg_begin = wg;
         a.seg[i].wg_count = (a.seg[i].n_rt + rpt - 1) / rpt;
         if (deal) {
-            const int share = (int)((long long)512 * a.seg[i].n_rt / total_rt);
+            const int share = (int)((long long)target * a.seg[i].n_rt / total_rt);
             a.seg[i].wg_count = share < 1 ? 1 : share > a.seg[i].n_rt ? a.seg[i].n_rt : share;
         }
         wg += a.seg[i].wg_count;
