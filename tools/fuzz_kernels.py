@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Random-shape sweep of the C-ABI matmul entry points against the CPU oracle (GPU box; test infrastructure, not product): random (rows, N, K, bits,
+prologue, bias / residual, strided x, segments) for the GEMV family, random (rows, N, K, bits, route) for the GEMM family, the tests' parity bar.
+usage: fuzz_kernels.py [cases=150] [seed=0]   -- prints every failing case and exits non-zero if there was one."""
+import os, sys, random
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from amq_amd import ops, _lib
+from amq_amd.hqq_format import random_hqq
+from oracle import hqq_ref, linear_ref
+
+RTOL = 1e-3
+dev = torch.device("cuda:0")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+fails = 0
+
+
+def close(y, ref, inter):
+    """the tests' bar on the final value; where bias / residual add further fp16 roundings, one fp16 ulp of the largest intermediate on top (a matmul that
+    rounds one ulp differently than the oracle's carries that ulp through the adds, whatever the final value cancels to)"""
+    y, ref = np.asarray(y, np.float32), np.asarray(ref, np.float32)
+    floor = RTOL * float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    bar = RTOL * np.abs(ref) + floor
+    if inter is not None:
+        bar = bar + 2.0 ** -10 * np.asarray(inter, np.float32)
+    err = np.abs(y - ref)
+    return not (err > bar).any(), float((err / bar).max())
+
+
+def layer(bits, n, k, seed):
+    h = random_hqq(n, k, bits, seed=seed)
+    hd = h.to(dev)
+    qn, mn = ops.repack_from_hqq(hd.W_q, hd.scale.reshape(-1), hd.zero.reshape(-1), bits, n, k)
+    return qn, mn, hqq_ref.dequantize(h.W_q.numpy(), h.scale.numpy(), h.zero.numpy(), bits, (n, k))
+
+
+def rms_ref(x, g, eps):
+    xf = x.float()
+    return (g * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(torch.float16))
+
+
+for c in range(cases):
+    gen = torch.Generator().manual_seed(1000 + c)
+    K = 128 * rng.choice([1, 2, 3, 5, 8, 11, 16, 24, 32, 33, 40, 43, 64, 86])
+    what = None
+    try:
+        if rng.random() < 0.6:          # ---- GEMV family
+            m = rng.choice([1, 1, 1, 2, 3, 4, 5, 7, 8, 9, 12, 16])
+            nseg = rng.choice([1, 1, 2, 3])
+            pro = rng.choice([ops.PRO_NONE, ops.PRO_RMSNORM, ops.PRO_SILU_MUL])
+            if m > ops.gemv_max_rows(K, plain=True, norm=pro == ops.PRO_RMSNORM):
+                m = 1
+            segs, refs = [], []
+            strided = rng.random() < 0.2 and m > 1
+            xs = K + 64 if strided else K
+            xfull = torch.randn(m, xs, generator=gen).to(torch.float16)
+            x = xfull[:, :K]
+            up = torch.randn(m, xs, generator=gen).to(torch.float16)[:, :K]
+            gamma = (1.0 + 0.1 * torch.randn(K, generator=gen)).to(torch.float16)
+            xin = x if pro == ops.PRO_NONE else rms_ref(x, gamma, 1e-5) if pro == ops.PRO_RMSNORM else torch.nn.functional.silu(x.float()).to(torch.float16) * up
+            desc = []
+            for s in range(nseg):
+                bits = rng.choice([2, 3, 4])
+                n = 16 * rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 256, 257])
+                qn, mn, w = layer(bits, n, K, 7 * c + s)
+                use_bias, use_res = rng.random() < 0.3, rng.random() < 0.4
+                bias = torch.randn(n, generator=gen).to(torch.float16) * 0.1 if use_bias else None
+                res = torch.randn(m, n, generator=gen).to(torch.float16) if use_res else None
+                y = torch.empty(m, n, dtype=torch.float16, device=dev)
+                segs.append(dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_HQQ, N=n, y=y, bias=None if bias is None else bias.to(dev), residual=None if res is None else res.to(dev)))
+                r = linear_ref.linear_f16(xin.numpy(), w)
+                inter = np.abs(r.astype(np.float32))
+                if bias is not None:
+                    r = (r + bias.numpy()).astype(np.float16)
+                    inter = np.maximum(inter, np.abs(r.astype(np.float32)))
+                if res is not None:
+                    r = (res.numpy() + r).astype(np.float16)
+                refs.append((r, inter if (use_bias or use_res) else None))
+                desc.append((bits, n, use_bias, use_res))
+            what = f"gemv m={m} K={K} pro={pro} strided={strided} segs={desc}"
+            xd = xfull.to(dev)[:, :K] if strided else x.contiguous().to(dev)
+            upd = up.contiguous().to(dev) if not strided else torch.randn(1)  # placeholder
+            if strided:
+                upfull = torch.zeros(m, xs, dtype=torch.float16); upfull[:, :K] = up
+                upd = upfull.to(dev)[:, :K]
+            ops.gemv_grouped(xd, segs, K, prologue=pro, x2=upd if pro == ops.PRO_SILU_MUL else None, gamma=gamma.to(dev) if pro == ops.PRO_RMSNORM else None, eps=1e-5)
+            for sg, (r, b) in zip(segs, refs):
+                ok, worst = close(sg["y"].cpu().numpy(), r, b)
+                if not ok:
+                    fails += 1
+                    print("FAIL", what, "worst/bar", worst, flush=True)
+        else:                           # ---- GEMM family
+            m = rng.choice([9, 16, 17, 33, 64, 65, 100, 128, 200, 256, 300, 512, 777, 1024, 2048])
+            bits = rng.choice([2, 3, 4])
+            n = 16 * rng.choice([1, 4, 16, 17, 64, 128, 256, 320])
+            route = rng.choice([ops.GEMM_AUTO, ops.GEMM_AUTO, ops.GEMM_TILED, ops.GEMM_SKINNY, ops.GEMM_RING, ops.GEMM_RING128, ops.GEMM_WS, ops.GEMM_DEQ])
+            if route == ops.GEMM_SKINNY and m > 64:
+                route = ops.GEMM_AUTO
+            qn, mn, w = layer(bits, n, K, 13 * c)
+            x = (torch.randn(m, K, generator=gen) * 0.5).to(torch.float16)
+            use_bias, use_res = rng.random() < 0.3, rng.random() < 0.3
+            bias = torch.randn(n, generator=gen).to(torch.float16) * 0.1 if use_bias else None
+            res = torch.randn(m, n, generator=gen).to(torch.float16) if use_res else None
+            what = f"gemm m={m} N={n} K={K} bits={bits} route={route} bias={use_bias} res={use_res}"
+            try:
+                y = ops.gemm(x.to(dev), qn, mn, bits, ops.MODE_HQQ, n, K, bias=None if bias is None else bias.to(dev), residual=None if res is None else res.to(dev), route=route)
+            except _lib.AmqError as e:       # a route that refuses the shape says so
+                print("refused:", what, "--", str(e)[:100], flush=True)
+                continue
+            r = linear_ref.linear_f16(x.numpy(), w)
+            inter = np.abs(r.astype(np.float32))
+            if bias is not None:
+                r = (r + bias.numpy()).astype(np.float16)
+                inter = np.maximum(inter, np.abs(r.astype(np.float32)))
+            if res is not None:
+                r = (res.numpy() + r).astype(np.float16)
+            ok, worst = close(y.cpu().numpy(), r, inter if (use_bias or use_res) else None)
+            if not ok:
+                fails += 1
+                print("FAIL", what, "worst/bar", worst, flush=True)
+    except Exception as e:      # noqa: BLE001
+        fails += 1
+        print("ERROR", what, "--", repr(e)[:300], flush=True)
+    if c % 25 == 24:
+        print(f"... {c + 1} cases, {fails} failures", flush=True)
+print(f"{cases} cases, {fails} failures")
+sys.exit(1 if fails else 0)
