@@ -625,6 +625,30 @@ def test_batched_decode_matches_single_sequence_runs(B, gqa):
         mb.prefill(ids[:1])                                # wrong number of prompts
 
 
+@pytest.mark.parametrize("B", [3, 5, 7, 8])
+def test_batched_decode_at_7b_width(B):
+    """the runner's per-row-count routes at Llama-2-7B layer widths (hidden 4096, intermediate 11008; one block): SiLU*mul unfused from 2 rows, RMSNorms
+    from 5, down_proj's x in two K phases at 7 - 8 rows -- every sequence against its own batch-1 run, graph replay == eager"""
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama
+    cfg = dict(arch._cfg(1, 4096, 11008, 32, 32, 1, vocab=1024))
+    ids = torch.randint(0, 1024, (B, 16), generator=torch.Generator().manual_seed(B)).to(_dev())
+    steps = 4
+    mb = QuantLlama(cfg, None, device="cuda:0", max_seq=32, seed=4, batch=B)
+    out_b = mb.generate(ids, steps, use_graph=False).clone()
+    logits_b = mb.logits.float().clone()
+    m1 = QuantLlama(cfg, None, device="cuda:0", max_seq=32, seed=4)
+    for b in range(B):
+        m1.reset()
+        m1.generate(ids[b], steps, use_graph=False)
+        ref = m1.logits.float()
+        assert (logits_b[b] - ref).abs().max() <= 1e-2 * ref.abs().max(), b
+    mb.reset()
+    out_g = mb.generate(ids, steps, use_graph=True)
+    assert torch.equal(out_g, out_b) and torch.equal(mb.logits.float(), logits_b)
+    mb.check()
+
+
 def test_batched_decode_long_cache_and_chunked_prompt():
     """batch 3 over a cache long enough for the split attention kernel (several workgroups per head and sequence), the prompt fed in
     two chunks: every sequence agrees with its own batch-1 run (whole prompt, single-workgroup attention forced)"""
