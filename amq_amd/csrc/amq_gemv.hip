@@ -116,7 +116,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
 #ifndef AMQ_DEAL_SCOPE
 #define AMQ_DEAL_SCOPE 1
 #endif
-    const bool deal = a.force_rpt <= 0 && !ph2 && total_rt > target && total_rt / target < 255 &&
+    const bool deal = a.force_rpt <= 0 && !ph2 && total_rt > target &&
                       ((rs128 && nw == 8) || (AMQ_DEAL_SCOPE >= 1 && mid_k) || AMQ_DEAL_SCOPE >= 2);
     int wg = 0, mask = 0;
     for (int i = 0; i < a.nseg; ++i) {
@@ -126,6 +126,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
             const int share = (int)((long long)target * a.seg[i].n_rt / total_rt);
             a.seg[i].wg_count = share < 1 ? 1 : share > a.seg[i].n_rt ? a.seg[i].n_rt : share;
         }
+        if (a.seg[i].n_rt / a.seg[i].wg_count > GEMV_SPLIT_BASE_MASK || a.seg[i].wg_count >= (1 << 19)) return hipErrorInvalidValue;      // (N beyond 50 M rows)
         wg += a.seg[i].wg_count;
         mask |= 1 << a.seg[i].bits;
     }

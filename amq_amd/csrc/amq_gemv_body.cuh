@@ -524,7 +524,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     const int nt = (Gp - wave + NW - 1) / NW;                     // tiles of one (row-tile, phase) owned by this wave: g = phase * Gp + wave + i*NW
     // this workgroup's row-tiles: rt0 .. rt0 + n_my - 1 (contiguous bytes).  seg_split = gemv_split(): the segment's first `rem` workgroups walk
     // base + 1 row-tiles, the others base -- no workgroup carries more than one row-tile more than any other
-    const int sp_base = seg_split & 0xFF, sp_rem = seg_split >> 8;
+    const int sp_base = seg_split & GEMV_SPLIT_BASE_MASK, sp_rem = seg_split >> GEMV_SPLIT_BASE_BITS;
     const int rt0 = local * sp_base + (local < sp_rem ? local : sp_rem);
     const int n_my = sp_base + (local < sp_rem ? 1 : 0);
     const int total = n_my * PH * nt;

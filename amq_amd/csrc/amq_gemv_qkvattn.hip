@@ -252,7 +252,7 @@ __global__ __launch_bounds__(512, 6) void gemv_qkv_attn_kernel(const void* p_x, 
     // ---- publish this workgroup's row-tiles: drain (the storing threads sit in wave 0), barrier, one lane adds to the tickets
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int sp_base = nrt & 0xFF, sp_rem = nrt >> 8;           // (nrt = gemv_split() of the segment: gemv_body's row-tile range)
+    const int sp_base = nrt & GEMV_SPLIT_BASE_MASK, sp_rem = nrt >> GEMV_SPLIT_BASE_BITS;           // (nrt = gemv_split() of the segment: gemv_body's row-tile range)
     const int rt0 = local * sp_base + (local < sp_rem ? local : sp_rem);
     const int n_my = sp_base + (local < sp_rem ? 1 : 0);
     const int group = at.n_heads / at.n_kv_heads;

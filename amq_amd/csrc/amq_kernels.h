@@ -74,8 +74,9 @@ struct GemvArgs {
     int gp;                // (scale, zero) pairs per (row, tile) of every segment's meta: 0 / 1 (groups of 128), 2 (64), 4 (32)
 };
 // how a segment's row-tiles are dealt to its workgroups: the first n_rt % wg_count workgroups walk one row-tile more than the others
-// (packed base | rem << 8; base <= 255)
-inline int gemv_split(int n_rt, int wg_count) { return (n_rt / wg_count) | ((n_rt % wg_count) << 8); }
+// (packed base | rem << 12: base <= 4095 row-tiles per workgroup, rem < 2^19 workgroups -- launch_gemv refuses what does not fit)
+constexpr int GEMV_SPLIT_BASE_BITS = 12, GEMV_SPLIT_BASE_MASK = (1 << GEMV_SPLIT_BASE_BITS) - 1;
+inline int gemv_split(int n_rt, int wg_count) { return (n_rt / wg_count) | ((n_rt % wg_count) << GEMV_SPLIT_BASE_BITS); }
 enum { GEMV_FLAG_DOT = 1, GEMV_FLAG_LINEAR = 2, GEMV_FLAG_RS128 = 4 /* internal: half-size cross-wave sum buffer (<= 8 rows) */,
        GEMV_FLAG_GS = 8 /* group-scale arithmetic for the two-rounding (HQQ) segments */,
        GEMV_FLAG_RS64 = 16 /* internal: the 2 .. 4-row kernels */,
