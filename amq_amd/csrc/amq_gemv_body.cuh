@@ -90,6 +90,13 @@ struct GemvHot {
 #define AMQ_STAMP_AT(a_, slot_) do { } while (0)
 #endif
 enum { MATH_EXACT = 0, MATH_DOT = 1, MATH_LINEAR = 2, MATH_GS = 3 };
+// A/B build knob (-DAMQ_SD_E9=1): the exact two-rounding unpack over the group-scale body's field positions (E = -9: one shift per dword instead of one per
+// pair or three per dword).  Measured: 7B 851 -> 866 tokens/s (+1.7 %), 70B 143.1 -> 146.9 (+2.6 %).  Not taken: the first rounding is then exact only for
+// |q - z|, |z| >= 2^-5 (now 2^-9 .. 2^-11) -- ~0.6 % of weights (those within 3 % of a step of their zero) would differ from the oracle's by up to 2^-15 of a
+// step, and the GEMV would stop being bit-identical to the GEMM families and to dequantize + fp16 GEMM on the same inputs (HISTORY.md R5).
+#ifndef AMQ_SD_E9
+#define AMQ_SD_E9 0
+#endif
 
 // whole-wave sum without LDS-crossbar shuffles (six dependent ds_bpermute round trips cost ~0.3 us on the prologue's
 // critical path): DPP inside the four 16-lane rows, then four v_readlane; every lane gets the total (fixed order)
@@ -681,6 +688,11 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
         if (MATH == MATH_LINEAR) unpack_lane_sub<BITS>(pay[slot].w, wv);                         \
         else if constexpr (GS) dequant_lane_gs<BITS>(pay[slot].w, gs_zero(meta[slot]), wv);      /* first rounding only; the scale follows the MFMAs */ \
         else if constexpr (GP == 1 && MODE == MODE_FMA1) dequant_lane_fma1<BITS>(pay[slot].w, meta[slot], wv);   /* reference-format weights, one op per pair */ \
+        else if constexpr (GP == 1 && MODE == MODE_HQQ && AMQ_SD_E9) {                           /* A/B: the fields where the packing left them (E = -9), then the multiply */ \
+            dequant_lane_gs<BITS>(pay[slot].w, gs_zero(meta[slot]), wv);                         \
+            const h2 sc9_ = bcast(meta[slot].x) * bcast((_Float16)512.0f);                       \
+            _Pragma("unroll") for (int p_ = 0; p_ < 16; ++p_) wv[p_] = wv[p_] * sc9_;            \
+        }                                                                                        \
         else if constexpr (GP == 1) dequant_lane_sd<BITS, MODE>(pay[slot].w, meta[slot], wv);    \
         else dequant_lane_sd_g<BITS, MODE, GP>(pay[slot].w, metag[slot], wv);                    \
         if (MATH == MATH_DOT) {                                                                  \
