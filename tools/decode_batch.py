@@ -6,8 +6,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from amq_amd import arch, ops
 from amq_amd.llama import QuantLlama
-if os.environ.get("GEMV_WAVES") or os.environ.get("GEMV_DEPTH"):
-    ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(waves=int(os.environ.get("GEMV_WAVES", "0")), depth=int(os.environ.get("GEMV_DEPTH", "0")))   # A/B: waves per workgroup, ring depth
+if os.environ.get("GEMV_WAVES") or os.environ.get("GEMV_DEPTH") or os.environ.get("GEMV_DOT"):
+    ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(waves=int(os.environ.get("GEMV_WAVES", "0")), depth=int(os.environ.get("GEMV_DEPTH", "0")),
+                                         dot=int(os.environ.get("GEMV_DOT", "0")))   # A/B: waves per workgroup, ring depth, v_dot2 body at one row
 
 batches = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,4,8".split(","))]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 128
