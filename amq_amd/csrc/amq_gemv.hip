@@ -65,6 +65,9 @@ AMQ_GEMV_EXTERN(PRO_SILU_MUL)
 #undef AMQ_GEMV_EXTERN
 
 // Fills the per-segment workgroup ranges and launches.  rpt = row-tiles per workgroup.
+#ifndef AMQ_RS128_THREE
+#define AMQ_RS128_THREE 1
+#endif
 hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     StreamDevice sd_(st);                                  // kernel attributes are per device: the stream's, not the current one
     int total_rt = 0;
@@ -102,7 +105,8 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     // not fit the register file at 78 VGPRs, a second round of workgroups would run on an empty chip); a workgroup walks
     // `rpt` row-tiles
     int rpt = ph2 ? 1 : a.force_rpt;                       // (K phases: one row-tile per workgroup -- its accumulators live across the phases)
-    const bool two_per_cu = nw == 8 && (rs128 || (rs64 && 3 * gemv_lds_bytes_rows(a.M, a.K, 8) > 160 * 1024));     // (the 5 .. 8-row kernels hold 105 - 128 VGPRs: two 8-wave workgroups per CU)
+    // (the 5 .. 8-row kernels with a fused RMSNorm hold 105 - 128 VGPRs: two 8-wave workgroups per CU; without it 77 - 80, and three where their LDS fits -- 5 rows of K = 4096)
+    const bool two_per_cu = nw == 8 && ((rs128 && (a.prologue == PRO_RMSNORM || !AMQ_RS128_THREE)) || ((rs64 || rs128) && 3 * gemv_lds_bytes_rows(a.M, a.K, 8) > 160 * 1024));
     const int target = (mid_k || two_per_cu) ? 512 : nw == 16 ? 256 : 256 * 24 / nw;
     if (rpt <= 0) {
         rpt = (total_rt + target - 1) / target;
