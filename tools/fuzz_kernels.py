@@ -87,9 +87,22 @@ for c in range(cases):
             if strided:
                 upfull = torch.zeros(m, xs, dtype=torch.float16); upfull[:, :K] = up
                 upd = upfull.to(dev)[:, :K]
-            ops.gemv_grouped(xd, segs, K, prologue=pro, x2=upd if pro == ops.PRO_SILU_MUL else None, gamma=gamma.to(dev) if pro == ops.PRO_RMSNORM else None, eps=1e-5)
+            math = rng.choice([ops.MATH_DEFAULT, ops.MATH_DEFAULT, ops.MATH_GROUPSCALE, ops.MATH_LINEAR])
+            if math == ops.MATH_LINEAR and m > ops.gemv_max_rows(K):
+                math = ops.MATH_DEFAULT
+            what += f" math={math}"
+            ops.gemv_grouped(xd, segs, K, prologue=pro, x2=upd if pro == ops.PRO_SILU_MUL else None, gamma=gamma.to(dev) if pro == ops.PRO_RMSNORM else None, eps=1e-5,
+                             opts=ops.GemvOpts(math=math) if math else None)
             for sg, (r, b) in zip(segs, refs):
-                ok, worst = close(sg["y"].cpu().numpy(), r, b)
+                if math == ops.MATH_DEFAULT:
+                    ok, worst = close(sg["y"].cpu().numpy(), r, b)
+                else:       # the opt-in arithmetics: their own (tested) bound -- 2 fp16 ulps + 1e-3 rms per element, one ulp of the intermediates on top
+                    y_, r_ = sg["y"].float().cpu().numpy(), np.asarray(r, np.float32)
+                    rms_ = float(np.sqrt(np.mean(r_.astype(np.float64) ** 2)))
+                    # (AMQ_MATH_LINEAR's tested bound is one ulp + 2e-3 rms: no per-weight rounding at all)
+                    bar_ = (2.0 ** -9 * np.abs(r_) + 1.25e-3 * rms_ if math == ops.MATH_GROUPSCALE else 2.0 ** -10 * np.abs(r_) + 2e-3 * rms_) + (0 if b is None else 2.0 ** -10 * b)
+                    e_ = np.abs(y_ - r_)
+                    ok, worst = not (e_ > bar_).any(), float((e_ / bar_).max())
                 if not ok:
                     fails += 1
                     print("FAIL", what, "worst/bar", worst, flush=True)
