@@ -21,7 +21,7 @@ PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
 MATH_DEFAULT, MATH_LINEAR, MATH_GROUPSCALE, MATH_EXACT = 0, 1, 2, 3
 FEWROW_AUTO, FEWROW_TILE, FEWROW_STREAM = 0, 1, 2      # kernel form of the grouped few-row launch (amq_gemm_xfrag_grouped_form_f16)
-ABI_VERSION = 500            # include/amq_hip.h AMQ_VERSION these bindings mirror (checked at load)
+ABI_VERSION = 510            # include/amq_hip.h AMQ_VERSION these bindings mirror (checked at load)
 GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, GEMM_WS, GEMM_DEQ = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -62,6 +62,10 @@ SIGNATURES = {
     "amq_repack_from_awq": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "amq_dequantize_f16": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "amq_dequantize_hqq_f16": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "amq_dequantize_bf16": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "amq_gemv_bf16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "amq_gemm_bf16_workspace_bytes": (_sz, [_i, _i, _i]),
+    "amq_gemm_bf16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "amq_gemv_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_gemm_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_linear_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

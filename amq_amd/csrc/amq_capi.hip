@@ -538,6 +538,47 @@ int amq_linear_f16(int bits, int mode, const void* x, const void* qn, const void
     return amq_gemm_f16(bits, mode, x, qn, mn, bias, y, M, N, K, group, 0, 0, stream);
 }
 
+// ---- bfloat16 variants (amq_bf16.hip) -------------------------------------------------------------------
+int amq_dequantize_bf16(int bits, const void* qn, const void* mn, int N, int K, int group, void* W, void* stream) {
+    if (int rc = check_shape128(bits, N, K, group, "amq_dequantize_bf16")) return rc;
+    if (!qn || !mn || !W) return fail(AMQ_EINVAL, "null pointer");
+    return check_hip(amq::launch_dequantize_bf16(bits, qn, mn, N, K, W, (hipStream_t)stream), "dequantize_bf16");
+}
+
+int amq_gemv_bf16(int bits, const void* x, const void* qn, const void* mn, const void* bias, const void* residual, void* y,
+                  int M, int N, int K, int group, int x_stride, int y_stride, void* stream) {
+    if (int rc = check_shape128(bits, N, K, group, "amq_gemv_bf16")) return rc;
+    if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1 || M > 16) return fail(AMQ_ESHAPE, "amq_gemv_bf16 takes 1 .. 16 rows (got %d); use amq_gemm_bf16", M);
+    if (x_stride == 0) x_stride = K;
+    if (y_stride == 0) y_stride = N;
+    if (x_stride < K || y_stride < N) return fail(AMQ_ESHAPE, "row strides shorter than the rows (x_stride=%d K=%d y_stride=%d N=%d)", x_stride, K, y_stride, N);
+    if (x_stride & 7) return fail(AMQ_ESHAPE, "amq_gemv_bf16 reads x in 16-byte pieces: x_stride must be a multiple of 8 elements (got %d)", x_stride);
+    return check_hip(amq::launch_gemv_bf16(bits, x, qn, mn, bias, residual, y, M, N, K, x_stride, y_stride, (hipStream_t)stream), "gemv_bf16");
+}
+
+size_t amq_gemm_bf16_workspace_bytes(int M, int N, int K) {
+    if (M <= 16 || N <= 0 || K <= 0) return 0;
+    return (size_t)N * (size_t)K * 2;
+}
+
+int amq_gemm_bf16(int bits, const void* x, const void* qn, const void* mn, const void* bias, const void* residual, void* y,
+                  int M, int N, int K, int group, int x_stride, int y_stride, void* workspace, size_t workspace_bytes, void* stream) {
+    if (M >= 1 && M <= 16) return amq_gemv_bf16(bits, x, qn, mn, bias, residual, y, M, N, K, group, x_stride, y_stride, stream);
+    if (int rc = check_shape128(bits, N, K, group, "amq_gemm_bf16")) return rc;
+    if (!x || !qn || !mn || !y) return fail(AMQ_EINVAL, "null pointer");
+    if (M < 1) return fail(AMQ_ESHAPE, "M must be >= 1 (got %d)", M);
+    if (x_stride == 0) x_stride = K;
+    if (y_stride == 0) y_stride = N;
+    if (x_stride < K || y_stride < N) return fail(AMQ_ESHAPE, "row strides shorter than the rows (x_stride=%d K=%d y_stride=%d N=%d)", x_stride, K, y_stride, N);
+    const size_t need = amq_gemm_bf16_workspace_bytes(M, N, K);
+    if (!workspace || workspace_bytes < need) return fail(AMQ_EINVAL, "amq_gemm_bf16 workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    if (!amq::gemm_f16w_ok(M, N, K, x_stride, y_stride))
+        return fail(AMQ_ESHAPE, "amq_gemm_bf16 beyond 16 rows needs x_stride %% 8 == 0, y_stride %% 4 == 0 and x, W spans below 4 GiB (M=%d N=%d K=%d)", M, N, K);
+    if (int rc = check_hip(amq::launch_dequantize_bf16(bits, qn, mn, N, K, workspace, (hipStream_t)stream), "dequantize_bf16")) return rc;
+    return check_hip(amq::launch_gemm_bf16w(x, workspace, bias, residual, y, M, N, K, x_stride, y_stride, (hipStream_t)stream), "gemm_bf16");
+}
+
 // ---- reference-FFI-shaped entry points ---------------------------------------------------------------
 namespace {
 struct CompatWs { void* qn; void* mn; void* ytmp; };

@@ -96,12 +96,23 @@ __device__ unsigned amq_pp_stamp_buf[256 * 8 * 16];
 __device__ unsigned long long amq_pp_trace_buf[16 * 8 * 128 * 4];
 #endif
 
+typedef __bf16 pp_b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pp_b4 __attribute__((ext_vector_type(4)));
+template <bool BF>
+__device__ __forceinline__ f4 pp_mfma(const h8& w, const h8& x, const f4& c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pp_b8, w), __builtin_bit_cast(pp_b8, x), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0);
+}
+
 struct GemmF16Args {
     const void* x; const void* w; const void* bias; const void* residual; const void* gate; void* y;
     int M, N, K, x_stride, y_stride;
 };
 
-__global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, int ntm, int ntn) {
+// BF = false: fp16 operands and output (the product path).  BF = true: the same stream of bytes multiplied as bfloat16 (v_mfma_f32_16x16x32_bf16 has the
+// fp16 instruction's operand map), output / bias / residual bfloat16 -- the batched end of the optional bf16 entry points (amq_bf16.hip).
+template <bool BF>
+__device__ __forceinline__ void gemm_pp_body(const GemmF16Args& a, int ntm, int ntn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    acc[4 * ah + b][2 * bh + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[c][ks], af[b][ks], acc[4 * ah + b][2 * bh + c], 0, 0, 0);
+                    acc[4 * ah + b][2 * bh + c] = pp_mfma<BF>(bf[c][ks], af[b][ks], acc[4 * ah + b][2 * bh + c]);
     };
 
 #ifdef AMQ_PP_TRACE                /* diagnostic build: MFMA-burst begin / end stamps of the first 128 phases, per wave (tools/f16pp_trace.py) */
@@ -321,6 +332,34 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
 
         // ---- epilogue of this tile (the next tile's first K-tiles are landing meanwhile):
         // acc[b][c][i] = y[m0 + 128 wr + 16 b + r][n0 + 64 wc + 16 c + 4 o + i]
+        if constexpr (BF) {
+            // bfloat16: y = bf16(acc), + bias and + residual as separate bf16 adds (each the fp32 sum of two bf16 values, rounded to nearest even)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int n = n0 + 64 * wc + 16 * c + 4 * o;
+                if (n >= a.N) continue;
+                pp_b4 bv = {0, 0, 0, 0};
+                if (bias) bv = *(const pp_b4*)((const __bf16*)a.bias + n);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int m = m0 + 128 * wr + 16 * b + r;
+                    if (m >= a.M) continue;
+                    pp_b4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (__bf16)acc[b][c][i];
+                    if (bias) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = (__bf16)((float)v[i] + (float)bv[i]);
+                    }
+                    if (res) {
+                        const pp_b4 rv = *(const pp_b4*)((const __bf16*)a.residual + (size_t)m * a.y_stride + n);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = (__bf16)((float)rv[i] + (float)v[i]);
+                    }
+                    *(pp_b4*)((__bf16*)a.y + (size_t)m * a.y_stride + n) = v;
+                }
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int n = n0 + 64 * wc + 16 * c + 4 * o;
@@ -354,6 +393,7 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
                 if (m < a.M) *(h4*)(y + (size_t)m * a.y_stride + n) = v;
             }
         }
+        }
         if (nb == tb) break;
         tb = nb; m0 = nm0; n0 = nn0;
         // the epilogue's loads and stores sit on the same counter as the DMA pieces (and stores may return out of order with loads):
@@ -376,6 +416,9 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, 
     if (wr == 0) PP_BARRIER();                                          // barrier counts of the two wave groups match again
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the trailing re-reads must not land after the workgroup has gone
 }
+
+__global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, int ntm, int ntn) { gemm_pp_body<false>(a, ntm, ntn); }
+__global__ __launch_bounds__(PP_THREADS) void gemm_bf16_pp_kernel(GemmF16Args a, int ntm, int ntn) { gemm_pp_body<true>(a, ntm, ntn); }
 
 
 bool gemm_f16w_ok(int M, int N, int K, int x_stride, int y_stride) {
@@ -400,6 +443,20 @@ static int pp_grid_limit() {
         c = v;
     }
     return c;
+}
+
+// the bfloat16 instantiation: x, w, bias, residual, y are bfloat16 (no gate epilogue)
+hipError_t launch_gemm_bf16w(const void* x, const void* w, const void* bias, const void* residual, void* y,
+                             int M, int N, int K, int x_stride, int y_stride, hipStream_t st) {
+    StreamDevice sd_(st);
+    static unsigned long long attr_done = 0;
+    const hipError_t attr = ensure_dyn_lds(attr_done, (const void*)gemm_bf16_pp_kernel, PP_LDS_ALLOC);
+    if (attr != hipSuccess) return attr;
+    GemmF16Args a{x, w, bias, residual, nullptr, y, M, N, K, x_stride, y_stride};
+    const int ntm = (M + PP_BM - 1) / PP_BM, ntn = (N + PP_BN - 1) / PP_BN;
+    const int nt = ntm * ntn, lim = pp_grid_limit();
+    hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(nt < lim ? nt : lim), dim3(PP_THREADS), PP_LDS_ALLOC, st, a, ntm, ntn);
+    return hipGetLastError();
 }
 
 hipError_t launch_gemm_f16w(const void* x, const void* w, const void* bias, const void* residual, const void* gate, void* y,

@@ -214,6 +214,12 @@ hipError_t launch_accumulate_f32(void* mul, const void* y, size_t n, hipStream_t
 hipError_t launch_dequantize(int bits, int mode, const void* q_native, const void* meta_native,
                              int N, int K, void* w_out, hipStream_t st, int gp = 1);    // gp: meta pairs per (row, tile), 1 / 2 / 4
 // HQQ Format A -> fp16 W[N,K] directly (ATEN-style standalone dequant, f-4)
+// the optional bfloat16 entry points (amq_bf16.hip; the batched end: amq_gemm_f16.hip's kernel instantiated for bf16 operands)
+hipError_t launch_dequantize_bf16(int bits, const void* q_native, const void* meta_native_bf16, int N, int K, void* w_bf16, hipStream_t st);
+hipError_t launch_gemv_bf16(int bits, const void* x, const void* q_native, const void* meta_native_bf16, const void* bias, const void* residual,
+                            void* y, int M, int N, int K, int x_stride, int y_stride, hipStream_t st);
+hipError_t launch_gemm_bf16w(const void* x, const void* w, const void* bias, const void* residual, void* y,
+                             int M, int N, int K, int x_stride, int y_stride, hipStream_t st);
 hipError_t launch_dequantize_hqq(int bits, const void* wq, const void* scale, const void* zero,
                                  int N, int K, void* w_out, hipStream_t st, int group = 128);
 

@@ -113,5 +113,8 @@ def from_hqq_layer(layer) -> HQQWeights:
     if nbits not in (2, 3, 4):
         raise NotImplementedError("Only 2,3,4 bits are supported.")
     W_q = layer.W_q.data if hasattr(layer.W_q, "data") else layer.W_q
-    return HQQWeights(W_q, meta["scale"].to(torch.float16).reshape(-1, 1), meta["zero"].to(torch.float16).reshape(-1, 1),
+    # compute_dtype = bfloat16 layers keep scale / zero in bf16 and dequantize in bf16 (quantize.py:184-199, 516): kept as they are (the bf16 entry
+    # points reproduce that arithmetic); any other dtype goes to fp16, what the reference's kernels run in (ft.py:62)
+    md = torch.bfloat16 if meta["scale"].dtype == torch.bfloat16 and meta["zero"].dtype == torch.bfloat16 else torch.float16
+    return HQQWeights(W_q, meta["scale"].to(md).reshape(-1, 1), meta["zero"].to(md).reshape(-1, 1),
                       nbits, tuple(meta["shape"]), int(meta["group_size"]), getattr(layer, "bias", None), getattr(layer, "name", None))

@@ -226,6 +226,9 @@ class QuantLlama:
                 m = getattr(getattr(layer, parent), attr)
                 if not isinstance(m, HIPQuantLinear) or m.bias is not None or not m.qweight.is_cuda:
                     raise ValueError(f"model.layers.{b}.{name}: expected a bias-free HIPQuantLinear on the GPU (run prepare_for_inference first)")
+                if m.is_bf16:
+                    raise ValueError(f"model.layers.{b}.{name}: a bfloat16 module -- the decode runner is fp16 (the reference's kernels are, ft.py:62); "
+                                     "bf16 models run through the modules' own forward")
                 dev = dev or m.qweight.device
                 pre[(b, name)] = _Lin(m.qweight, m.meta, m.bits, m.mode, m.outfeatures, m.infeatures)
                 arch_linear[name].append(m.bits)

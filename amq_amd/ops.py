@@ -40,10 +40,10 @@ def native_sizes(bits, N, K, group=GROUP):
     return int(lib.amq_native_qweight_bytes(bits, N, K)), int(lib.amq_native_meta_bytes(N, K, native_group(group)))
 
 
-def alloc_native(bits, N, K, device, group=GROUP):
+def alloc_native(bits, N, K, device, group=GROUP, meta_dtype=torch.float16):
     qb, mb = native_sizes(bits, N, K, group)
     return (torch.empty(qb // 4, dtype=torch.int32, device=device),
-            torch.empty(mb // 2, dtype=torch.float16, device=device))
+            torch.empty(mb // 2, dtype=meta_dtype, device=device))
 
 
 def _check_shape(bits, N, K):
@@ -74,9 +74,14 @@ def repack_from_hqq(W_q, scale, zero, bits, N, K, group=GROUP):
         _need(W_q, torch.int32, "W_q", ((R + 9) // 10) * group)
     else:
         _need(W_q, torch.uint8, "W_q", R * group * bits // 8)
-    _need(scale, torch.float16, "scale", R)
-    _need(zero, torch.float16, "zero", R)
-    qn, mn = alloc_native(bits, N, K, W_q.device, group)
+    # compute_dtype = bfloat16 models (quantize.py:516): the repack copies 16-bit patterns, the native meta is then a bfloat16 tensor and only the
+    # *_bf16 entry points take it (the tensor's dtype is the tag the C ABI does not carry)
+    meta_dtype = torch.bfloat16 if isinstance(scale, torch.Tensor) and scale.dtype == torch.bfloat16 else torch.float16
+    if meta_dtype == torch.bfloat16 and group in FINE_GROUPS:
+        raise ValueError("bfloat16 meta: groups of 128 (and multiples) only")
+    _need(scale, meta_dtype, "scale", R)
+    _need(zero, meta_dtype, "zero", R)
+    qn, mn = alloc_native(bits, N, K, W_q.device, group, meta_dtype)
     _lib.check(lib.amq_repack_from_hqq(bits, _lib.ptr(W_q), _lib.ptr(scale), _lib.ptr(zero), N, K, group,
                                        _lib.ptr(qn), _lib.ptr(mn), _lib.current_stream()))
     return qn, mn
@@ -427,6 +432,57 @@ def linear(x, qn, mn, bits, mode, N, K, bias=None):
         return y.reshape(*x.shape[:-1], N)
     _lib.check(_lib.load().amq_linear_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias),
                                           _lib.ptr(y), M, N, K, GROUP, _lib.current_stream()))
+    return y.reshape(*x.shape[:-1], N)
+
+
+# ---- bfloat16 variants (include/amq_hip.h "bfloat16 variants"; csrc/amq_bf16.hip): models quantized with compute_dtype = torch.bfloat16
+_DEQ_SCRATCH_BF16 = _ScratchPool(torch.bfloat16)
+
+
+def _check_native_bf16(qn, mn, bits, N, K):
+    qb, mb = native_sizes(bits, N, K)
+    _need(qn, torch.int32, "qweight_native", qb // 4)
+    if isinstance(mn, torch.Tensor) and mn.dtype == torch.float16:
+        raise ValueError("meta_native is float16: this buffer was repacked from an fp16 model -- use the fp16 entry points")
+    _need(mn, torch.bfloat16, "meta_native", mb // 2)
+
+
+def dequantize_bf16(qn, mn, bits, N, K, out=None):
+    """native (bf16 meta) -> W[N, K] bfloat16, bit-identical to Quantizer.dequantize under compute_dtype = bfloat16"""
+    _check_shape(bits, N, K)
+    _check_native_bf16(qn, mn, bits, N, K)
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.bfloat16, device=qn.device)
+    _need(out, torch.bfloat16, "out", N * K)
+    _lib.check(_lib.load().amq_dequantize_bf16(bits, _lib.ptr(qn), _lib.ptr(mn), N, K, GROUP, _lib.ptr(out), _lib.current_stream()))
+    return out
+
+
+def linear_bf16(x, qn, mn, bits, N, K, bias=None, residual=None, out=None):
+    """y = x . W^T (+ bias) (+ residual) in bfloat16: up to 16 rows the weight-streaming kernel, beyond dequantize once + the bf16 MFMA GEMM"""
+    _check_shape(bits, N, K)
+    _check_native_bf16(qn, mn, bits, N, K)
+    if x.dtype != torch.bfloat16:
+        raise ValueError(f"x: expected bfloat16, got {x.dtype}")
+    if x.shape[-1] != K:
+        raise ValueError(f"x: last dim {x.shape[-1]} != K={K}")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if bias is not None:
+        _need(bias, torch.bfloat16, "bias", N)
+    if residual is not None:
+        _need(residual, torch.bfloat16, "residual", M * N)
+    y = out if out is not None else torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _need(y, torch.bfloat16, "y", M * N)
+    if M == 0:
+        return y.reshape(*x.shape[:-1], N)
+    lib = _lib.load()
+    need = int(lib.amq_gemm_bf16_workspace_bytes(M, N, K))
+    ws = _DEQ_SCRATCH_BF16.get(x.device, need // 2) if need else None
+    _lib.check(lib.amq_gemm_bf16(bits, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(y),
+                                 M, N, K, GROUP, 0, 0, _lib.ptr(ws), need, _lib.current_stream()))
     return y.reshape(*x.shape[:-1], N)
 
 
@@ -880,7 +936,7 @@ def _on_tensor_device(fn):
     return wrapped
 
 
-for _name in ("repack_from_hqq", "repack_from_gptq", "repack_from_awq", "dequantize", "dequantize_hqq", "gemv", "gemm", "gemm_f16w", "xfrag",
+for _name in ("repack_from_hqq", "repack_from_gptq", "repack_from_awq", "dequantize", "dequantize_hqq", "dequantize_bf16", "linear_bf16", "gemv", "gemm", "gemm_f16w", "xfrag",
               "rmsnorm_xfrag", "gemm_xfrag", "gemm_xfrag_grouped", "linear", "gemv_grouped", "rmsnorm", "gemv_f16w", "decode_tail", "rope_cache",
               "attn_prefill", "rope_rows", "silu_mul", "gemv_qkv_attn", "attn_decode"):
     globals()[_name] = _on_tensor_device(globals()[_name])

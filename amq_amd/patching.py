@@ -116,7 +116,7 @@ def _walk_hip(model, fct):
 
 def _fusable(m):
     """a HIPQuantLinear the grouped / fused launches take"""
-    return isinstance(m, HIPQuantLinear)
+    return isinstance(m, HIPQuantLinear) and not m.is_bf16        # (bfloat16 modules run unfused: ops.linear_bf16)
 
 
 def _same_group(mods):

@@ -225,7 +225,11 @@ class HIPQuantLinear(nn.Module):
             raise NotImplementedError("group_size must be 32, 64 or a multiple of 128 that divides infeatures.")
         if infeatures % 128 or outfeatures % 16:
             raise ValueError(f"need infeatures % 128 == 0 and outfeatures % 16 == 0 (got {infeatures}, {outfeatures})")
-        assert weight_dtype == torch.float16, "Only fp16 is supported."      # ft.py:62
+        # fp16 is what the reference's kernels take (ft.py:62); bfloat16 is this build's optional variant for models quantized with
+        # compute_dtype = torch.bfloat16: HQQ arithmetic only, groups of 128 (and multiples), no sibling grouping / fusion (ops.linear_bf16)
+        assert weight_dtype in (torch.float16, torch.bfloat16), "Only fp16 (and, for HQQ-format weights, bf16) is supported."
+        if weight_dtype == torch.bfloat16 and (mode != ops.MODE_HQQ or group_size in ops.FINE_GROUPS):
+            raise NotImplementedError("bfloat16 modules: HQQ dequant arithmetic and groups of 128 (or multiples) only")
         self.bits = bits
         self.group_size = group_size
         self.infeatures = infeatures
@@ -235,7 +239,7 @@ class HIPQuantLinear(nn.Module):
         self.name = name
         self.register_buffer("qweight", torch.zeros(infeatures * outfeatures * bits // 32, dtype=torch.int32))
         self.native_group = ops.native_group(group_size)           # granularity of the native meta: 128, or the group itself for 64 / 32
-        self.register_buffer("meta", torch.zeros(infeatures // self.native_group * outfeatures * 2, dtype=torch.float16))
+        self.register_buffer("meta", torch.zeros(infeatures // self.native_group * outfeatures * 2, dtype=weight_dtype))
         # dequant arithmetic travels with the weights (0: (q - z) * s two roundings, 1: fma(q, s, c))
         self.register_buffer("mode_flag", torch.tensor([mode], dtype=torch.int32))
         if bias is not None and bias is not False:
@@ -262,7 +266,7 @@ class HIPQuantLinear(nn.Module):
         dev = torch.device(device) if device is not None else h.W_q.device
         if dev.type != "cuda":
             raise RuntimeError("HIPQuantLinear.from_hqq needs a GPU device (repack runs as a HIP kernel)")
-        mod = cls(h.nbits, h.group_size, k, n, bias=h.bias, name=h.name)
+        mod = cls(h.nbits, h.group_size, k, n, bias=h.bias, name=h.name, weight_dtype=torch.bfloat16 if h.scale.dtype == torch.bfloat16 else torch.float16)
         qn, mn = ops.repack_from_hqq(h.W_q.to(dev).contiguous(), h.scale.to(dev).reshape(-1).contiguous(),
                                      h.zero.to(dev).reshape(-1).contiguous(), h.nbits, n, k, group=h.group_size)
         mod._set_native(qn, mn, ops.MODE_HQQ)
@@ -323,7 +327,7 @@ class HIPQuantLinear(nn.Module):
         the group, |dw| <= ~ulp(z * s) -- relative to |z * s|, so several ulps of a small weight (z ~ 7.5, q - z = 0.5: ~7) -- which IS the reference's
         ``backend='gptq'`` arithmetic, bit for bit (tests/test_gpu_hf.py).  The GEMV kernel then unpacks a weight pair
         with one packed op where the layer's scales allow it (``AMQ_MODE_FMA1``): ~5-8 % more decode tokens/s.  Idempotent; returns self."""
-        if self.mode != ops.MODE_HQQ:
+        if self.mode != ops.MODE_HQQ or self.is_bf16:       # (bf16 modules: the reference's kernels, whose arithmetic this is, are fp16-only)
             return self
         mt = self.meta.clone().view(-1, 2)                   # a NEW buffer: launch handles built over the old one notice and rebuild
         mt[:, 1] = -(mt[:, 1] * mt[:, 0])                    # fp16 product, as the reference forms it
@@ -356,8 +360,16 @@ class HIPQuantLinear(nn.Module):
             self.__dict__["_ptrs_ok"] = key
         return key
 
+    @property
+    def is_bf16(self):
+        return self.meta.dtype == torch.bfloat16     # (the buffer's dtype: survives state_dict / deepcopy / unpickling of older modules)
+
     def forward(self, x):
         x_dtype = x.dtype
+        if self.is_bf16:                             # the optional bfloat16 variant: one call, any row count, no grouping
+            y = ops.linear_bf16(x if x_dtype == torch.bfloat16 else x.to(torch.bfloat16), self.qweight, self.meta, self.bits,
+                                self.outfeatures, self.infeatures, bias=self.bias)
+            return y if x_dtype == torch.bfloat16 else y.to(x_dtype)
         if x_dtype != torch.float16:
             # the reference casts (with a warning) too: autogptq.py:166-169
             x = x.to(torch.float16)

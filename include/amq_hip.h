@@ -45,8 +45,9 @@
 extern "C" {
 #endif
 
-#define AMQ_VERSION 500            /* 0.5.0: amq_gemv_opts.math renumbered (0 = the build's default), amq_default_gemv_math added; the decode-engine and
-                                    * fused q/k/v-attention entry points live in libamq_hip_ab.so (include/amq_hip_ab.h) since 0.4 */
+#define AMQ_VERSION 510            /* 0.5.1: the bfloat16 entry points (amq_*_bf16) added, nothing else changed.  0.5.0: amq_gemv_opts.math renumbered
+                                    * (0 = the build's default), amq_default_gemv_math added; the decode-engine and fused q/k/v-attention entry points live in
+                                    * libamq_hip_ab.so (include/amq_hip_ab.h) since 0.4 */
 
 #define AMQ_OK            0
 #define AMQ_EINVAL       -1        /* bad argument (null pointer, bits, mode ...) */
@@ -384,6 +385,25 @@ int amq_rope_rows_f16(void* q, void* k, const void* rope_table, int rope_rows, i
                       int n_kv_heads, int head_dim, void* stream);
 /* out = fp16(silu(gate)) * up elementwise, n fp16 elements (n % 8 == 0): the LlamaMLP activation between up/gate and down */
 int amq_silu_mul_f16(const void* gate, const void* up, void* out, size_t n, void* stream);
+
+/* ---- bfloat16 variants (optional) ------------------------------------------------------------------
+ * For models quantized with compute_dtype = torch.bfloat16: HQQLinear keeps scale / zero in the compute dtype and dequantizes in it
+ * (hqq/core/quantize.py:184-199, 396-407, 516), W = bf16(bf16(q - zero) * scale).  The native payload is the fp16 path's; the meta words hold
+ * bfloat16 (scale, zero) pairs -- amq_repack_from_hqq copies 16-bit patterns, so it repacks a bf16 model as it stands.  A native buffer repacked from
+ * bf16 meta must only be given to the *_bf16 entry points (and one repacked from fp16 meta only to the *_f16 ones): the meta carries no dtype tag.
+ * AMQ_MODE_HQQ arithmetic and groups of 128 (or multiples) only: the reference's GPTQ / AWQ kernels are fp16-only (hqq/backends/ft.py:62).
+ * x, bias, residual, y, W_out: bfloat16.  Weights bit-identical to Quantizer.dequantize; fp32 accumulation, one bf16 rounding of y, bias and residual as
+ * separate bf16 adds. */
+int amq_dequantize_bf16(int bits, const void* qweight_native, const void* meta_native_bf16, int N, int K, int group, void* W_out, void* stream);
+/* 1 .. 16 rows: weight-streaming kernel (unpacked block = MFMA operand, v_mfma_f32_16x16x32_bf16); x_stride / y_stride in elements (0 = dense;
+ * x_stride a multiple of 8: rows are read in 16-byte pieces).  residual (or null): y = residual + (x W^T + bias), bfloat16 [M, y_stride], may alias y */
+int amq_gemv_bf16(int bits, const void* x, const void* qweight_native, const void* meta_native_bf16, const void* bias, const void* residual, void* y,
+                  int M, int N, int K, int group, int x_stride, int y_stride, void* stream);
+/* any M: up to 16 rows amq_gemv_bf16; beyond, dequantize once into `workspace` (>= amq_gemm_bf16_workspace_bytes(M, N, K) bytes = N * K * 2 from 17 rows)
+ * and multiply with the bf16 instantiation of the MFMA-bound GEMM kernel (amq_gemm_f16.hip); x_stride % 8 == 0 and y_stride % 4 == 0 there */
+size_t amq_gemm_bf16_workspace_bytes(int M, int N, int K);
+int amq_gemm_bf16(int bits, const void* x, const void* qweight_native, const void* meta_native_bf16, const void* bias, const void* residual, void* y,
+                  int M, int N, int K, int group, int x_stride, int y_stride, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -119,3 +119,32 @@ def dequantize_from_q(q_nk, scale, zero, group_size=128):
     scale = np.asarray(scale, dtype=np.float16).reshape(r, 1)
     zero = np.asarray(zero, dtype=np.float16).reshape(r, 1)
     return ((wr - zero).astype(np.float16) * scale).astype(np.float16).reshape(n, k)
+
+
+# ------------------------------------------------- bfloat16 compute dtype
+# HQQLinear(compute_dtype=torch.bfloat16) keeps scale / zero in bf16 and runs
+# the same two-op dequantize in bf16 (quantize.py:184-199, 396-407, 516).
+# numpy has no bfloat16: values travel as uint16 bit patterns; each torch bf16
+# op is "widen to fp32, operate, round to nearest even", restated below.
+def bf16_bits_to_f32(bits):
+    return (np.asarray(bits, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def f32_to_bf16_bits(x):
+    """round-to-nearest-even fp32 -> bf16 bit patterns (finite inputs; NaN kept quiet)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    rounded = ((u + (np.uint32(0x7FFF) + ((u >> 16) & 1))) >> 16).astype(np.uint16)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    return np.where(nan, np.uint16(0x7FC0), rounded).astype(np.uint16)
+
+
+def dequantize_bf16(wq, scale_bits, zero_bits, nbits, shape, group_size=128):
+    """Quantizer.dequantize with compute_dtype = bfloat16 -> bf16 bits [N,K]:
+    W = bf16(bf16(W_r - zero) * scale), scale / zero given as bf16 bits [R,1]."""
+    n, k = shape
+    r = n * k // group_size
+    wr = _UNPACK[nbits](wq)[:r].astype(np.float32)
+    s = bf16_bits_to_f32(scale_bits).reshape(r, 1)
+    z = bf16_bits_to_f32(zero_bits).reshape(r, 1)
+    d = bf16_bits_to_f32(f32_to_bf16_bits(wr - z))
+    return f32_to_bf16_bits(d * s).reshape(n, k)

@@ -41,3 +41,17 @@ def hqq_forward(x, wq, scale, zero, nbits, shape, group_size=128, bias=None):
     (patching.py:95-100 with quantize.py:184-199)."""
     from .hqq_ref import dequantize
     return linear_f16(x, dequantize(wq, scale, zero, nbits, shape, group_size), bias)
+
+
+def linear_bf16(x_bits, w_bits, bias_bits=None):
+    """F.linear on bfloat16 tensors given as uint16 bit patterns: fp32 accumulate,
+    one rounding of y to bf16, bias as a separate bf16 add (what torch's CPU
+    bf16 matmul + add do; summation order is implementation-defined, so parity
+    is to bf16 output rounding, not bitwise)."""
+    from .hqq_ref import bf16_bits_to_f32, f32_to_bf16_bits
+    x = bf16_bits_to_f32(x_bits)
+    w = bf16_bits_to_f32(w_bits)
+    y = f32_to_bf16_bits(x.reshape(-1, x.shape[-1]) @ w.T)
+    if bias_bits is not None:
+        y = f32_to_bf16_bits(bf16_bits_to_f32(y) + bf16_bits_to_f32(bias_bits))
+    return y.reshape(*x.shape[:-1], -1)

@@ -155,3 +155,46 @@ def test_coarser_group_oracle_matches_reference(path):
     yf = gptq_ref.forward_fallback(g["gptq_x"], g["gptq_qweight"], g["gptq_scales"], g["gptq_zeros"], bits, G)
     rf = g["gptq_y"].astype(np.float32)
     assert np.all(np.abs(yf.astype(np.float32) - rf) <= 1e-3 * np.abs(rf) + 2e-4)
+
+
+# ---- bfloat16 compute dtype (tests/golden/gen_golden_bf16.py: HQQLinear(compute_dtype=torch.bfloat16) on CPU)
+BF16_CASES = sorted(glob.glob(os.path.join(GOLDEN, "bf16_b*.npz")))
+
+
+def bf16_close(y_bits, ref_bits, ulps=1.0, floor=2.0 ** -8):
+    """|y - ref| <= ulps * 2^-7 * |ref| + floor * rms(ref): one bf16 ulp of the output (bf16 keeps 8 significant bits, so the
+    1e-3 bar of the fp16 path is below its rounding step) plus a floor for outputs that cancel."""
+    y, ref = hqq_ref.bf16_bits_to_f32(y_bits).astype(np.float64), hqq_ref.bf16_bits_to_f32(ref_bits).astype(np.float64)
+    bar = ulps * 2.0 ** -7 * np.abs(ref) + floor * np.sqrt(np.mean(ref ** 2))
+    return bool(np.all(np.abs(y - ref) <= bar)), float(np.max(np.abs(y - ref) / bar))
+
+
+def test_bf16_fixture_inventory():
+    assert len(BF16_CASES) == 6
+
+
+def test_bf16_rounding_helper():
+    import torch
+    x = torch.randn(4096, dtype=torch.float32) * torch.logspace(-8, 8, 4096)
+    x[:4] = torch.tensor([1.00390625, 1.01171875, -1.00390625, 3.0e38])      # ties: to even both ways; near the top of the range
+    got = hqq_ref.f32_to_bf16_bits(x.numpy())
+    want = x.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(got, want)
+    assert np.array_equal(hqq_ref.bf16_bits_to_f32(want), x.to(torch.bfloat16).float().numpy())
+
+
+@pytest.mark.parametrize("path", BF16_CASES, ids=[os.path.basename(c) for c in BF16_CASES])
+def test_bf16_dequantize_bit_exact(path):
+    g = _load(path)
+    bits, shape = int(g["nbits"]), tuple(int(v) for v in g["shape"])
+    w = hqq_ref.dequantize_bf16(g["W_q"], g["scale"], g["zero"], bits, shape, 128)
+    assert w.dtype == np.uint16 and np.array_equal(w, g["W_deq"])
+
+
+@pytest.mark.parametrize("path", BF16_CASES, ids=[os.path.basename(c) for c in BF16_CASES])
+def test_bf16_reference_forward(path):
+    g = _load(path)
+    for tag in ("", "16"):
+        y = linear_ref.linear_bf16(g["x" + tag], g["W_deq"], g.get("bias"))
+        ok, worst = bf16_close(y, g["y" + tag + "_ref"])
+        assert ok, (tag, worst)
