@@ -11,7 +11,9 @@
 //     w = bf16(float(d) * float(s))      the product of two 8-bit significands is exact in fp32
 // => bit-identical to Quantizer.dequantize under compute_dtype = bfloat16 (tests: the reference's own output as a golden vector).
 // There is no packed bf16 VALU arithmetic on gfx950: the unpack runs in fp32 (v_cvt_f32_ubyte, v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_bf16_f32),
-// ~5.5 instructions per weight against 1.5 - 3 on the fp16 path, so the bf16 GEMV is VALU-bound at 2 - 4 bit where the fp16 one is not.
+// ~4.7 instructions per weight against 1.5 - 3 on the fp16 path, so the bf16 GEMV is VALU-bound at 2 - 4 bit: 5.9 / 11.5 / 12.1 us per launch on the 7B
+// shapes (4096 x 4096 / gate-up / down, 4 bit, one row) against 4.6 / 7.6 / 7.7 for the fp16 kernel (tools/bf16_bench.py, profiles/r05_bf16.txt); two or
+// four tile loads in flight per wave measure the same.
 //
 // gemv_bf16_kernel: 8 waves own one row-tile (16 output rows) at a time and split its K / 128 tiles round-robin; the unpacked 16 x 32 block is the A
 // operand of v_mfma_f32_16x16x32_bf16, 16 x rows (clamped to M) the B operand, fp32 accumulation, a fixed-order cross-wave sum through LDS (deterministic).
@@ -34,15 +36,54 @@ __device__ __forceinline__ uint32_t pair_raw(const uint32_t* w, int P) {
     return ((w[0] >> 15) & 0x00010001u) | ((w[1] >> 14) & 0x00020002u) | ((w[2] >> 13) & 0x00040004u);
 }
 
-// one lane's 8 weights of MFMA step t as bfloat16, from the meta word (scale | zero << 16)
+// (float) of byte B of a dword, where it lies: v_cvt_f32_ubyte<B>.  Written as asm: the compiler turns the C expression into shift + and + ubyte0
+// (measured: 180 -> 150 VALU instructions per tile, -10 % per launch -- the kernel is VALU-bound)
+template <int B>
+__device__ __forceinline__ float cvt_ubyte(uint32_t v) {
+    float f;
+    if (B == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(v));
+    else if (B == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(v));
+    else if (B == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(v));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(v));
+    return f;
+}
+
+// one lane's 8 weights of MFMA step t as bfloat16, from the meta word (scale | zero << 16).
+// 4 / 2 bit: one mask isolates FOUR weights in the four bytes of a dword (byte 0 / 2 = low / high weight of a pair, byte 1 / 3 = of the pair 8 bits on), and
+// v_cvt_f32_ubyte0..3 converts a byte where it lies; 3 bit: a pair at a time (fields do not fall on byte boundaries).
 template <int BITS>
 __device__ __forceinline__ b8 dequant_step_bf16(const uint32_t* w, int t, float s, float z) {
+    float q[8];                                                                   // q[2 p], q[2 p + 1] = pair 4 t + p
+    if (BITS == 4) {
+        const uint32_t a = w[t] & 0x0F0F0F0Fu, b = (w[t] >> 4) & 0x0F0F0F0Fu;     // a: pairs 0 (bytes 0, 2) and 2 (bytes 1, 3); b: pairs 1 and 3
+        q[0] = cvt_ubyte<0>(a); q[1] = cvt_ubyte<2>(a); q[4] = cvt_ubyte<1>(a); q[5] = cvt_ubyte<3>(a);
+        q[2] = cvt_ubyte<0>(b); q[3] = cvt_ubyte<2>(b); q[6] = cvt_ubyte<1>(b); q[7] = cvt_ubyte<3>(b);
+    } else if (BITS == 2) {
+        // pairs P = 4 t + p live in dword P / 8 at bits 2 (P % 8): t even -> slots 0 .. 3 (bits 0 .. 7 of each half), t odd -> slots 4 .. 7 (bits 8 .. 15):
+        // with the odd steps' fields left where they are, slot p + 4 is byte 1 / 3 of (u >> 2 p) & 0x03000300
+        const uint32_t u = w[t >> 1];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (t & 1) {
+                const uint32_t a = (u >> (2 * p)) & 0x03000300u;
+                q[2 * p] = cvt_ubyte<1>(a); q[2 * p + 1] = cvt_ubyte<3>(a);
+            } else {
+                const uint32_t a = (u >> (2 * p)) & 0x00030003u;
+                q[2 * p] = cvt_ubyte<0>(a); q[2 * p + 1] = cvt_ubyte<2>(a);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t a = pair_raw<BITS>(w, 4 * t + p);
+            q[2 * p] = cvt_ubyte<0>(a); q[2 * p + 1] = cvt_ubyte<2>(a);
+        }
+    }
     b8 out;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const uint32_t pr = pair_raw<BITS>(w, 4 * t + p);
-        const f2 q = {(float)(pr & 0xFFu), (float)((pr >> 16) & 0xFFu)};
-        const b2 d = __builtin_convertvector(q - (f2){z, z}, b2);                 // rounding 1: W_r - zero
+        const f2 qq = {q[2 * p], q[2 * p + 1]};
+        const b2 d = __builtin_convertvector(qq - (f2){z, z}, b2);                 // rounding 1: W_r - zero
         const b2 v = __builtin_convertvector(__builtin_convertvector(d, f2) * (f2){s, s}, b2);   // rounding 2: * scale
         out[2 * p] = v[0];
         out[2 * p + 1] = v[1];
@@ -71,6 +112,10 @@ __global__ __launch_bounds__(256) void dequant_native_bf16_kernel(const uint32_t
 }
 
 constexpr int BG_WAVES = 8, BG_THREADS = BG_WAVES * 64;
+#ifndef AMQ_BF16_DEPTH
+#define AMQ_BF16_DEPTH 2
+#endif
+constexpr int BG_DEPTH = AMQ_BF16_DEPTH;                                // tile loads in flight per wave
 constexpr int BG_XPAD = 8;                                 // halves of padding per staged x row: 16 rows' ds_read_b128 then start in different banks
 constexpr size_t BG_RED_BYTES = (size_t)BG_WAVES * 64 * sizeof(f4);
 constexpr size_t BG_LDS_LIMIT = 152 * 1024;
@@ -85,11 +130,26 @@ __global__ __launch_bounds__(BG_THREADS) void gemv_bf16_kernel(GemvBf16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f4* const red = (f4*)smem;                              // [wave][lane]
     __bf16* const xs = (__bf16*)(smem + BG_RED_BYTES);      // XL: [M][K + BG_XPAD]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: the ring's conditions are wave-uniform)
     const int r = lane & 15, o = lane >> 4;
     const int G = a.K >> 7, n_rt = a.N >> 4;
     const __bf16* const x = (const __bf16*)a.x;
     const int xrow = r < a.M ? r : a.M - 1;                 // B-operand rows past M repeat the last one: their output columns are never stored
+    // a wave's tiles of a row-tile are g = wave, wave + 8, ...; BG_DEPTH of them are in flight in a register ring.  The first row-tile's loads leave
+    // BEFORE x is staged (they do not depend on it), the next row-tile's before the cross-wave sum of the current one.
+    LanePayload<BITS> p[BG_DEPTH];
+    uint32_t mw[BG_DEPTH];
+    auto issue = [&](int d, int rt, int g) {
+        p[d] = load_payload<BITS>(a.qn + ((size_t)rt * G + g) * 64 * BITS, lane);
+        mw[d] = a.mn[((size_t)rt * G + g) * 16 + r];
+    };
+    auto prime = [&](int rt) {
+#pragma unroll
+        for (int d = 0; d < BG_DEPTH; ++d)
+            if (wave + BG_WAVES * d < G) issue(d, rt, wave + BG_WAVES * d);
+    };
+    int rt = blockIdx.x;
+    if (rt < n_rt) prime(rt);
     if (XL) {
         const int k8 = a.K >> 3;                            // 16-byte pieces per row
         for (int i = tid; i < a.M * k8; i += BG_THREADS) {
@@ -100,28 +160,26 @@ __global__ __launch_bounds__(BG_THREADS) void gemv_bf16_kernel(GemvBf16Args a) {
     }
     const __bf16* const xl = XL ? xs + (size_t)xrow * (a.K + BG_XPAD) + 8 * o : x + (size_t)xrow * a.x_stride + 8 * o;
 
-    for (int rt = blockIdx.x; rt < n_rt; rt += gridDim.x) {
+    for (; rt < n_rt; rt += gridDim.x) {
         f4 acc = {0.f, 0.f, 0.f, 0.f};
-        const uint32_t* const qrt = a.qn + (size_t)rt * G * 64 * BITS;
-        const uint32_t* const mrt = a.mn + (size_t)rt * G * 16 + r;
-        int g = wave;
-        LanePayload<BITS> p;
-        uint32_t m = 0;
-        if (g < G) { p = load_payload<BITS>(qrt + (size_t)g * 64 * BITS, lane); m = mrt[(size_t)g * 16]; }
-        while (g < G) {
-            const int gn = g + BG_WAVES;
-            LanePayload<BITS> pn = p;
-            uint32_t mnx = m;
-            if (gn < G) { pn = load_payload<BITS>(qrt + (size_t)gn * 64 * BITS, lane); mnx = mrt[(size_t)gn * 16]; }     // the next tile is in flight under this one's unpack
-            const float s = bf_lo(m), z = bf_hi(m);
-            b8 xf[4];
+        for (int g0 = wave; g0 < G; g0 += BG_WAVES * BG_DEPTH) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xf[t] = *(const b8*)(xl + g * 128 + 32 * t);
+            for (int d = 0; d < BG_DEPTH; ++d) {
+                const int g = g0 + BG_WAVES * d;            // (wave-uniform conditions)
+                if (g < G) {
+                    const float s = bf_lo(mw[d]), z = bf_hi(mw[d]);
+                    b8 xf[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dequant_step_bf16<BITS>(p.w, t, s, z), xf[t], acc, 0, 0, 0);
-            p = pn; m = mnx; g = gn;
+                    for (int t = 0; t < 4; ++t) xf[t] = *(const b8*)(xl + g * 128 + 32 * t);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dequant_step_bf16<BITS>(p[d].w, t, s, z), xf[t], acc, 0, 0, 0);
+                    const int gn = g + BG_WAVES * BG_DEPTH;
+                    if (gn < G) issue(d, rt, gn);           // the slot is free: its next tile of this row-tile
+                }
+            }
         }
+        if (rt + (int)gridDim.x < n_rt) prime(rt + (int)gridDim.x);
         // acc[i] = partial y[m = r][n = 16 rt + 4 o + i]: sum over the waves in wave order
         red[wave * 64 + lane] = acc;
         __syncthreads();
