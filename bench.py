@@ -184,12 +184,48 @@ def beyond_the_metric(dev):
                 "bits_usage": round(usage, 3),
                 "config": "BASELINE.json configs[3]: 16 x 2048 rows, whole model (linears + attention + norms + lm_head)"}
 
+    def bf16_variant():
+        # the optional bfloat16 entry points (include/amq_hip.h "bfloat16 variants"): a 4096 x 4096 3-bit layer with bf16 (scale, zero) --
+        # weights against the oracle bit for bit, y against torch's CPU F.linear on them (bar: one bf16 ulp), and what a launch costs: the few-row kernel
+        # over weights cold in HBM (72 copies in one graph), the batched end (dequantize once + the bf16 MFMA GEMM) at 8192 rows of the 13B gate/up shape
+        import numpy as np
+        from amq_amd.hqq_format import random_hqq
+        from oracle import hqq_ref
+        bits, n, k = 3, 4096, 4096
+        h = random_hqq(n, k, bits, seed=11)
+        sb, zb = h.scale.float().to(torch.bfloat16), h.zero.float().to(torch.bfloat16)
+        as_bits = lambda t: t.detach().contiguous().cpu().view(torch.int16).numpy().view(np.uint16)
+        w_ref = hqq_ref.dequantize_bf16(h.W_q.numpy(), as_bits(sb), as_bits(zb), bits, (n, k), 128)
+        qn, mn = ops.repack_from_hqq(h.W_q.to(dev), sb.reshape(-1).to(dev), zb.reshape(-1).to(dev), bits, n, k)
+        exact = bool(np.array_equal(as_bits(ops.dequantize_bf16(qn, mn, bits, n, k)), w_ref))
+        x = torch.randn(5, k, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16)
+        y = ops.linear_bf16(x.to(dev), qn, mn, bits, n, k).float().cpu().double()
+        ref = torch.nn.functional.linear(x, torch.from_numpy(w_ref.view(np.int16)).view(torch.bfloat16)).double()
+        bar = 2.0 ** -7 * ref.abs() + 2.0 ** -8 * ref.pow(2).mean().sqrt()
+        worst = float(((y - ref).abs() / bar).max())
+        copies = [qn.clone() for _ in range(72)]                       # 72 x 6.3 MB: past the 256 MB last-level cache
+        xd = x[:1].to(dev).contiguous()
+        yd = torch.empty(1, n, dtype=torch.bfloat16, device=dev)
+        t = _graph_time(dev, lambda: [ops.linear_bf16(xd, c, mn, bits, n, k, out=yd) for c in copies], 5) / len(copies)
+        del copies
+        M, N, K = 8192, 13824, 5120
+        hb = random_hqq(N, K, bits, seed=12).to(dev)
+        qb, mb = ops.repack_from_hqq(hb.W_q, hb.scale.float().to(torch.bfloat16).reshape(-1), hb.zero.float().to(torch.bfloat16).reshape(-1), bits, N, K)
+        xb = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        yb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        tg = _graph_time(dev, lambda: ops.linear_bf16(xb, qb, mb, bits, N, K, out=yb), 5)
+        return {"weights_bit_exact": exact, "max_err_over_bar": round(worst, 3), "ok": bool(exact and worst <= 1.0),
+                "bar": "|y - y_cpu| <= 2^-7*|y_cpu| + 2^-8*rms(y_cpu) (one bf16 ulp)", "gemv_us_per_launch_4096x4096_3bit": round(t * 1e6, 2),
+                "gemm_tflops_8192x13824x5120": round(2.0 * M * N * K / tg / 1e12, 1),
+                "kernels": "amq::gemv_bf16_kernel; amq::dequant_native_bf16_kernel + amq::gemm_bf16_pp_kernel"}
+
     leg("decode_tokens_per_s_at_2048_cached_keys", long_cache)
     leg("decode_tokens_per_s_8_sequences", eight_sequences)
     leg("decode_tokens_per_s_reference_format_weights", reference_format)
     leg("decode_tokens_per_s_groupscale_math", groupscale)
     leg("llama70b_one_replica", llama70b)
     leg("llama13b_prompt_pass", llama13b)
+    leg("bf16_variant", bf16_variant)
     return out
 
 
