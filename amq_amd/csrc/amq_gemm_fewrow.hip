@@ -97,6 +97,17 @@ __device__ __forceinline__ void fewrow_stream_body(const GemmArgs& a, int bx, un
             for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xr[xs_][mb], b, acc[mb][nb], 0, 0, 0);
 #endif
         }
+#ifdef AMQ_FS_INTERLEAVE           /* A/B: a block's four MFMAs issue one per four unpack instructions of the NEXT block (the default order is 16 unpack, 4 MFMAs per block) */
+        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+#pragma unroll
+        for (int nb = 0; nb + 1 < NSUB; ++nb)
+#pragma unroll
+            for (int i_ = 0; i_ < 4; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
     };
 
     // prime: weights of this wave's first two tiles, x steps of the first (XS = 8: first two) tiles
