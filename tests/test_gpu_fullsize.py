@@ -73,6 +73,38 @@ def test_llama70b_block_shapes_grouped_decode_step():
     assert torch.equal(m2.logits, m.logits)
 
 
+def test_llama70b_whole_replica_decodes():
+    """BASELINE.json configs[4]'s unit of work: ONE whole Llama-2-70B replica (80 blocks, GQA 64 / 8 heads, 28672-wide MLP, the synthesized avg-3-bit
+    arch; ~26 GB of synthetic weights) prefills 64 tokens and decodes: the hipGraph step and the eager step produce the same tokens and logits bit for
+    bit, every logit finite, no step past the cache, and the replica's linears weigh what the arch says (the bench line's roofline figure uses it)"""
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama
+    cfg = arch.MODEL_CONFIGS["Llama-2-70b-hf"]
+    a, usage = arch.synthesize_arch(cfg, 3.0, seed=0, pinned=())
+    assert abs(usage - 3.0) < 0.05 and len(a["linear"]["self_attn.q_proj"]) == 80
+    m = QuantLlama(cfg, a["linear"], device=torch.device("cuda:0"), max_seq=64 + 16, seed=0)
+    assert len(m.blocks) == 80
+    numel = sum(blk[name].N * blk[name].K for blk in m.blocks for name in m.cfg["linear"])
+    assert abs(m.linear_bytes_per_token() / (numel * (usage + 0.25) / 8 + 0) - 1.0) < 0.02     # bits_usage counts the 0.25 bit of (scale, zero) apart?  see below
+    ids = torch.randint(0, m.vocab - 1, (64,), generator=torch.Generator().manual_seed(0)).to("cuda:0")
+    m.prefill(ids)
+    first = int(m.token.item())
+    toks_graph = []
+    for _ in range(6):
+        m.decode_step()
+        toks_graph.append(int(m.token.item()))
+    logits_graph = m.logits.clone()
+    m.check()
+    assert torch.isfinite(logits_graph.float()).all() and int(m.pos.item()) == 70
+    m.prefill(ids)                                          # the same replica again, eager steps over the same weights
+    assert int(m.token.item()) == first
+    toks_eager = []
+    for _ in range(6):
+        m.decode_step(use_graph=False)
+        toks_eager.append(int(m.token.item()))
+    assert toks_eager == toks_graph and torch.equal(m.logits, logits_graph)
+
+
 def test_llama13b_block_batched_prompt_pass_at_config4_size():
     """BASELINE.json configs[3] at size: one 13B-shaped block, 16 x 2048 prompt rows through prefill_batch (every linear at
     M = 32768).  Checked through properties: finite logits; the hand-written kernels and the dequantize + library route
