@@ -84,8 +84,9 @@ def test_llama70b_whole_replica_decodes():
     assert abs(usage - 3.0) < 0.05 and len(a["linear"]["self_attn.q_proj"]) == 80
     m = QuantLlama(cfg, a["linear"], device=torch.device("cuda:0"), max_seq=64 + 16, seed=0)
     assert len(m.blocks) == 80
-    numel = sum(blk[name].N * blk[name].K for blk in m.blocks for name in m.cfg["linear"])
-    assert abs(m.linear_bytes_per_token() / (numel * (usage + 0.25) / 8 + 0) - 1.0) < 0.02     # bits_usage counts the 0.25 bit of (scale, zero) apart?  see below
+    # packed payload + 0.25 bit of (scale, zero) per weight: BASELINE.md section 3's per-layer bytes, summed (25.9 GB per token)
+    want = sum(blk[name].N * blk[name].K * (4 * blk[name].bits + 1) // 32 for blk in m.blocks for name in m.cfg["linear"])
+    assert m.linear_bytes_per_token() == want and 25e9 < want < 27e9
     ids = torch.randint(0, m.vocab - 1, (64,), generator=torch.Generator().manual_seed(0)).to("cuda:0")
     m.prefill(ids)
     first = int(m.token.item())
