@@ -52,6 +52,26 @@ def test_from_hqq_layer_duck_typing_and_rejections():
             hqq_format.from_hqq_layer(layer)
 
 
+def test_from_hqq_layer_keeps_a_bf16_layer_in_bf16():
+    """compute_dtype = bfloat16 layers (scale / zero in bf16, quantize.py:516) stay bf16 -- the bf16 entry points reproduce their arithmetic; any other
+    meta dtype goes to fp16, the dtype of the reference's kernels"""
+    class HQQLinear:
+        pass
+    h = hqq_format.random_hqq(32, 256, 4, seed=2)
+    for src, want in ((torch.bfloat16, torch.bfloat16), (torch.float32, torch.float16), (torch.float16, torch.float16)):
+        layer = HQQLinear()
+        meta = dict(h.meta)
+        meta["scale"], meta["zero"] = h.scale.to(src), h.zero.to(src)
+        layer.W_q, layer.meta, layer.bias, layer.name = h.W_q, meta, None, "v_proj"
+        got = hqq_format.from_hqq_layer(layer)
+        assert got.scale.dtype == want and got.zero.dtype == want and got.scale.shape == (32 * 256 // 128, 1)
+    # one bf16, one fp16: not a bf16 layer
+    meta = dict(h.meta)
+    meta["scale"] = h.scale.to(torch.bfloat16)
+    layer.meta = meta
+    assert hqq_format.from_hqq_layer(layer).scale.dtype == torch.float16
+
+
 def test_checkpoint_loader_reads_reference_files():
     root = os.path.join(GOLDEN, "ckpt")
     for bits in (2, 3, 4):
