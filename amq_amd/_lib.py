@@ -63,6 +63,7 @@ SIGNATURES = {
     "amq_dequantize_f16": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "amq_dequantize_hqq_f16": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "amq_dequantize_bf16": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "amq_dequantize_hqq_bf16": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "amq_gemv_bf16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_gemm_bf16_workspace_bytes": (_sz, [_i, _i, _i]),
     "amq_gemm_bf16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -111,6 +111,43 @@ __global__ __launch_bounds__(256) void dequant_native_bf16_kernel(const uint32_t
     for (int t = 0; t < 4; ++t) *(b8*)(row + 32 * t) = dequant_step_bf16<BITS>(p.w, t, s, z);
 }
 
+// HQQ Format A -> bfloat16 W[N,K] without going through the native layout: amq_repack.hip's dequant_hqq_kernel (one thread = 8 consecutive columns of one
+// packed row = C output rows' 16-byte stores) with the bf16 arithmetic above; any group size the fp16 kernel takes.
+template <int BITS>
+__global__ __launch_bounds__(256) void dequant_hqq_bf16_kernel(const void* wq, const uint16_t* scale, const uint16_t* zero, int R, __bf16* out, int gs) {
+    constexpr int C = BITS == 4 ? 2 : BITS == 2 ? 4 : 10;
+    const int step = BITS == 3 ? (R + 9) / 10 : R / C;     // packed rows (3 bit: rows zero-padded to a multiple of 10)
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int tpr = gs >> 3;
+    const int i = (int)(gid / tpr), c8 = (int)(gid % tpr) * 8;
+    if (i >= step) return;
+    uint32_t q[8];
+    if (BITS == 3) {
+        const u4 a = *(const u4*)((const uint32_t*)wq + (size_t)i * gs + c8);
+        const u4 b = *(const u4*)((const uint32_t*)wq + (size_t)i * gs + c8 + 4);
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    } else {
+        const u2 p = *(const u2*)((const uint8_t*)wq + (size_t)i * gs + c8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { q[e] = (p.x >> (8 * e)) & 0xFFu; q[4 + e] = (p.y >> (8 * e)) & 0xFFu; }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int row = c * step + i;
+        if (BITS == 3 && row >= R) continue;               // padding rows of the last chunks
+        const float s = bf_lo(scale[row]), z = bf_lo(zero[row]);
+        constexpr int width = BITS == 3 ? 3 : BITS;
+        const int shift = BITS == 3 ? 27 - 3 * c : 8 - width * (c + 1);      // chunk 0 sits in the top bits
+        b8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const __bf16 d = (__bf16)((float)((q[e] >> shift) & ((1u << width) - 1u)) - z);      // rounding 1
+            v[e] = (__bf16)((float)d * s);                                                        // rounding 2
+        }
+        *(b8*)(out + (size_t)row * gs + c8) = v;
+    }
+}
+
 constexpr int BG_WAVES = 8, BG_THREADS = BG_WAVES * 64;
 #ifndef AMQ_BF16_DEPTH
 #define AMQ_BF16_DEPTH 2
@@ -240,6 +277,16 @@ hipError_t launch_dequantize_bf16(int bits, const void* qn, const void* mn, int 
     if (bits == 4) hipLaunchKernelGGL((dequant_native_bf16_kernel<4>), dim3(blocks), dim3(256), 0, st, (const uint32_t*)qn, (const uint32_t*)mn, N, K, (__bf16*)w);
     else if (bits == 3) hipLaunchKernelGGL((dequant_native_bf16_kernel<3>), dim3(blocks), dim3(256), 0, st, (const uint32_t*)qn, (const uint32_t*)mn, N, K, (__bf16*)w);
     else hipLaunchKernelGGL((dequant_native_bf16_kernel<2>), dim3(blocks), dim3(256), 0, st, (const uint32_t*)qn, (const uint32_t*)mn, N, K, (__bf16*)w);
+    return hipGetLastError();
+}
+
+hipError_t launch_dequantize_hqq_bf16(int bits, const void* wq, const void* scale, const void* zero, int N, int K, void* w, hipStream_t st, int gs) {
+    const int R = (int)((size_t)N * K / gs);
+    const int step = bits == 3 ? (R + 9) / 10 : bits == 4 ? R / 2 : R / 4;
+    const unsigned blocks = (unsigned)(((size_t)step * (gs >> 3) + 255) / 256);
+    if (bits == 4) hipLaunchKernelGGL((dequant_hqq_bf16_kernel<4>), dim3(blocks), dim3(256), 0, st, wq, (const uint16_t*)scale, (const uint16_t*)zero, R, (__bf16*)w, gs);
+    else if (bits == 3) hipLaunchKernelGGL((dequant_hqq_bf16_kernel<3>), dim3(blocks), dim3(256), 0, st, wq, (const uint16_t*)scale, (const uint16_t*)zero, R, (__bf16*)w, gs);
+    else hipLaunchKernelGGL((dequant_hqq_bf16_kernel<2>), dim3(blocks), dim3(256), 0, st, wq, (const uint16_t*)scale, (const uint16_t*)zero, R, (__bf16*)w, gs);
     return hipGetLastError();
 }
 

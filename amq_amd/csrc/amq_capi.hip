@@ -545,6 +545,12 @@ int amq_dequantize_bf16(int bits, const void* qn, const void* mn, int N, int K, 
     return check_hip(amq::launch_dequantize_bf16(bits, qn, mn, N, K, W, (hipStream_t)stream), "dequantize_bf16");
 }
 
+int amq_dequantize_hqq_bf16(int bits, const void* W_q, const void* scale, const void* zero, int N, int K, int group, void* W, void* stream) {
+    if (int rc = check_shape(bits, N, K, group)) return rc;
+    if (!W_q || !scale || !zero || !W) return fail(AMQ_EINVAL, "null pointer");
+    return check_hip(amq::launch_dequantize_hqq_bf16(bits, W_q, scale, zero, N, K, W, (hipStream_t)stream, group), "dequantize_hqq_bf16");
+}
+
 int amq_gemv_bf16(int bits, const void* x, const void* qn, const void* mn, const void* bias, const void* residual, void* y,
                   int M, int N, int K, int group, int x_stride, int y_stride, void* stream) {
     if (int rc = check_shape128(bits, N, K, group, "amq_gemv_bf16")) return rc;

@@ -216,6 +216,7 @@ hipError_t launch_dequantize(int bits, int mode, const void* q_native, const voi
 // HQQ Format A -> fp16 W[N,K] directly (ATEN-style standalone dequant, f-4)
 // the optional bfloat16 entry points (amq_bf16.hip; the batched end: amq_gemm_f16.hip's kernel instantiated for bf16 operands)
 hipError_t launch_dequantize_bf16(int bits, const void* q_native, const void* meta_native_bf16, int N, int K, void* w_bf16, hipStream_t st);
+hipError_t launch_dequantize_hqq_bf16(int bits, const void* wq, const void* scale_bf16, const void* zero_bf16, int N, int K, void* w_bf16, hipStream_t st, int gs);
 hipError_t launch_gemv_bf16(int bits, const void* x, const void* q_native, const void* meta_native_bf16, const void* bias, const void* residual,
                             void* y, int M, int N, int K, int x_stride, int y_stride, hipStream_t st);
 hipError_t launch_gemm_bf16w(const void* x, const void* w, const void* bias, const void* residual, void* y,

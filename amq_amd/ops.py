@@ -160,6 +160,13 @@ def dequantize_hqq(W_q, scale, zero, bits, N, K, group=GROUP):
         _need(W_q, torch.int32, "W_q", ((R + 9) // 10) * group)
     else:
         _need(W_q, torch.uint8, "W_q", R * group * bits // 8)
+    if isinstance(scale, torch.Tensor) and scale.dtype == torch.bfloat16:      # a compute_dtype = bfloat16 layer: dequantized in bf16, as the reference does
+        _need(scale, torch.bfloat16, "scale", R)
+        _need(zero, torch.bfloat16, "zero", R)
+        out = torch.empty(N, K, dtype=torch.bfloat16, device=W_q.device)
+        _lib.check(_lib.load().amq_dequantize_hqq_bf16(bits, _lib.ptr(W_q), _lib.ptr(scale), _lib.ptr(zero), N, K, group,
+                                                       _lib.ptr(out), _lib.current_stream()))
+        return out
     _need(scale, torch.float16, "scale", R)
     _need(zero, torch.float16, "zero", R)
     out = torch.empty(N, K, dtype=torch.float16, device=W_q.device)

@@ -395,6 +395,8 @@ int amq_silu_mul_f16(const void* gate, const void* up, void* out, size_t n, void
  * x, bias, residual, y, W_out: bfloat16.  Weights bit-identical to Quantizer.dequantize; fp32 accumulation, one bf16 rounding of y, bias and residual as
  * separate bf16 adds. */
 int amq_dequantize_bf16(int bits, const void* qweight_native, const void* meta_native_bf16, int N, int K, int group, void* W_out, void* stream);
+/* Format A with bfloat16 scale / zero -> W[N,K] bfloat16: Quantizer.dequantize under compute_dtype = bfloat16 as one kernel (any group amq_dequantize_hqq_f16 takes) */
+int amq_dequantize_hqq_bf16(int bits, const void* W_q, const void* scale, const void* zero, int N, int K, int group, void* W_out, void* stream);
 /* 1 .. 16 rows: weight-streaming kernel (unpacked block = MFMA operand, v_mfma_f32_16x16x32_bf16); x_stride / y_stride in elements (0 = dense;
  * x_stride a multiple of 8: rows are read in 16-byte pieces).  residual (or null): y = residual + (x W^T + bias), bfloat16 [M, y_stride], may alias y */
 int amq_gemv_bf16(int bits, const void* x, const void* qweight_native, const void* meta_native_bf16, const void* bias, const void* residual, void* y,

@@ -88,6 +88,9 @@ def test_bf16_golden(path):
     assert mn.dtype == torch.bfloat16
     w = ops.dequantize_bf16(qn, mn, bits, n, k)
     assert np.array_equal(_bits(w), g["W_deq"])
+    # ... and straight from Format A (the standalone dequantize)
+    w2 = ops.dequantize_hqq(torch.from_numpy(g["W_q"]).to(_dev()), _bf(g["scale"].reshape(-1)), _bf(g["zero"].reshape(-1)), bits, n, k)
+    assert w2.dtype == torch.bfloat16 and np.array_equal(_bits(w2), g["W_deq"])
     bias = _bf(g["bias"]) if "bias" in g else None
     for tag in ("", "16"):
         y = ops.linear_bf16(_bf(g["x" + tag]), qn, mn, bits, n, k, bias=bias)
@@ -157,6 +160,20 @@ def test_bf16_many_rows_vs_oracle(bits, m, n, k):
     # 3-D input, leading dims kept
     y3 = ops.linear_bf16(x.to(_dev()).reshape(2, m // 2, k) if m % 2 == 0 else x.to(_dev()).reshape(1, m, k), qn, mn, bits, n, k)
     assert y3.shape[-1] == n and torch.equal(y3.reshape(m, n), y)
+
+
+@pytest.mark.parametrize("group", [32, 64, 128, 256])
+@pytest.mark.parametrize("bits", [2, 3, 4])
+def test_bf16_dequantize_hqq_groups(bits, group):
+    """Format A -> bf16 W at every group size the fp16 kernel takes, against the oracle bit for bit (3 bit: the zero-padded last chunks)"""
+    from amq_amd import ops
+    from amq_amd.hqq_format import random_hqq
+    n, k = 80, 512
+    h = random_hqq(n, k, bits, seed=bits + group, group=group)
+    sb, zb = h.scale.float().to(torch.bfloat16), h.zero.float().to(torch.bfloat16)
+    want = hqq_ref.dequantize_bf16(h.W_q.numpy(), _bits(sb), _bits(zb), bits, (n, k), group)
+    got = ops.dequantize_hqq(h.W_q.to(_dev()), sb.reshape(-1).to(_dev()), zb.reshape(-1).to(_dev()), bits, n, k, group=group)
+    assert np.array_equal(_bits(got), want)
 
 
 def test_bf16_rows_agree_across_the_kernel_boundary():
