@@ -571,6 +571,7 @@ constexpr int ATT_WS_STRIDE = ATT_D + 4;       // floats per (head, chunk): O[12
 #else
 #define ATT_KV_LOAD(p) (*(const h8*)(p))
 #endif
+template <int RING>
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_kc, void* p_vc, const void* p_state, int p_heads,
                                                                          int p_max_seq, const void* p_q, const void* p_k,
                                                                          const void* p_v, AttnRest rest, AttnSplit sp) {
@@ -631,23 +632,30 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_
     const bool has_new = t1 == T;                    // the chunk that holds the new token (the last active one)
     if (tid < 64 && !p_cur && rest.rope_table) cs_tab = ((const h2*)rest.rope_table)[(size_t)pos * 64 + tid];
     const int last_old = pos > 0 ? pos - 1 : 0;      // rows >= pos are never read from the cache
+    // The chunk's K and V rows travel through a RING of row loads per thread: RING rows of K leave here, a row's successor when the row is about to be
+    // used, V's first rows behind K's last, the rest of V as the output accumulates.  All 2 x 9 rows of a thread at once (the first form) put 144 KB per
+    // workgroup in flight -- 37 MB over the chip at 2048 keys, more than the launch reads -- and the rows then arrive at 3.9 TB/s at the margin; the memory
+    // system takes less in flight better: RING = ATT_PF (all of K at once, V trailing the scores) for launches of at most one workgroup per CU, 4 beyond
+    // (profiles/r05_attn_decode_long.txt: 13.7 -> 11.9 us at 2048 keys, 21.9 -> 18.1 at 4000).  Same values in the same order of arithmetic: results
+    // unchanged bit for bit.
     h8 krow[ATT_PF], vrow[ATT_PF];
-#pragma unroll
-    for (int i = 0; i < ATT_PF; ++i) {
+    auto load_k = [&](int i) {
         if (ATT_GROUPS * i < Tl) {
             int t = t0 + grp + ATT_GROUPS * i;
             t = t < last_old ? t : last_old;
             krow[i] = ATT_KV_LOAD(kc + (size_t)t * ATT_D + 8 * l16);
         }
-    }
-#pragma unroll
-    for (int i = 0; i < ATT_PF; ++i) {
+    };
+    auto load_v = [&](int i) {
         if (ATT_GROUPS * i < Tl) {
             int t = t0 + grp + ATT_GROUPS * i;
             t = t < last_old ? t : last_old;
             vrow[i] = ATT_KV_LOAD(vc + (size_t)t * ATT_D + 8 * l16);
         }
-    }
+    };
+    static_assert(RING >= 1 && RING <= ATT_PF, "ring depth");
+#pragma unroll
+    for (int i = 0; i < RING; ++i) load_k(i);
     if (tid < 64) {
         _Float16 c16, s16;
         if (p_cur) { c16 = cs_cur.x; s16 = cs_cur.y; }
@@ -685,6 +693,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_
     };
 #pragma unroll
     for (int i = 0; i < ATT_PF; ++i) {
+        if (i + RING < ATT_PF) load_k(i + RING);
+        else load_v(i + RING - ATT_PF);
         if (ATT_GROUPS * i < Tl) {
             const int t = t0 + grp + ATT_GROUPS * i;
             const float sv = score(t == pos ? knew : krow[i]);
@@ -727,6 +737,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_
     };
 #pragma unroll
     for (int i = 0; i < ATT_PF; ++i) {
+        if (i + RING < ATT_PF) load_v(i + RING);
         const int t = t0 + grp + ATT_GROUPS * i;
         if (ATT_GROUPS * i < Tl && t < t1) {
             const float p = weight(t - t0);
@@ -966,11 +977,10 @@ static int att_chunk_max(int max_seq, int n_splits) {
     return c < ATT_MIN_CHUNK ? ATT_MIN_CHUNK : c;
 }
 
-hipError_t launch_attn_decode_split(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, hipStream_t st) {
-    StreamDevice sd_(st);                                  // kernel attributes are per device: the stream's, not the current one
-    const size_t lds = 6 * ATT_D + (size_t)att_chunk_max(a.max_seq, n_splits) * 4;
+template <int RING>
+static hipError_t launch_attn_decode_split_ring(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_decode_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)attn_decode_split_kernel<RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     AttnRest rest{a.out, a.rope_table, a.pos, a.rope_theta};
@@ -979,10 +989,25 @@ hipError_t launch_attn_decode_split(const AttnArgs& a, int batch, int n_splits, 
 #endif
     AttnSplit sp{(float*)ws, (int*)tickets, n_splits};
     const bool cur = a.rope_cur != nullptr;
-    hipLaunchKernelGGL(attn_decode_split_kernel, dim3(a.n_heads, batch, n_splits), dim3(ATT_THREADS), lds, st, a.kcache, a.vcache,
+    hipLaunchKernelGGL(attn_decode_split_kernel<RING>, dim3(a.n_heads, batch, n_splits), dim3(ATT_THREADS), lds, st, a.kcache, a.vcache,
                        cur ? a.rope_cur : (const void*)a.pos_dev, a.n_heads | (a.n_kv_heads << 8) | ((int)cur << 16), a.max_seq,
                        a.q, a.k, a.v, rest, sp);
     return hipGetLastError();
+}
+
+hipError_t launch_attn_decode_split(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, hipStream_t st) {
+    StreamDevice sd_(st);                                  // kernel attributes are per device: the stream's, not the current one
+    const size_t lds = 6 * ATT_D + (size_t)att_chunk_max(a.max_seq, n_splits) * 4;
+    // row loads in flight per thread (the kernel's RING): while the launch is at most one workgroup per CU all of K at once and V behind it as the scores
+    // are taken (RING = ATT_PF), four rows beyond (256 CUs on MI355X); measured 8 / 9 / 12 and 2 / 3 / 4 / 6 / 8: profiles/r05_attn_decode_long.txt
+#ifndef AMQ_ATT_RING_WIDE
+#define AMQ_ATT_RING_WIDE 12
+#endif
+#ifndef AMQ_ATT_RING_NARROW
+#define AMQ_ATT_RING_NARROW 4
+#endif
+    if ((long)a.n_heads * batch * n_splits <= 256) return launch_attn_decode_split_ring<AMQ_ATT_RING_WIDE>(a, batch, n_splits, ws, tickets, lds, st);
+    return launch_attn_decode_split_ring<AMQ_ATT_RING_NARROW>(a, batch, n_splits, ws, tickets, lds, st);
 }
 
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st) {

@@ -860,8 +860,8 @@ ATTN_CUS = 256             # workgroups per round of the chip (MI355X: 256 CUs)
 
 def attn_decode_splits(max_seq, n_heads=32, batch=1):
     """workgroups per head the auto policy gives a cache of ``max_seq`` rows (1: the single-workgroup kernel): about ATTN_CHUNK keys each, and --
-    where the heads divide the CU count -- a whole number of rounds of the chip (7B at 2048 keys: 8 x 32 = 256 workgroups of 264 keys ran the launch
-    in 14.0 us, 6 x 32 of 352 keys in 14.1, 16 x 32 in 14.7; at 4000 keys 16 x 32 in 22.1 against 11 x 32 in 24.7: profiles/r05_attn_decode_long.txt)"""
+    where the heads divide the CU count -- a whole number of rounds of the chip (7B at 2048 keys: 8 x 32 = 256 workgroups of 264 keys run the launch
+    in 11.9 us, 6 x 32 of 352 keys in 11.8; at 4000 keys 16 x 32 in 18.1 against 11 x 32 in 19.6: profiles/r05_attn_decode_long.txt)"""
     if max_seq <= ATTN_SPLIT_FROM:
         return 1
     s = max(1, round(max_seq / ATTN_CHUNK))
