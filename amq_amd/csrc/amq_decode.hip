@@ -328,12 +328,19 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // t = group + 32 i and a lane the 16-byte slice [8 lane, 8 lane + 8) of each 256-byte row, so every wave-load is four
 // whole contiguous rows (the first version gave each thread one key row: 64 different cache lines per load
 // instruction).  A single CU pulls its head's K/V rows at what it keeps in flight, so ALL rows of contexts up to
-// 32 * ATT_PF = 384 tokens are requested before anything is computed (the first 128 keys even before the position
+// 32 * ATT_PF = 384 tokens are requested before anything is computed (the first 32 * ATT_SPEC keys even before the position
 // has arrived); longer contexts continue with a plain loop.  The leading arguments are kernarg-preloaded (Makefile).
 constexpr int ATT_THREADS = 512;
 constexpr int ATT_GROUPS = ATT_THREADS / 16;
 constexpr int ATT_PF = 12;             // rows of K and of V per group held in registers
-constexpr int ATT_SPEC = 8;            // of those, K rows requested before the position is known (256 keys)
+// of those, K rows requested before the position is known.  Eight (256 keys) until round 5: at the benchmark's 64 .. 330 cached keys most of them were rows the
+// context does not have yet -- real reads all the same, 17 MB per launch when 8 sequences decode together.  Two: 8 sequences 1.683 -> 1.664 ms per step,
+// 4 sequences 1.505 -> 1.485, one sequence 832 -> 834 - 837 tokens/s (inside the run-to-run spread); 0 / 1 / 3 / 4 measured beside it
+// (profiles/r05_attn_decode_long.txt, last section)
+#ifndef AMQ_ATT_SPEC
+#define AMQ_ATT_SPEC 2
+#endif
+constexpr int ATT_SPEC = AMQ_ATT_SPEC;
 
 struct AttnRest {
     void* out; const void* rope_table; int pos; float rope_theta;
