@@ -434,14 +434,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
             krow[i] = *(const h8*)(kc + (size_t)t * ATT_D + 8 * l16);
         }
     }
-#pragma unroll
-    for (int i = 0; i < ATT_PF; ++i) {
+    auto load_v = [&](int i) {
         if (ATT_GROUPS * i < pos) {
             int t = grp + ATT_GROUPS * i;
             t = t < last_old ? t : last_old;
             vrow[i] = *(const h8*)(vc + (size_t)t * ATT_D + 8 * l16);
         }
-    }
+    };
+    // (V's rows are requested as the scores are taken, not here behind K's: with a workgroup per CU -- 8 sequences x 32 heads -- everything at once costs
+    //  more than it hides: 8 sequences 1.668 -> 1.640 ms per step, 4 sequences 1.480 -> 1.465, one sequence unchanged; profiles/r05_attn_decode_long.txt)
     auto rotate_and_append = [&](_Float16 c16, _Float16 s16) {
         const int i = tid;                          // rotary pair (i, i + 64)
         qs[i] = q0 * c16 + (-q1) * s16;             // q*cos + rotate_half(q)*sin  (fp16 ops, HF apply_rotary_pos_emb)
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(void* p_kc, vo
     };
 #pragma unroll
     for (int i = 0; i < ATT_PF; ++i) {
+        load_v(i);                                   // V's row i leaves as score i is taken (the split kernel's order at one workgroup per CU)
         if (ATT_GROUPS * i < T) {                   // wave-uniform: iterations wholly past the context never touch their row
             const int t = grp + ATT_GROUPS * i;
             const float sv = score(t == pos ? knew : krow[i]);
