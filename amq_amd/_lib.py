@@ -21,7 +21,7 @@ PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
 MATH_DEFAULT, MATH_LINEAR, MATH_GROUPSCALE, MATH_EXACT = 0, 1, 2, 3
 FEWROW_AUTO, FEWROW_TILE, FEWROW_STREAM = 0, 1, 2      # kernel form of the grouped few-row launch (amq_gemm_xfrag_grouped_form_f16)
-ABI_VERSION = 510            # include/amq_hip.h AMQ_VERSION these bindings mirror (checked at load)
+ABI_VERSION = 520            # include/amq_hip.h AMQ_VERSION these bindings mirror (checked at load)
 GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, GEMM_WS, GEMM_DEQ = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -80,6 +80,7 @@ SIGNATURES = {
     "amq_gemv_f16w": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "amq_attn_decode_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "amq_rope_table_f16": (_i, [_vp, _i, _f, _vp]),
+    "amq_rope_table_freqs_f16": (_i, [_vp, _i, _vp, _f, _vp]),
     "amq_decode_tail_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "amq_attn_decode_cur_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amq_gemm_res_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -183,6 +184,44 @@ def use_library(path):
         raise AmqError("use_library() must be called before the library is first loaded")
     LIB_PATH = os.path.abspath(path)
     AB_LIB_PATH = LIB_PATH          # (a variant that carries the A/B routes -- `make abvariant` -- serves them too; others fail loudly on load_ab)
+
+
+SAFE_LIB_PATH = os.path.join(_HERE, "libamq_hip_safe.so")      # the twin built with -DAMQ_WAITS_CONSERVATIVE (`make -C amq_amd/csrc safe`)
+
+
+def open_twin(path=None):
+    """tests/ and tools/ only: a SECOND build of the library (default: the conservative-waits twin) opened beside the product one, with the same
+    signatures.  Nothing in the product path calls this; route the ops wrappers through it for a block with :func:`routed_to`."""
+    path = SAFE_LIB_PATH if path is None else os.path.abspath(path)
+    if not os.path.exists(path):
+        raise AmqError(f"{path} not found: `make -C amq_amd/csrc safe` (or __graft_entry__.build())")
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.amq_version() != ABI_VERSION:
+        raise AmqError(f"{path} reports ABI version {lib.amq_version()}, expected {ABI_VERSION}")
+    return lib
+
+
+class routed_to:
+    """tests/ and tools/ only: ``with routed_to(twin): ops.gemm(...)`` -- every ``load()`` inside the block hands out ``twin`` (the ctypes
+    wrappers of ops.py fetch the library per call; the C++ fast path of the modules, _amq_ext, is not affected)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        global _lib
+        load()                      # (the product library is loaded first, as in any product run)
+        self.prev, _lib = _lib, self.lib
+        return self.lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
 
 
 def check(rc):

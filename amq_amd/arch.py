@@ -20,9 +20,11 @@ LINEARS = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_att
            "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"]
 
 
-def _cfg(n_block, hidden, inter, heads, kv_heads, numel, vocab=32000):
+def _cfg(n_block, hidden, inter, heads, kv_heads, numel, vocab=32000, **extra):
+    """``extra``: rms_norm_eps, rope_theta, rope_scaling (HF's dict, "llama3"), qkv_bias (Qwen2: q / k / v projections carry a bias)"""
     kv = hidden * kv_heads // heads
     return {
+        **extra,
         "n_block": n_block, "hidden_size": hidden, "intermediate_size": inter, "num_heads": heads,
         "num_kv_heads": kv_heads, "head_dim": hidden // heads, "vocab_size": vocab, "model_numel": numel,
         "linear": list(LINEARS),
@@ -34,11 +36,23 @@ def _cfg(n_block, hidden, inter, heads, kv_heads, numel, vocab=32000):
     }
 
 
-# shapes / model_numel as in amq/configs/llama.json:2-79
+_LLAMA3_SCALING = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}
+
+# shapes / model_numel as in amq/configs/llama.json:2-79 (Llama 2), :82+ (Llama 3.x), mistral.json, qwen2.json -- the families the reference lists
+# (README.md:90-92); rope / norm / bias settings as in the models' published config.json (they do not change any linear's shape)
 MODEL_CONFIGS = {
     "Llama-2-7b-hf": _cfg(32, 4096, 11008, 32, 32, 6476005376),
     "Llama-2-13b-hf": _cfg(40, 5120, 13824, 40, 40, 12687769600),
     "Llama-2-70b-hf": _cfg(80, 8192, 28672, 64, 8, 68451041280),
+    "Meta-Llama-3-8B": _cfg(32, 4096, 14336, 32, 8, 6979321856, vocab=128256, rope_theta=500000.0),
+    "Llama-3.1-8B": _cfg(32, 4096, 14336, 32, 8, 6979321856, vocab=128256, rope_theta=500000.0, rope_scaling=_LLAMA3_SCALING),
+    "Llama-3.1-8B-Instruct": _cfg(32, 4096, 14336, 32, 8, 6979321856, vocab=128256, rope_theta=500000.0, rope_scaling=_LLAMA3_SCALING),
+    "Llama-3.1-70B": _cfg(80, 8192, 28672, 64, 8, 68451041280, vocab=128256, rope_theta=500000.0, rope_scaling=_LLAMA3_SCALING),
+    "Mistral-7B-v0.3": _cfg(32, 4096, 14336, 32, 8, 6979321856, vocab=32768, rope_theta=1000000.0),
+    "Qwen2.5-7B": _cfg(28, 3584, 18944, 28, 4, 6525288448, vocab=152064, rope_theta=1000000.0, rms_norm_eps=1e-6, qkv_bias=True),
+    "Qwen2.5-14B": _cfg(48, 5120, 13824, 40, 8, 13212057600, vocab=152064, rope_theta=1000000.0, rms_norm_eps=1e-6, qkv_bias=True),
+    "Qwen2.5-32B": _cfg(64, 5120, 27648, 40, 8, 31205621760, vocab=152064, rope_theta=1000000.0, rms_norm_eps=1e-6, qkv_bias=True),
+    "Qwen2.5-72B": _cfg(80, 8192, 29568, 64, 8, 70212648960, vocab=152064, rope_theta=1000000.0, rms_norm_eps=1e-6, qkv_bias=True),
     # small shapes for tests / smoke (not in the reference)
     "tiny-llama-test": _cfg(2, 256, 512, 4, 4, 2 * (4 * 256 * 256 + 3 * 256 * 512), vocab=1000),
 }
@@ -46,6 +60,31 @@ MODEL_CONFIGS = {
 # Llama-2-7B layers whose measured sensitivity exceeds 2x the median are pinned to 4 bit by the
 # search (amq/search/optimizer.py:53-55; list derived in SURVEY.md 3.4 from amq/sensitivity/*.json)
 PINNED_7B = ["0.self_attn.v_proj", "1.self_attn.v_proj", "1.mlp.down_proj", "31.mlp.down_proj"]
+
+
+def rope_inv_freq(config):
+    """fp32 inverse frequencies [64] and attention scaling of a config's rotary embedding, as transformers resolves them
+    (modeling_rope_utils: ``_compute_default_rope_parameters`` / ``_compute_llama3_parameters``); None for the plain rope_theta form."""
+    import torch
+    rs = config.get("rope_scaling") or None
+    if not rs or rs.get("rope_type", rs.get("type", "default")) == "default":
+        return None, 1.0
+    kind = rs.get("rope_type", rs.get("type"))
+    theta = float(config.get("rope_theta", 10000.0))
+    dim = int(config.get("head_dim", 128))
+    inv = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.int64).to(torch.float32) / dim))
+    if kind == "linear":
+        return inv / float(rs["factor"]), 1.0
+    if kind != "llama3":
+        raise ValueError(f"rope_scaling type '{kind}' is not served (default, linear, llama3)")
+    factor, lo, hi, old = float(rs["factor"]), float(rs["low_freq_factor"]), float(rs["high_freq_factor"]), float(rs["original_max_position_embeddings"])
+    low_wavelen, high_wavelen = old / lo, old / hi
+    wavelen = 2 * math.pi / inv
+    out = torch.where(wavelen > low_wavelen, inv / factor, inv)
+    smooth = (old / wavelen - lo) / (hi - lo)
+    smoothed = (1 - smooth) * out / factor + smooth * out
+    medium = ~(wavelen < high_wavelen) & ~(wavelen > low_wavelen)
+    return torch.where(medium, smoothed, out), 1.0
 
 
 def get_bits_usage(arch, config, group_size=128):

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
     };
     // this wave's DMA has landed, then every wave's
     auto tile_ready = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AMQ_WAIT_VM("prefill.kv", 0, "");
         __syncthreads();
     };
 

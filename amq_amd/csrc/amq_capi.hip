@@ -148,8 +148,10 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     if (o.depth != 0 && o.depth != 2 && o.depth != 4) return fail(AMQ_EINVAL, "opts.depth must be 0, 2 or 4");
     if (o.rpt < 0 || o.rpt > 64) return fail(AMQ_EINVAL, "opts.rpt (row-tiles per workgroup) must be 0..64");
     const bool plain_form = !o.dot && o.math != AMQ_MATH_LINEAR && o.depth != 4 && amq::meta_pairs(group) == 1 && o.waves != 4;
-    if (M > amq::GEMV_MAX_M || amq::gemv_min_lds_bytes(M, K, plain_form && o.waves == 0 && o.rpt == 0, prologue == AMQ_PRO_RMSNORM) > LDS_LIMIT)
-        return fail(AMQ_ESHAPE, "M=%d rows of K=%d do not fit LDS for the GEMV path; use amq_gemm_f16", M, K);
+    // (rows staged in two K phases -- 7 - 8 rows of K = 11008 -- need dense x rows and no full-row statistic: launch_gemv makes the same decision)
+    const bool whole_rows = prologue == AMQ_PRO_RMSNORM || (x_stride != 0 && x_stride != K);
+    if (M > amq::GEMV_MAX_M || amq::gemv_min_lds_bytes(M, K, plain_form && o.waves == 0 && o.rpt == 0, whole_rows) > LDS_LIMIT)
+        return fail(AMQ_ESHAPE, "M=%d rows of K=%d%s do not fit LDS for the GEMV path; use amq_gemm_f16", M, K, (x_stride != 0 && x_stride != K) ? " (strided x)" : "");
     amq::GemvArgs a{};
     for (int i = 0; i < nseg; ++i) {
         const amq_segment& s = segs[i];
@@ -789,6 +791,11 @@ int amq_decode_tail_batch_f16(const void* logits, int vocab, const void* embed, 
 int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream) {
     if (!table || max_seq < 1) return fail(AMQ_EINVAL, "bad rope table request");
     return check_hip(amq::launch_rope_table(table, max_seq, rope_theta, (hipStream_t)stream), "rope_table");
+}
+
+int amq_rope_table_freqs_f16(void* table, int max_seq, const float* inv_freq, float scale, void* stream) {
+    if (!table || !inv_freq || max_seq < 1) return fail(AMQ_EINVAL, "bad rope table request");
+    return check_hip(amq::launch_rope_table_freqs(table, max_seq, inv_freq, scale, (hipStream_t)stream), "rope_table_freqs");
 }
 
 }  // extern "C"

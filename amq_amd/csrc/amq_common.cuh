@@ -52,6 +52,29 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 enum { MODE_HQQ = 0, MODE_FMA = 1, MODE_FMA1 = 2 };
 enum { TILE_N = 16, TILE_K = 128, GROUP = 128 };
 
+// ---- hand-counted waits --------------------------------------------------------------------------------------------------------------
+// LDS-DMA transfers (global_load_lds / buffer_load ... lds, issued from inline asm) are invisible to the compiler's wait insertion, and the
+// software pipelines built on them leave a COUNTED number of younger transfers in flight.  Every s_waitcnt this build writes itself goes
+// through these helpers (tests/test_waits_cpu.py refuses a bare one anywhere in csrc/):
+//   * the site's name and what its count is derived from travel as an assembler comment into the device assembly the Makefile keeps under
+//     csrc/asm/; tools/check_waits.py walks the control-flow graph of every kernel there and checks, per site, that the number of
+//     vector-memory instructions the compiler actually emitted between the named points is the number the source's count assumes
+//     (`from=<site>:<ops>` pairs; `entry` = kernel start).  A load the compiler merged, split or sank shows as a CPU-side failure.
+//   * -DAMQ_WAITS_CONSERVATIVE (make safe -> libamq_hip_safe.so) turns every one of them into a full drain: the twin library the GPU suite
+//     compares the product with bit for bit (tests/test_gpu_waits.py).
+// AMQ_WAIT_VM(name, n, "from=<site>:%1 ...", "n"(ops) ...)   s_waitcnt vmcnt(n); n and the spec's counts are compile-time integers (asm operands)
+// AMQ_WAIT_VM_LGKM0(...)                                      ... and lgkmcnt(0)
+// AMQ_MARK(name)                                              a comment on an EXISTING asm statement (no instruction of its own) for `from=`
+#ifdef AMQ_WAITS_CONSERVATIVE
+#define AMQ_WAIT_VM(name, n, spec, ...) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0) ; AMQ_WAIT id=" name " conservative" ::: "memory")
+#define AMQ_WAIT_VM_LGKM0(name, n, spec, ...) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0) ; AMQ_WAIT id=" name " conservative" ::: "memory")
+#else
+#define AMQ_WAIT_VM(name, n, spec, ...) asm volatile("s_waitcnt vmcnt(%0) ; AMQ_WAIT id=" name " n=%0 " spec :: "n"(n), ##__VA_ARGS__ : "memory")
+#define AMQ_WAIT_VM_LGKM0(name, n, spec, ...) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0) ; AMQ_WAIT id=" name " n=%0 " spec :: "n"(n), ##__VA_ARGS__ : "memory")
+#endif
+#define AMQ_WAIT_LGKM0(name) asm volatile("s_waitcnt lgkmcnt(0) ; AMQ_WAIT id=" name " lgkm" ::: "memory")
+#define AMQ_MARK(name) " ; AMQ_MARK id=" name
+
 __device__ __forceinline__ h2 as_h2(uint32_t u) { return __builtin_bit_cast(h2, u); }
 __device__ __forceinline__ uint32_t as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ h2 bcast(_Float16 v) { return (h2){v, v}; }

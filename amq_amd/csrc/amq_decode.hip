@@ -784,7 +784,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(void* p_
     // workgroup barrier, and only then does ONE lane take the ticket.  A workgroup-scope fence emits no s_waitcnt on
     // gfx950 -- the previous form let wave 0's ticket overtake the stores of waves 1 and 2 -- and the
     // wait is inline asm so that the compiler's wait-count pass cannot drop it.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AMQ_WAIT_VM("attn.split.partials", 0, "");
     __syncthreads();
     if (tid == 0) {
         int* const ticket = sp.tickets + (size_t)b * n_heads + h;
@@ -868,6 +868,23 @@ __global__ void rope_table_kernel(_Float16* tab, int max_seq, float theta) {
 
 hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st) {
     hipLaunchKernelGGL(rope_table_kernel, dim3((max_seq * 64 + 255) / 256), dim3(256), 0, st, (_Float16*)tab, max_seq, theta);
+    return hipGetLastError();
+}
+
+// The same table from explicit inverse frequencies (fp32 [64]: what HF's rotary embedding holds in `inv_freq` after any static rope_scaling --
+// Llama-3.1's "llama3" wavelength-dependent factors, "linear", ...) and its attention_scaling: fp16(cosf(pos * inv_freq[i]) * scale), the
+// expression of LlamaRotaryEmbedding.forward (fp32 product, fp32 cos / sin, one rounding to fp16).
+__global__ void rope_table_freqs_kernel(_Float16* tab, int max_seq, const float* inv_freq, float scale) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= max_seq * 64) return;
+    float sn, cs;
+    sincosf((float)(idx >> 6) * inv_freq[idx & 63], &sn, &cs);
+    tab[2 * idx] = (_Float16)(cs * scale);
+    tab[2 * idx + 1] = (_Float16)(sn * scale);
+}
+
+hipError_t launch_rope_table_freqs(void* tab, int max_seq, const void* inv_freq, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(rope_table_freqs_kernel, dim3((max_seq * 64 + 255) / 256), dim3(256), 0, st, (_Float16*)tab, max_seq, (const float*)inv_freq, scale);
     return hipGetLastError();
 }
 

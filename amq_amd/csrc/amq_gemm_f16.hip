@@ -271,10 +271,11 @@ __device__ __forceinline__ void gemm_pp_body(const GemmF16Args& a, int ntm, int 
         if constexpr (P == 0) { read_b(set, U_BF, b0f); read_b(set, U_BS, b1f); read_a(set, U_AF); issue(kt + 1, set ^ 1, U_BS, 2); issue(kt + 1, set ^ 1, U_AS); }
         if constexpr (P == 1) { read_a(set, U_AS); issue(kt + 2, set, U_AF); issue(kt + 2, set, U_BF); issue(kt + 2, set, U_BS, 1); }
         PP_STAMP(1);
-        if constexpr (P == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // X's three and Y's five youngest stay in flight: AS(kt) has landed
-        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                       // Y's five and AS(kt + 1): AF, BF, BS(kt + 1) have landed
+        // (check_waits: a P = 0 phase issues exactly 3 pieces since the previous phase's wait, a P = 1 phase exactly 5 -- what 8 = 3 + 5 and 7 = 5 + 2 count)
+        if constexpr (P == 0) AMQ_WAIT_VM("f16pp.x", 8, "from=f16pp.y:3 from=f16pp.pro:3 from=f16pp.drain:3");   // X's three and Y's five youngest stay in flight: AS(kt) has landed
+        else AMQ_WAIT_VM("f16pp.y", 7, "from=f16pp.x:5");                           // Y's five and AS(kt + 1): AF, BF, BS(kt + 1) have landed
         PP_STAMP(2);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this phase's operands are in registers; the slots they came from may be refilled
+        AMQ_WAIT_LGKM0("f16pp.operands");                               // this phase's operands are in registers; the slots they came from may be refilled
         PP_STAMP(3);
         PP_TRACE_READY();
         __builtin_amdgcn_sched_barrier(0);
@@ -301,7 +302,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmF16Args& a, int ntm, int 
     // ---- prologue (once per workgroup): K-tile 0 complete, AF / BF / BS of K-tile 1 -- the seven units of lead the loop keeps
     issue(0, 0, U_AF); issue(0, 0, U_BF); issue(0, 0, U_BS); issue(0, 0, U_AS);
     issue(1, 1, U_AF); issue(1, 1, U_BF); issue(1, 1, U_BS, 1);
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                    // K-tile 0 has landed (this wave's pieces)
+    AMQ_WAIT_VM("f16pp.pro", 5, "from=entry:13");                       // K-tile 0 has landed (this wave's pieces: the 8 oldest of 13)
     PP_BARRIER();                                                       // ... everybody's
     if (wr == 1) PP_BARRIER();                                          // the second wave of every SIMD runs one barrier behind
 
@@ -394,11 +395,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmF16Args& a, int ntm, int 
             }
         }
         }
+        // the epilogue's loads and stores sit on the same counter as the DMA pieces (and stores may return out of order with loads):
+        // drain it, so that the loop's vmcnt(8) counts pieces only (the next tile's units in flight were issued >= 2 phases ago).
+        // (In front of the exit test, not behind it: every path back to the loop then passes this wait in the control-flow graph
+        //  tools/check_waits.py walks -- behind a `break` the structurizer's flag blocks leave a static path around it.)
+        AMQ_WAIT_VM("f16pp.drain", 0, "");
         if (nb == tb) break;
         tb = nb; m0 = nm0; n0 = nn0;
-        // the epilogue's loads and stores sit on the same counter as the DMA pieces (and stores may return out of order with loads):
-        // drain it, so that the loop's vmcnt(8) counts pieces only (the next tile's units in flight were issued >= 2 phases ago)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #ifdef AMQ_PP_TRACE
     __syncthreads();
@@ -414,7 +417,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmF16Args& a, int ntm, int 
     }
 #endif
     if (wr == 0) PP_BARRIER();                                          // barrier counts of the two wave groups match again
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the trailing re-reads must not land after the workgroup has gone
+    AMQ_WAIT_VM("f16pp.exit", 0, "");                                   // the trailing re-reads must not land after the workgroup has gone
 }
 
 __global__ __launch_bounds__(PP_THREADS) void gemm_f16_pp_kernel(GemmF16Args a, int ntm, int ntn) { gemm_pp_body<false>(a, ntm, ntn); }

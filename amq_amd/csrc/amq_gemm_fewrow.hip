@@ -126,7 +126,7 @@ __device__ __forceinline__ void fewrow_stream_body(const GemmArgs& a, int bx, un
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
 #ifdef AMQ_FS_STAMP
-            if (i == 0 && d == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FS_STAMP(a, 8 + wave); }      // everything primed has landed
+            if (i == 0 && d == 0) { AMQ_WAIT_VM("fewrow.primed", 0, ""); FS_STAMP(a, 8 + wave); }      // everything primed has landed
 #endif
             const int kt_next = wave + NWV * (i + d + TA);
             const int s0 = (XS == 8 ? d * 4 : 0);  // this tile's first x slot (the loop is unrolled over d: compile-time)

@@ -62,12 +62,11 @@ __device__ __forceinline__ void rg_glds4(const void* sbase, unsigned voff, unsig
 #else
 #define RG_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
-// all but the youngest x half-tile (NXI DMA instructions of this wave) have landed
-#define RG_WAIT_X()                                                              \
-    do {                                                                         \
-        if constexpr (NXI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                    \
-    } while (0)
+// all but the youngest x half-tile (NXI DMA instructions of this wave) have landed.  (check_waits: the first half of a group issues exactly
+// NWI + 1 + NXI pieces -- packed W and meta of the next group FIRST, then the x half-tile -- the second half exactly NXI: the NXI youngest
+// operations at either wait are one x half-tile's)
+#define RG_WAIT_X0() AMQ_WAIT_VM("ring.x0", NXI, "from=ring.x1:%1 from=ring.pro:0", "n"(NXI))
+#define RG_WAIT_X1() AMQ_WAIT_VM("ring.x1", NXI, "from=ring.x0:%1", "n"(NWI + 1 + NXI))
 template <int BITS, int MODE, int BM>
 __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int ntm, int ntn) {
     constexpr int RG_BM = BM;
@@ -314,8 +313,7 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
     issue_a(0, 0);
     issue_a(1, 1);
     WHalf w0, w1;
-    if constexpr (NXI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // W(0) landed (two x half-tiles may be in flight)
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    AMQ_WAIT_VM("ring.pro", 2 * NXI, "from=entry:%1", "n"(NWI + 1 + 2 * NXI));      // W(0) landed (two x half-tiles may be in flight)
     {
         WPacked pk;
         read_packed(0, pk);
@@ -337,18 +335,18 @@ __global__ __launch_bounds__(RG_THREADS) void gemm_ring_kernel(GemmArgs a, int n
         // clobber) must all be issued BEFORE this wave arrives at the barrier -- an MFMA issues only once its ds_read
         // operands have returned, so "every wave has passed compute_half" makes the vacated slot safe to refill (WAR).
         __builtin_amdgcn_sched_barrier(0);
-        RG_WAIT_X();
+        RG_WAIT_X0();
         RG_BARRIER();                                      // every wave's pieces landed; every wave is done reading half-tile 2g - 1
         asm volatile("" ::: "memory");                     // (compiler fence: no DMA issue / LDS read may move above the barrier)
         compute_half(std::integral_constant<int, 0>{}, sa, w0, g & 1, w1, 2 * g + 2, s2, g + 1, (g + 1) & 1);
         // half-tile 2g + 1
-        RG_WAIT_X();
+        RG_WAIT_X1();
         RG_BARRIER();
         asm volatile("" ::: "memory");
         compute_half(std::integral_constant<int, 1>{}, s1, w1, (g + 1) & 1, w0, 2 * g + 3, sa, 0, 0);
         sa = s2;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing (clamped) DMAs must not land after the workgroup has gone
+    AMQ_WAIT_VM("ring.exit", 0, "");                       // the trailing (clamped) DMAs must not land after the workgroup has gone
 
     // ---- epilogue: acc[rb][nb][i] = y[m0 + 16 rb + r][n0 + 32 wave + 16 nb + 4 o + i]
     const _Float16* bias = (const _Float16*)a.bias;

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(GemmArgs a, int ntm
             const unsigned char* const qsrc = qbase + (size_t)gc * TB;
             const unsigned adst = lds_a + xslot * WS_ABYTES, pdst = lds_p + ((g + 1) & 1) * WS_PSLOT;
             if constexpr (S == 1) {
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // packed W(g + 1) landed (x(2g + 2) may be in flight)
+                AMQ_WAIT_VM("ws.w", NXI, "from=ws.p0:0");                    // packed W(g + 1) landed (x(2g + 2), the half before's NXI youngest pieces, may be in flight)
                 read_packed((g + 1) & 1);
             }
             h8 f[2][2];
@@ -246,13 +246,13 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(GemmArgs a, int ntm
                 __builtin_amdgcn_sched_barrier(0);
             });
 #ifdef AMQ_WS_CYCLES
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            AMQ_WAIT_LGKM0("ws.cycles");
             const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
 #endif
             // x(h - 1) landed: all but this half-tile's own pieces; the fragment stores are in the LDS
-            if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else if constexpr (NP == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
+            // (check_waits: this half-tile issued exactly NP pieces since the previous half's wait)
+            if constexpr (S == 0) AMQ_WAIT_VM_LGKM0("ws.p0", NP, "from=ws.p1:%0 from=ws.pro2:%0");
+            else AMQ_WAIT_VM_LGKM0("ws.p1", NP, "from=ws.p0:%0");
 #ifdef AMQ_WS_CYCLES
             const unsigned long long tc_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -270,10 +270,10 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(GemmArgs a, int ntm
         issue_w(0, 0);
         issue_a(0, 0);
         issue_a(1, 1);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                    // W(0) landed
+        AMQ_WAIT_VM("ws.pro", 2 * NXI, "from=entry:%1", "n"(NWI + 1 + 2 * NXI));   // W(0) landed
         read_packed(0);
         unpack_store(std::integral_constant<int, 0>{}, 0);
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");          // x(0) landed, W16(0) written
+        AMQ_WAIT_VM_LGKM0("ws.pro2", NXI, "from=ws.pro:0");                  // x(0) landed, W16(0) written
         __builtin_amdgcn_s_barrier();                                         // B_0
         WS_FENCE();
         int sa = 0;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(GemmArgs a, int ntm
             produce(std::integral_constant<int, 1>{}, g, sa);                // ... B_(2g + 2)
             sa = s2;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the trailing (clamped) DMAs must not outlive the workgroup
+        AMQ_WAIT_VM("ws.exit", 0, "");                                       // the trailing (clamped) DMAs must not outlive the workgroup
 #ifdef AMQ_WS_CYCLES
         if (p == 0 && lane == 0 && blockIdx.x < 8192) { ws_pcycles[blockIdx.x][0] = pc_[0]; ws_pcycles[blockIdx.x][1] = pc_[1]; ws_pcycles[blockIdx.x][2] = pc_[2]; }
 #endif
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(GemmArgs a, int ntm
             if constexpr (rb == 6) {
                 // every operand of this half-tile has been received (the last read was issued at step 4): arrive at B_(h+1), then
                 // request the next half-tile's W operands and first x operands, two row blocks (16 MFMAs) before their use
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                AMQ_WAIT_LGKM0("ws.consumer");
 #ifndef AMQ_WS_ABL_NOBAR           /* timing-only ablation: consumers do not wait for the producers */
                 __builtin_amdgcn_s_barrier();
 #endif

@@ -83,7 +83,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     // A/B options and groups of 64 / 32 keep the generic staging (RS = 256), 16 waves once three 8-wave workgroups no longer fit.
     bool rs128 = false, rs64 = false;
     const bool plain = !(a.flags & (GEMV_FLAG_DOT | GEMV_FLAG_LINEAR)) && a.force_depth != 4 && gp == 1;
-    const bool ph2 = !a.force_waves && a.force_rpt <= 0 && gemv_rows_phased(a.M, a.K, plain, a.prologue == PRO_RMSNORM);
+    const bool ph2 = !a.force_waves && a.force_rpt <= 0 && gemv_rows_phased(a.M, a.K, plain, a.prologue == PRO_RMSNORM || a.x_stride != a.K);      // (the phased kernel takes dense rows only: LDS-DMA staging)
     if (ph2) {
         rs128 = true;
         nw = 16;

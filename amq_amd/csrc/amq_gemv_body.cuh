@@ -332,7 +332,7 @@ template <int RS> struct RowsCfg { static constexpr int MRMAX = RS == 64 ? 4 : R
 // primed ring (they arrive with the first weight tiles) four rows at a time.
 // (inline asm, not __builtin_amdgcn_global_load_lds: see amq_gemm_ring.hip)
 __device__ __forceinline__ void gv_glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" AMQ_MARK("gemv.xdma") :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
 // (k0, Ks: the columns staged -- all of K, or one K phase of a launch whose rows do not fit LDS whole: gemv_body's PH)
@@ -370,7 +370,9 @@ __device__ __forceinline__ void x_finish_dma(const GemvHot& a, const XRegs& xr, 
     const int chunks = Ks >> 3;
     // everything this wave issued before the ring's NRING loads has landed: its LDS-DMA transfers (and, RMSNorm, gamma's loads, issued right behind them).
     // Inline asm: the compiler neither sees the transfers nor may it move LDS reads above this wait ("memory").
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRING) : "memory");
+    // (check_waits: on every path from the last transfer to here the wave has issued AT LEAST NRING vector-memory instructions -- the ring's 2 U
+    //  loads, plus gamma's under a fused RMSNorm: those sit between the transfers and the ring and only make the wait stricter)
+    AMQ_WAIT_VM("gemv.xrows", NRING, "from=gemv.xdma:>=%0");
     if (PRO == PRO_NONE) return;
     if (PRO == PRO_RMSNORM) {
         // all rows side by side (MR = the kernel's row bound, rows >= M predicated off by uniform branches): the rows' LDS reads, square sums and
@@ -791,7 +793,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned long long t0 = AMQ_T();
-            __builtin_amdgcn_s_waitcnt(0x0F70 | ((U - 1) * OPS_PER_TILE));      /* vmcnt((U-1)*ops) [hi bits 0], lgkm/exp untouched */
+            AMQ_WAIT_VM("gemv.stamp", (U - 1) * OPS_PER_TILE, "");               /* (stamp build only: the wait the compiler would insert itself) */
             if (first_) { AMQ_STAMP_AT(blk, 112 + wave); first_ = false; }       // realtime: first tile has arrived
             const unsigned long long t1 = AMQ_T();
             AMQ_COMPUTE(u);

@@ -85,8 +85,8 @@ constexpr int GEMV_MAX_M = 16;
 
 size_t gemv_lds_bytes(int M, int K, int copies);
 size_t gemv_lds_bytes_rows(int M, int K, int nw);                   // the 2 .. 8-row kernels
-size_t gemv_min_lds_bytes(int M, int K, bool plain, bool norm = true);   // what the C ABI checks against the LDS limit (norm: an RMSNorm prologue, which cannot stage x in K phases)
-bool gemv_rows_phased(int M, int K, bool plain, bool norm);      // the launch stages x in two K phases
+size_t gemv_min_lds_bytes(int M, int K, bool plain, bool norm = true);   // what the C ABI checks against the LDS limit (norm: an RMSNorm prologue or strided x rows, which cannot be staged in K phases)
+bool gemv_rows_phased(int M, int K, bool plain, bool norm);      // the launch stages x in two K phases (norm: as above -- callers pass `RMSNorm prologue || x_stride != K`)
 hipError_t launch_gemv(GemvArgs& a, hipStream_t st);
 
 // y[M,N] = x[M,K] . W^T for any M (MFMA, LDS-staged x tiles)
@@ -144,6 +144,7 @@ struct AttnArgs {
                               // maintained by launch_decode_tail, or null
 };
 hipError_t launch_rope_table(void* tab, int max_seq, float theta, hipStream_t st);
+hipError_t launch_rope_table_freqs(void* tab, int max_seq, const void* inv_freq, float scale, hipStream_t st);   // explicit inverse frequencies (rope_scaling)
 hipError_t launch_attn_decode(const AttnArgs& a, int batch, hipStream_t st);
 #ifndef AMQ_ATT_MIN_CHUNK
 #define AMQ_ATT_MIN_CHUNK 256

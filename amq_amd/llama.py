@@ -23,7 +23,7 @@ import math
 import torch
 
 from . import ops
-from .arch import MODEL_CONFIGS, arch_bits, uniform_arch
+from .arch import MODEL_CONFIGS, arch_bits, rope_inv_freq, uniform_arch
 from .hqq_format import HQQWeights
 
 EPS = 1e-5
@@ -31,17 +31,17 @@ ROPE_THETA = 10000.0
 
 
 class _Lin:
-    """native weights of one linear"""
-    __slots__ = ("qn", "mn", "bits", "mode", "N", "K")
+    """native weights of one linear (+ its fp16 bias: Qwen2's q / k / v projections carry one)"""
+    __slots__ = ("qn", "mn", "bits", "mode", "N", "K", "bias")
 
-    def __init__(self, qn, mn, bits, mode, N, K):
-        self.qn, self.mn, self.bits, self.mode, self.N, self.K = qn, mn, bits, mode, N, K
+    def __init__(self, qn, mn, bits, mode, N, K, bias=None):
+        self.qn, self.mn, self.bits, self.mode, self.N, self.K, self.bias = qn, mn, bits, mode, N, K, bias
 
     def seg(self, y, residual=None):
-        return dict(qn=self.qn, mn=self.mn, bits=self.bits, mode=self.mode, N=self.N, y=y, residual=residual)
+        return dict(qn=self.qn, mn=self.mn, bits=self.bits, mode=self.mode, N=self.N, y=y, residual=residual, bias=self.bias)
 
     def nbytes(self):
-        return self.qn.numel() * 4 + self.mn.numel() * 2
+        return self.qn.numel() * 4 + self.mn.numel() * 2 + (0 if self.bias is None else self.bias.numel() * 2)
 
 
 def _synthetic_linear(n, k, bits, gen, device, group=128):
@@ -74,10 +74,13 @@ class QuantLlama:
     # 755 vs 830 tokens/s (profiles/r03_qkv_attn_fused_negative.txt) -- so it is off unless a caller sets fuse_qkv_attn.
     FUSE_QKV_ATTN = False
     ENGINE_DEFAULT = False      # what engine=None means (the engine is opt-in until it beats the five-launch step: HISTORY.md 3.2b)
+    # prompt passes also leave the logits of EVERY prompt row in self.logits_rows [B, S, vocab] (HF's forward returns them all; the runner's own
+    # generate loop needs the last row only): final norm + one fp16 GEMM over the prompt rows, inside the captured prompt graph (hf_fast.py sets it)
+    all_logits = False
     fine = False                # any layer with groups of 64 / 32 (set by __init__)
 
     def __init__(self, config, arch_linear=None, device="cuda:0", max_seq=256, seed=0, synthetic=True,
-                 hqq_layers=None, dense=None, batch=1, engine=None, prebuilt=None, group=128):
+                 hqq_layers=None, dense=None, batch=1, engine=None, prebuilt=None, group=128, rope=None):
         """config: an entry of arch.MODEL_CONFIGS (or its name).
         arch_linear: {'self_attn.q_proj': [bits]*n_block, ...}; default uniform 4.
         hqq_layers: {(block, name): HQQWeights} real quantized layers (else synthetic).
@@ -85,7 +88,9 @@ class QuantLlama:
         prebuilt: {(block, name): _Lin} linears already in the native layout (from_hf: shared with the modules that own them).
         group: group size of the SYNTHETIC layers (128; 64 / 32: see ``fine``).
         batch: sequences decoded together, 1 .. 8 (same prompt length; one step = the same launches with ``batch`` rows: the
-        weights are streamed once per step for all of them).  batch = 1 is the reference's FT configuration."""
+        weights are streamed once per step for all of them).  batch = 1 is the reference's FT configuration.
+        rope: (inv_freq fp32 [64], attention_scaling) of the rotary embedding when it is not the plain ``rope_theta`` form (from_hf hands over
+        the HF module's own; otherwise derived from config["rope_scaling"]: Llama-3.1's "llama3")."""
         if isinstance(config, str):
             config = MODEL_CONFIGS[config]
         if not 1 <= int(batch) <= 8:
@@ -121,10 +126,13 @@ class QuantLlama:
                 assert h.nbits == bits and tuple(h.shape) == (n, k)
                 qn, mn = ops.repack_from_hqq(h.W_q.contiguous(), h.scale.reshape(-1).contiguous(),
                                              h.zero.reshape(-1).contiguous(), bits, n, k, group=h.group_size)
-                return _Lin(qn, mn, bits, ops.MODE_HQQ, n, k)
+                return _Lin(qn, mn, bits, ops.MODE_HQQ, n, k, None if h.bias is None else h.bias.to(dev, torch.float16).contiguous())
             if not synthetic:
                 raise ValueError("no weights given")
-            return _synthetic_linear(n, k, bits, gen, dev, group)
+            l = _synthetic_linear(n, k, bits, gen, dev, group)
+            if config.get("qkv_bias") and name in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"):
+                l.bias = (0.1 * torch.randn(n, device=dev, generator=gen)).to(torch.float16)
+            return l
 
         self.blocks = []
         for b in range(self.nb):
@@ -172,21 +180,24 @@ class QuantLlama:
         self.logits = torch.zeros(self.vocab, **f16) if B == 1 else torch.zeros(B, self.vocab, **f16)    # [vocab] | [B, vocab]
         self.token = torch.zeros(B, dtype=torch.int64, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.rope_tab = ops.rope_table(max_seq, self.theta, dev)
+        # the cos/sin table every rotating kernel reads: plain rope_theta frequencies, or the rotary embedding's own (rope_scaling)
+        self.inv_freq, self.rope_scale = rope if rope is not None else rope_inv_freq(config)
+        self.rope_tab = ops.rope_table(max_seq, self.theta, dev, inv_freq=self.inv_freq, scale=self.rope_scale)
         # step state: cos/sin row of self.pos + the position itself in one block (set_token / the step's tail keep it)
         self.rope_cur, self.pos, self.step_err = ops.new_step_state(dev)
         self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
         self.host_pos = 0          # host mirror of self.pos (decode_step refuses to run past the cache without a device sync)
+        self.has_bias = any(blk[n].bias is not None for blk in self.blocks for n in config["linear"])
         # down_proj's launch: the GEMV with the fused SiLU*mul prologue while the rows' x fits LDS whole; past that (7B: 7 - 8 rows of 11008) one
         # silu_mul launch + the GEMV without a prologue, x staged in two K phases (fusing the prologue there would make every workgroup take in gate
         # AND up -- 352 KB per CU at 8 rows: 23.9 us against 4.9 + ~11); past that too, the few-row MFMA kernel
         self._down_rows_fit = self.B <= min(ops.gemv_max_rows(self.I, plain=not self.fine), self.DOWN_FUSED_ROWS)
         self._down_rows_phased = not self._down_rows_fit and self.B <= ops.gemv_max_rows(self.I, plain=not self.fine, norm=False)
-        self.can_fuse_qkv_attn = self.B == 1 and max_seq <= ops.ATTN_SPLIT_FROM and self.H <= 8192 and not self.fine
+        self.can_fuse_qkv_attn = self.B == 1 and max_seq <= ops.ATTN_SPLIT_FROM and self.H <= 8192 and not self.fine and not self.has_bias
         self.fuse_qkv_attn = self.FUSE_QKV_ATTN and self.can_fuse_qkv_attn
         self._tickets = torch.zeros(max(self.nh, 64), dtype=torch.int32, device=dev)
-        eligible = self.B == 1 and max_seq <= self.ENGINE_MAX_SEQ and self.H == self.nh * 128 and not self.fine
+        eligible = self.B == 1 and max_seq <= self.ENGINE_MAX_SEQ and self.H == self.nh * 128 and not self.fine and not self.has_bias
         if engine and not eligible:
             raise ValueError("the decode engine needs batch 1 and max_seq <= %d" % self.ENGINE_MAX_SEQ)
         self.engine = None
@@ -198,44 +209,73 @@ class QuantLlama:
                       ln1=blk["ln1"], ln2=blk["ln2"], kc=blk["kc"], vc=blk["vc"]) for blk in self.blocks],
                 self.H, self.I, self.nh, self.nkv, max_seq, self.eps, self.x.view(-1), self.rope_cur)
 
+    # model families whose decoder is the Llama block -- RMSNorm, rotary q / k, (grouped-query) softmax attention, SiLU-gated MLP, no extra norms --
+    # and differs only in shapes, rope settings and projection biases: what the reference lists (README.md:90-92; amq/configs/{llama,mistral,qwen2}.json)
+    HF_MODEL_TYPES = ("llama", "mistral", "qwen2")
+
     @classmethod
-    def from_hf(cls, model, max_seq=256, batch=1, engine=None):
-        """The hipGraph runner over a SWAPPED HF ``LlamaForCausalLM`` -- what ``prepare_for_inference(model, backend="hip")`` (or the
-        reference's deepcopy + setattr assembly of a mixed-precision model, amq_speed_benchmark.py:231-256) leaves behind.  The
-        runner shares the modules' native weight buffers, the embedding, lm_head and norm weights (no copies); it is to the swapped
-        model what the reference's ``use_ft`` monkeypatch is to its HF model (kernel/monkeypatch/ftllama_modeling.py): the same weights
-        behind a static-cache, fused token step.  Needs fp16 weights on one GPU, head_dim 128, bias-free projections, SiLU, default RoPE."""
+    def check_hf(cls, model, max_seq=None):
+        """What ``from_hf`` needs of a swapped HF causal LM, checked without building anything: raises ValueError with the reason, returns
+        (runner config, (inv_freq, attention_scaling) or None)."""
         from .checkpoint import runner_config
-        from .quant_linear import HIPQuantLinear
         hf = model.config.to_dict()
+        mt = hf.get("model_type", "llama")
+        if mt not in cls.HF_MODEL_TYPES:
+            raise ValueError(f"from_hf: model_type '{mt}' is not one of {cls.HF_MODEL_TYPES} (a Llama-shaped decoder is required)")
+        if hf.get("hidden_act", "silu") != "silu":
+            raise ValueError("from_hf: a SiLU-gated MLP is required")
+        attn0 = model.model.layers[0].self_attn
+        if any(hasattr(attn0, n) for n in ("q_norm", "k_norm")):
+            raise ValueError("from_hf: per-head q / k norms are not part of the runner's block")
         rp = hf.get("rope_parameters") or {}
-        if (rp.get("rope_type", "default") != "default") or hf.get("rope_scaling") not in (None, {}):
-            raise ValueError("from_hf: only the default RoPE is implemented")
-        if hf.get("hidden_act", "silu") != "silu" or hf.get("attention_bias") or hf.get("mlp_bias"):
-            raise ValueError("from_hf: a SiLU-gated, bias-free Llama is required")
-        hf.setdefault("rope_theta", rp.get("rope_theta", 10000.0))
         if hf.get("rope_theta") is None:
             hf["rope_theta"] = rp.get("rope_theta", 10000.0)
+        rot = getattr(model.model, "rotary_emb", None)
+        kind = getattr(rot, "rope_type", None) or rp.get("rope_type") or (hf.get("rope_scaling") or {}).get("rope_type", "default")
+        rope = None
+        if kind != "default":
+            if kind not in ("llama3", "linear", "yarn") or rot is None or getattr(rot, "inv_freq", None) is None:
+                raise ValueError(f"from_hf: rope type '{kind}' is not served (default, linear, llama3, yarn: the static ones)")
+            rope = (rot.inv_freq.detach().to(torch.float32), float(getattr(rot, "attention_scaling", 1.0)))
+            if rope[0].numel() != 64:
+                raise ValueError("from_hf: head_dim must be 128")
+        sw = hf.get("sliding_window")
+        sliding = sw is not None and hf.get("use_sliding_window", True) is not False and \
+            (not hf.get("layer_types") or any(t == "sliding_attention" for t in hf["layer_types"]))
+        if sliding and max_seq is not None and max_seq > int(sw):
+            raise ValueError(f"from_hf: max_seq {max_seq} exceeds the model's sliding window ({sw}): the runner attends the whole cache")
         cfg = runner_config(hf)
+        return cfg, rope
+
+    @classmethod
+    def from_hf(cls, model, max_seq=256, batch=1, engine=None):
+        """The hipGraph runner over a SWAPPED HF causal LM of the Llama family (``HF_MODEL_TYPES``: Llama 2 / 3.x, Mistral, Qwen2.5) -- what
+        ``prepare_for_inference(model, backend="hip")`` (or the reference's deepcopy + setattr assembly of a mixed-precision model,
+        amq_speed_benchmark.py:231-256) leaves behind.  The runner shares the modules' native weight buffers and biases, the embedding, lm_head and
+        norm weights (no copies) and the rotary embedding's own frequencies (rope_scaling: Llama-3.1); it is to the swapped model what the
+        reference's ``use_ft`` monkeypatch is to its HF model (kernel/monkeypatch/ftllama_modeling.py): the same weights behind a static-cache,
+        fused token step.  Needs fp16 weights on one GPU, head_dim 128, SiLU."""
+        from .quant_linear import HIPQuantLinear
+        cfg, rope = cls.check_hf(model, max_seq)
         layers = model.model.layers
         pre, arch_linear = {}, {name: [] for name in cfg["linear"]}
         dev = None
+        f16 = lambda t: t.detach() if t.dtype is torch.float16 else t.detach().to(torch.float16)
         for b, layer in enumerate(layers):
             for name in cfg["linear"]:
                 parent, attr = name.split(".")
                 m = getattr(getattr(layer, parent), attr)
-                if not isinstance(m, HIPQuantLinear) or m.bias is not None or not m.qweight.is_cuda:
-                    raise ValueError(f"model.layers.{b}.{name}: expected a bias-free HIPQuantLinear on the GPU (run prepare_for_inference first)")
+                if not isinstance(m, HIPQuantLinear) or not m.qweight.is_cuda:
+                    raise ValueError(f"model.layers.{b}.{name}: expected a HIPQuantLinear on the GPU (run prepare_for_inference first)")
                 if m.is_bf16:
                     raise ValueError(f"model.layers.{b}.{name}: a bfloat16 module -- the decode runner is fp16 (the reference's kernels are, ft.py:62); "
                                      "bf16 models run through the modules' own forward")
                 dev = dev or m.qweight.device
-                pre[(b, name)] = _Lin(m.qweight, m.meta, m.bits, m.mode, m.outfeatures, m.infeatures)
+                pre[(b, name)] = _Lin(m.qweight, m.meta, m.bits, m.mode, m.outfeatures, m.infeatures, None if m.bias is None else f16(m.bias))
                 arch_linear[name].append(m.bits)
-        f16 = lambda t: t.detach() if t.dtype is torch.float16 else t.detach().to(torch.float16)
         dense = {"embed": f16(model.model.embed_tokens.weight), "lm_head": f16(model.lm_head.weight), "norm": f16(model.model.norm.weight),
                  "ln1": [f16(l.input_layernorm.weight) for l in layers], "ln2": [f16(l.post_attention_layernorm.weight) for l in layers]}
-        return cls(cfg, arch_linear, device=dev, max_seq=max_seq, dense=dense, batch=batch, engine=engine, prebuilt=pre, synthetic=False)
+        return cls(cfg, arch_linear, device=dev, max_seq=max_seq, dense=dense, batch=batch, engine=engine, prebuilt=pre, synthetic=False, rope=rope)
 
     # ----------------------------------------------------------------- sizes
     def linear_bytes_per_token(self):
@@ -282,7 +322,7 @@ class QuantLlama:
                 ops.gemv_grouped(ops.silu_mul(self.gate, self.up, out=self.gate), [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I)
             else:       # batch x intermediate size past the GEMV kernel's LDS stage: few-row MFMA kernel
                 d = blk["mlp.down_proj"]
-                ops.gemm(ops.silu_mul(self.gate, self.up, out=self.gate), d.qn, d.mn, d.bits, d.mode, d.N, d.K, residual=self.x, out=self.x)
+                ops.gemm(ops.silu_mul(self.gate, self.up, out=self.gate), d.qn, d.mn, d.bits, d.mode, d.N, d.K, bias=d.bias, residual=self.x, out=self.x)
         ops.gemv_f16w(self.x.reshape(-1) if self.B == 1 else self.x, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         # argmax, pos += 1, x = embed[token], rope_cur = cos/sin row of the new position (per sequence; the position is shared)
         ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
@@ -357,10 +397,11 @@ class QuantLlama:
     # ---------------------------------------------------------------- prefill
     def _rope(self, t, positions):
         # HF apply_rotary_pos_emb: cos/sin in fp32 -> fp16; rotate_half
-        inv = 1.0 / (self.theta ** (torch.arange(0, 128, 2, device=self.dev, dtype=torch.float32) / 128.0))
+        inv = 1.0 / (self.theta ** (torch.arange(0, 128, 2, device=self.dev, dtype=torch.float32) / 128.0)) if self.inv_freq is None \
+            else self.inv_freq.to(self.dev, torch.float32)
         fr = positions.to(torch.float32)[:, None] * inv[None, :]
         emb = torch.cat([fr, fr], dim=-1)
-        cos, sin = emb.cos().to(torch.float16)[:, None, :], emb.sin().to(torch.float16)[:, None, :]
+        cos, sin = (emb.cos() * self.rope_scale).to(torch.float16)[:, None, :], (emb.sin() * self.rope_scale).to(torch.float16)[:, None, :]
         t1, t2 = t[..., :64], t[..., 64:]
         rot = torch.cat([-t2, t1], dim=-1)
         return t * cos + rot * sin
@@ -393,10 +434,12 @@ class QuantLlama:
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     self._prefill_rows(static_ids, start_pos)
             torch.cuda.current_stream(self.dev).wait_stream(side)
-            ent = cache[(S, start_pos)] = (g, static_ids)
-        g, static_ids = ent
+            ent = cache[(S, start_pos)] = (g, static_ids, self.__dict__.get("logits_rows"))
+        g, static_ids, rows = ent
         static_ids.copy_(ids)
         g.replay()
+        if rows is not None:
+            self.logits_rows = rows             # (this graph's own output buffer: valid until its next replay)
         self.host_pos = start_pos + S           # (the replay sets the device-side position; the host mirror is not part of it)
         return self.logits
 
@@ -416,6 +459,8 @@ class QuantLlama:
         B, S = ids.shape
         last = self._rows_pass(ids, start_pos, cache=True)
         ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
+        if self.all_logits:
+            self.logits_rows = self._logits_of_rows(self.__dict__.pop("_rows_x"), B, S, self.logits)
         self.set_pos(start_pos + S)
         self.set_token(torch.argmax(self.logits, dim=1))
         return self.logits
@@ -443,7 +488,16 @@ class QuantLlama:
             h2 = ops.rmsnorm(x, blk["ln2"], self.eps)
             act = self._rows_up_gated(blk["mlp.up_proj"], h2, lin(blk["mlp.gate_proj"], h2))
             x = lin(blk["mlp.down_proj"], act, residual=x)
+        if self.all_logits:
+            self._rows_x = x                    # (picked up by _prefill_rows)
         return x.view(B, S, H)[:, S - 1].contiguous()
+
+    def _logits_of_rows(self, x, B, S, last_logits):
+        """logits of every prompt row, [B, S, vocab] fp16: final RMSNorm + one fp16 GEMM against the lm_head; each sequence's LAST row is the
+        weight-streaming kernel's result (what the decode steps and the runner's own token choice use), so that the two agree bit for bit"""
+        rows = ops.gemm_f16w(ops.rmsnorm(x, self.norm, self.eps), self.lm_head).view(B, S, self.vocab)
+        rows[:, S - 1].copy_(last_logits.view(B, self.vocab))
+        return rows
 
     # prompt rows (exclusive, inclusive) served by the fragment-ordered few-row kernels with q/k/v and gate/up as grouped
     # launches.  7B avg-3, ms per prompt pass, this path | the row-major / tiled kernels: 16 rows 2.91 | 2.55, 24 3.03 | 3.13,
@@ -463,17 +517,17 @@ class QuantLlama:
 
         def lin(l, inp, residual=None):
             if S > 8:
-                return ops.gemm(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, residual=residual, out=residual)
-            y = ops.linear(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K)
+                return ops.gemm(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, bias=l.bias, residual=residual, out=residual)
+            y = ops.linear(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, bias=l.bias)
             return y if residual is None else residual.add_(y)
 
         def lin_xf(l, xf, residual=None, gate=None):
-            return ops.gemm_xfrag(xf, S, l.qn, l.mn, l.bits, l.mode, l.N, l.K, residual=residual, gate=gate,
+            return ops.gemm_xfrag(xf, S, l.qn, l.mn, l.bits, l.mode, l.N, l.K, bias=l.bias, residual=residual, gate=gate,
                                   out=residual if residual is not None else gate)
 
         def lin_xf_group(ls, xf):
             ys = [torch.empty(S, l.N, dtype=torch.float16, device=self.dev) for l in ls]
-            ops.gemm_xfrag_grouped(xf, S, [dict(qn=l.qn, mn=l.mn, bits=l.bits, mode=l.mode, N=l.N, y=y) for l, y in zip(ls, ys)], ls[0].K)
+            ops.gemm_xfrag_grouped(xf, S, [l.seg(y) for l, y in zip(ls, ys)], ls[0].K)
             return ys
 
         # up to 256 rows the projections that read a normed / attention activation take it in fragment order (written
@@ -501,7 +555,7 @@ class QuantLlama:
                 g = lin(blk["mlp.gate_proj"], h2)
                 if S > 8:
                     u = blk["mlp.up_proj"]                                         # silu(gate) * up in up_proj's epilogue
-                    act = ops.gemm(h2, u.qn, u.mn, u.bits, u.mode, u.N, u.K, gate=g, out=g)
+                    act = ops.gemm(h2, u.qn, u.mn, u.bits, u.mode, u.N, u.K, bias=u.bias, gate=g, out=g)
                 else:
                     act = ops.silu_mul(g, lin(blk["mlp.up_proj"], h2), out=g)
             x = lin(blk["mlp.down_proj"], act, residual=x)
@@ -509,11 +563,11 @@ class QuantLlama:
 
     def _rows_linear(self, l, inp, residual=None):
         # y = inp . W^T (+ residual, in place) for many rows
-        return ops.gemm(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, residual=residual, out=residual)
+        return ops.gemm(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, bias=l.bias, residual=residual, out=residual)
 
     def _rows_up_gated(self, l, inp, gate):
         # silu(gate) * (inp . W^T), in place on gate: the LlamaMLP product formed in up_proj's epilogue
-        return ops.gemm(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, gate=gate, out=gate)
+        return ops.gemm(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, bias=l.bias, gate=gate, out=gate)
 
     def prefill_batch(self, ids):
         """ids: int64 [B, S].  The many-row pass over B prompts at once (B*S rows through every linear): what the reference
@@ -561,6 +615,8 @@ class QuantLlama:
             ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits[b])
             return self.logits[b]
         ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
+        if self.all_logits:
+            self.logits_rows = self._logits_of_rows(x, 1, S, self.logits)
         self.set_pos(start_pos + S)
         self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
         return self.logits
@@ -577,7 +633,7 @@ class QuantLlama:
         positions = torch.arange(S, device=self.dev)
 
         def lin(l, inp):
-            return ops.linear(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K)
+            return ops.linear(inp, l.qn, l.mn, l.bits, l.mode, l.N, l.K, bias=l.bias)
 
         for blk in self.blocks:
             h = ops.rmsnorm(x, blk["ln1"], self.eps)

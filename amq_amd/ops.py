@@ -826,9 +826,17 @@ class DecodeEngine:
         raise KeyError(name)
 
 
-def rope_table(max_seq, rope_theta, device):
+def rope_table(max_seq, rope_theta, device, inv_freq=None, scale=1.0):
+    """fp16 [max_seq, 64, 2] (cos, sin) rows.  ``inv_freq`` (fp32 [64]: HF's ``rotary_emb.inv_freq`` after a static rope_scaling -- Llama-3.1's
+    "llama3" factors, arch.rope_inv_freq) and ``scale`` (its attention_scaling) replace the plain ``rope_theta`` frequencies."""
     tab = torch.empty(max_seq, 64, 2, dtype=torch.float16, device=device)
-    _lib.check(_lib.load().amq_rope_table_f16(_lib.ptr(tab), max_seq, ctypes.c_float(rope_theta), _lib.current_stream()))
+    if inv_freq is None:
+        _lib.check(_lib.load().amq_rope_table_f16(_lib.ptr(tab), max_seq, ctypes.c_float(rope_theta), _lib.current_stream()))
+    else:
+        f = inv_freq.detach().to(device=device, dtype=torch.float32).contiguous()
+        if f.numel() != 64:
+            raise ValueError("inv_freq must hold 64 frequencies (head_dim 128)")
+        _lib.check(_lib.load().amq_rope_table_freqs_f16(_lib.ptr(tab), max_seq, _lib.ptr(f), ctypes.c_float(scale), _lib.current_stream()))
     return tab
 
 
@@ -856,6 +864,7 @@ _ATTN_TICKETS = _ZeroedPool()
 ATTN_SPLIT_FROM = 512      # caches longer than this use the split kernel (n_splits = 0 / auto)
 ATTN_CHUNK = 272           # keys per workgroup aimed at for a full cache (the kernel holds up to 384 in registers; its smallest chunk is 256)
 ATTN_CUS = 256             # workgroups per round of the chip (MI355X: 256 CUs)
+ATTN_PREFETCH_KEYS = 384   # keys of a chunk the split kernel requests ahead into registers (amq_decode.hip); longer chunks take its remainder loop
 
 
 def attn_decode_splits(max_seq, n_heads=32, batch=1):
@@ -869,6 +878,10 @@ def attn_decode_splits(max_seq, n_heads=32, batch=1):
     if ATTN_CUS % wg == 0:
         step = ATTN_CUS // wg              # splits per round of the chip
         s = max(step, round(s / step) * step) if s >= step else s
+        # rounding DOWN to a whole round may leave chunks beyond the kernel's 384-key register prefetch (32 heads at ~3000 - 3128 keys: 11 -> 8
+        # splits of 416 keys, the slower remainder loop): go up a round instead
+        while s >= step and (-(-max_seq // s) + 31) // 32 * 32 > ATTN_PREFETCH_KEYS:
+            s += step
     return s
 
 

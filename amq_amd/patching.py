@@ -56,7 +56,7 @@ class HQQWeightsModule(torch.nn.Module):
         self.device = weights.W_q.device
 
 
-def patch_linearlayers(model, fct, patch_param=None, verbose=False):
+def patch_linearlayers(model, fct, patch_params=None, verbose=False):
     """The reference's walk (patching.py:39-49): depth first over ``named_children``; every HQQ layer gets its attribute name as
     ``layer.name`` and is replaced by ``fct(layer, patch_param)``; anything else is descended into."""
     stack = [model]
@@ -67,7 +67,7 @@ def patch_linearlayers(model, fct, patch_param=None, verbose=False):
                 stack.append(child)
                 continue
             child.name = attr
-            setattr(parent, attr, fct(child, patch_param))
+            setattr(parent, attr, fct(child, patch_params))
 
 
 def _inner(layer):
@@ -84,10 +84,14 @@ def patch_hqq_to_hip(layer, patch_params=None, load=False):
     h.name = getattr(hqq_layer, "name", None) or getattr(layer, "name", None)
     n, k = h.shape
     device = (patch_params or {}).get("device", None) or h.W_q.device
+    # bfloat16 layers (compute_dtype = bfloat16) become fp16 modules like every module the reference's patchers build (ft.py:62) -- grouped, fused,
+    # served by the decode runner -- unless the caller asks to keep HQQ's bf16 arithmetic (keep_bf16) and the bf16 kernels serve the layer's groups
+    bf16 = bool((patch_params or {}).get("keep_bf16", False)) and h.scale.dtype == torch.bfloat16 and HIPQuantLinear.bf16_serves(h.group_size)
     if load:
-        new = HIPQuantLinear(h.nbits, h.group_size, k, n, bias=h.bias, name=h.name).to(device)
+        new = HIPQuantLinear(h.nbits, h.group_size, k, n, bias=h.bias, name=h.name,
+                             weight_dtype=torch.bfloat16 if bf16 else torch.float16).to(device)
     else:
-        new = HIPQuantLinear.from_hqq(h, device=device)
+        new = HIPQuantLinear.from_hqq(h, device=device, keep_bf16=bf16)
     if type(layer).__name__ == "HQQLinearLoRA":
         layer.linear_layer = new
         return layer
@@ -164,7 +168,10 @@ def fuse_llama_mlps(model):
 
 
 # RMSNorm classes whose forward is weight * x / sqrt(mean(x^2) + eps) with fp32 statistics (HF LlamaRMSNorm; module_walk's own)
-RMSNORM_CLASSES = ("LlamaRMSNorm", "_RMSNorm")
+# (transformers' Mistral / Qwen2 classes are generated from the Llama ones: the same forward, token for token)
+RMSNORM_CLASSES = ("LlamaRMSNorm", "MistralRMSNorm", "Qwen2RMSNorm", "_RMSNorm")
+# decoder layers whose ``forward`` is LlamaDecoderLayer's (checked by signature as well: fuse_llama_layers)
+HF_LAYER_CLASSES = ("LlamaDecoderLayer", "MistralDecoderLayer", "Qwen2DecoderLayer")
 
 
 def fuse_llama_norms(model):
@@ -259,7 +266,7 @@ def fuse_llama_layers(model):
             continue
         if cls.__name__ == "_Block" and cls.__module__.endswith("module_walk"):
             layer.forward = types.MethodType(_walk_block_forward, layer)
-        elif cls.__name__ == "LlamaDecoderLayer" and list(inspect.signature(cls.forward).parameters) == _HF_LAYER_PARAMS:
+        elif cls.__name__ in HF_LAYER_CLASSES and list(inspect.signature(cls.forward).parameters) == _HF_LAYER_PARAMS:
             layer.forward = types.MethodType(_hf_llama_layer_forward, layer)
         else:
             continue
@@ -285,7 +292,7 @@ def _merge_zeros_with_lora(model):
 
 
 def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False, load_path=None, group_siblings=True, fuse_mlp=True,
-                          fuse_norms=True, fuse_layers=True, kernel_arithmetic=False):
+                          fuse_norms=True, fuse_layers=True, kernel_arithmetic=False, keep_bf16=False):
     """patching.py:143-223 for the HIP backend.  ``kernel_arithmetic`` (default off): the swapped linears dequantize like the reference's GPTQ /
     FT CUDA kernels -- w = fma(q, s, -fp16(z s)), one rounding, what its own ``backend='gptq'`` / ``'ft'`` paths compute -- instead of like HQQ's
     ``dequantize()`` (two roundings, the default here: bit-identical to ``W_deq``).  The two differ by the rounding of c = fp16(z s): |dw| <= ~ulp(z s),
@@ -293,7 +300,9 @@ def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False
     (HIPQuantLinear.to_kernel_arithmetic).  The cache file always holds the HQQ form.  ``group_siblings`` (default on; not in the reference): q/k/v and gate/up
     siblings are additionally tied into grouped launches (group_sibling_linears); ``fuse_mlp`` / ``fuse_norms``: SiLU-gated MLPs
     and the decoder layers' RMSNorms are fused into those launches (fuse_llama_mlps, fuse_llama_norms); ``fuse_layers``: the decoder
-    layers' residual adds move into the o_proj / down_proj epilogues (fuse_llama_layers)."""
+    layers' residual adds move into the o_proj / down_proj epilogues (fuse_llama_layers).  ``keep_bf16`` (default off): layers quantized with
+    compute_dtype = bfloat16 keep HQQ's bf16 arithmetic (bfloat16 modules: ungrouped, unfused, groups of 128 and multiples) instead of
+    becoming fp16 modules as under the reference's patchers."""
     if backend not in HIP_BACKENDS:
         raise RuntimeError(f"backend '{backend}' is not available in amq_amd (use one of {HIP_BACKENDS})")
     if allow_merge:
@@ -301,7 +310,7 @@ def prepare_for_inference(model, allow_merge=False, backend="hip", verbose=False
     # the cache-file contract of patching.py:178-208: no path -> convert in place; a path that does not exist yet -> convert and
     # write the patched state_dict there; an existing file -> build empty modules and load it instead of re-packing
     cached = load_path is not None and os.path.exists(load_path)
-    patch_linearlayers(model, patch_hqq_to_hip_load if cached else patch_hqq_to_hip, verbose=verbose)
+    patch_linearlayers(model, patch_hqq_to_hip_load if cached else patch_hqq_to_hip, {"keep_bf16": keep_bf16}, verbose=verbose)
     if cached:
         print("Loading the model from", load_path)
         model.load_state_dict(torch.load(load_path, weights_only=True))

@@ -249,6 +249,11 @@ class HIPQuantLinear(nn.Module):
         else:
             self.bias = None
 
+    @staticmethod
+    def bf16_serves(group_size):
+        """groups a bfloat16 module can hold (the bf16 kernels read one (scale, zero) pair per 128 columns)"""
+        return group_size not in ops.FINE_GROUPS
+
     # ------------------------------------------------------------------ build
     def _set_native(self, qn, mn, mode):
         self.qweight = qn
@@ -259,9 +264,14 @@ class HIPQuantLinear(nn.Module):
             self.bias = self.bias.to(qn.device)
 
     @classmethod
-    def from_hqq(cls, hqq, device=None):
-        """From an HQQLinear (reference object, duck-typed) or HQQWeights."""
+    def from_hqq(cls, hqq, device=None, keep_bf16=True):
+        """From an HQQLinear (reference object, duck-typed) or HQQWeights.  A layer quantized with compute_dtype = bfloat16 stays a bfloat16
+        module (``keep_bf16``, and groups the bf16 kernels serve: 128 and multiples); otherwise its scale / zero go to fp16 -- what the reference's
+        patch_hqq_to_gptq / patch_hqq_to_ft make of every layer (autogptq.py:301-306, ft.py:62) -- and the module takes the fp16 kernels."""
         h = hqq if isinstance(hqq, HQQWeights) else from_hqq_layer(hqq)
+        if h.scale.dtype == torch.bfloat16 and not (keep_bf16 and cls.bf16_serves(h.group_size)):
+            h = HQQWeights(h.W_q, h.scale.to(torch.float16), h.zero.to(torch.float16), h.nbits, h.shape, h.group_size,
+                           None if h.bias is None else h.bias.to(torch.float16), h.name)
         n, k = h.shape
         dev = torch.device(device) if device is not None else h.W_q.device
         if dev.type != "cuda":
@@ -425,7 +435,9 @@ class HIPQuantLinear(nn.Module):
         return h[0].run(x if x.is_contiguous() else x.contiguous(), 0, None, 0.0, residual)[0]
 
     def dequantize(self):
-        """W[N,K] fp16 exactly as Quantizer.dequantize would give it (MODE_HQQ)."""
+        """W[N,K] exactly as Quantizer.dequantize would give it (MODE_HQQ): fp16, or bfloat16 for a bfloat16 module."""
+        if self.is_bf16:
+            return ops.dequantize_bf16(self.qweight, self.meta, self.bits, self.outfeatures, self.infeatures)
         return ops.dequantize(self.qweight, self.meta, self.bits, self.mode, self.outfeatures, self.infeatures)
 
     def extra_repr(self):

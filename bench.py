@@ -388,7 +388,9 @@ def cpu_baseline(seed=0):
         h = random_hqq(n, k, bits, seed=seed + len(layers))
         layers.append({"W_q": h.W_q, "scale": h.scale, "zero": h.zero, "nbits": bits, "shape": (n, k)})
     lm_head = torch.randn(cfg["vocab_size"], cfg["hidden_size"]).to(torch.float16)
-    return cb.time_decode_linears(layers, cfg["n_block"], tokens=3, extra_dense=lm_head, sample_blocks=4)
+    # the thread sweep on a 4-block sample, then -- at the best thread count -- 8 greedy tokens of the WHOLE 32-block model
+    return cb.time_decode_linears(layers, cfg["n_block"], tokens=3, extra_dense=lm_head, sample_blocks=4,
+                                  full_model=(cfg["num_heads"], cfg["num_kv_heads"]), full_tokens=8)
 
 
 def host_cpu_info():
@@ -562,9 +564,11 @@ def run_decode(args, rep, dev):
         gate_ok = out["parity"]["ok"]
         cb = cpu_baseline()
         cpu_model, physical = host_cpu_info()
-        out["cpu_baseline"] = {"value": cb["tokens_per_s_predequantized"], "unit": "tokens/s", "cores": cb["cores"],
+        out["cpu_baseline"] = {"value": cb["tokens_per_s_full_model"], "unit": "tokens/s", "cores": cb["cores"],
                                "best_threads": cb["cores"], "physical_cores": physical, "cpu_model": cpu_model,
-                               "kind": "port", "sample": cb["sample"], "host_threads": cb["host_threads"],
+                               "kind": "port", "sample": cb["full_model_sample"], "host_threads": cb["host_threads"],
+                               "seconds_per_token": cb["full_model_seconds_per_token"],
+                               "linears_only_sample_tokens_per_s": cb["tokens_per_s_predequantized"], "thread_sweep_sample": cb["sample"],
                                "thread_sweep_tokens_per_s": cb["thread_sweep"],
                                "dequant_every_call_tokens_per_s": cb["tokens_per_s_dequant_every_call"]}
     print(json.dumps(out), flush=True)
@@ -671,9 +675,10 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
 
-    if world > 1:
+    if world > 1 and "AMQ_RENDEZVOUS_FILE" not in os.environ:
         # ranks started by torch.distributed.run are not placed by anyone: bind this one to its GPU's NUMA node (its share of those cores)
-        # before the first GPU call creates the runtime's threads (launch_local's children arrive already bound: this then narrows nothing)
+        # before the first GPU call creates the runtime's threads.  launch_local's children (AMQ_RENDEZVOUS_FILE set) arrive already bound:
+        # computing the share again over the narrowed mask would divide it among the node's peers a second time
         from amq_amd.replicas import pin_rank_cpus
         pin_rank_cpus()
     if not torch.cuda.is_available():

@@ -45,7 +45,8 @@
 extern "C" {
 #endif
 
-#define AMQ_VERSION 510            /* 0.5.1: the bfloat16 entry points (amq_*_bf16) added, nothing else changed.  0.5.0: amq_gemv_opts.math renumbered
+#define AMQ_VERSION 520            /* 0.5.2: amq_rope_table_freqs_f16 added (rope_scaling), nothing else changed.  0.5.1: the bfloat16 entry points
+                                    * (amq_*_bf16) added.  0.5.0: amq_gemv_opts.math renumbered
                                     * (0 = the build's default), amq_default_gemv_math added; the decode-engine and fused q/k/v-attention entry points live in
                                     * libamq_hip_ab.so (include/amq_hip_ab.h) since 0.4 */
 
@@ -232,6 +233,11 @@ int amq_attn_decode_f16(const void* q, const void* k, const void* v, void* kcach
                         int max_seq, float rope_theta, const void* rope_table, void* stream);
 /* optional: fp16 [max_seq][64][2] (cos, sin) table for amq_attn_decode_f16 (NULL there = computed in-kernel, same values) */
 int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream);
+/* the same table from explicit inverse frequencies: inv_freq fp32 [64] on the device -- what HF's rotary embedding holds after a static
+ * rope_scaling (Llama-3.1's "llama3" factors, "linear", ...; amq/configs/llama.json:82+ lists the Llama-3.x models) -- and its attention_scaling
+ * factor (1 for those): table[pos][i] = (fp16(cos(pos * inv_freq[i]) * scale), fp16(sin(...) * scale)), LlamaRotaryEmbedding.forward's expression.
+ * Every kernel that rotates (amq_attn_decode_*_f16 through the step-state row, amq_rope_cache_*, amq_rope_rows_f16) reads the table it is given. */
+int amq_rope_table_freqs_f16(void* table, int max_seq, const float* inv_freq, float scale, void* stream);
 
 /* Decode attention for graph-replayed token steps.  step_state is a 264-byte device block
  *     { fp16 cos/sin [64][2] of the CURRENT position ; int32 position at byte 256 ; int32 sticky error word at byte 260 }

@@ -12,8 +12,13 @@ torch CPU ops on all host threads --
        reference's CPU path can possibly be: dequantization hoisted out), and
   (ii) unpack + ``(W_r - zero) * scale`` + matmul on every call (what
        ``forward_hqq_inferece`` literally does).
-A bounded sample is timed (the 7 linears of ``blocks`` decoder blocks for
-``tokens`` decode tokens) and extrapolated to the whole model per token.
+A bounded sample is timed per thread count (the 7 linears of ``blocks`` decoder blocks
+for ``tokens`` decode tokens, extrapolated: the thread sweep); at the best thread count
+the WHOLE model then decodes ``full_tokens`` greedy tokens (">= 8
+greedy decode tokens of the synthetic Llama-2-7B, pre-dequantized fp16, ~13 GB host
+RAM"): every block's seven matrices in their own memory, RMSNorm, rotary embedding, KV
+cache, softmax attention, SiLU-gated MLP, final norm, lm_head, arg-max -- the forward the
+reference's CPU model runs -- and that is the value reported.
 """
 import os
 import time
@@ -53,15 +58,69 @@ def _time_tokens(mats, xs, tokens):
     return float(np.median(t))
 
 
+def _rmsnorm(x, eps):
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(torch.float16)        # (gamma = 1: synthetic)
+
+
+def decode_full_model(block, n_block, n_heads, n_kv_heads, lm_head, tokens=8, eps=1e-5, theta=10000.0, prompt_token=1):
+    """``tokens`` greedy decode tokens of a whole decoder on the host cores (torch CPU ops, the current thread count), after one un-timed token.
+    block: the seven pre-dequantized fp16 matrices of ONE block in forward order (q, k, v, o, gate, up, down); every one of the ``n_block`` blocks gets
+    its own copy (distinct memory: the weights of a token do not fit any cache), the embedding is the lm_head's rows (synthetic model).
+    Returns (seconds per token: list, tokens: list)."""
+    F = torch.nn.functional
+    blocks = [block] + [[w.clone() for w in block] for _ in range(n_block - 1)]
+    H = block[0].shape[1]
+    d = H // n_heads
+    ctx = tokens + 2
+    kc = [torch.zeros(n_kv_heads, ctx, d, dtype=torch.float16) for _ in range(n_block)]
+    vc = [torch.zeros(n_kv_heads, ctx, d, dtype=torch.float16) for _ in range(n_block)]
+    inv = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    rep = n_heads // n_kv_heads
+
+    def rope(t, pos):
+        fr = pos * inv
+        cos, sin = torch.cat([fr, fr]).cos().to(torch.float16), torch.cat([fr, fr]).sin().to(torch.float16)
+        return t * cos + torch.cat([-t[..., d // 2:], t[..., :d // 2]], -1) * sin
+
+    def step(tok, pos):
+        x = lm_head[tok:tok + 1].clone()
+        for b, (wq, wk, wv, wo, wg, wu, wd) in enumerate(blocks):
+            h = _rmsnorm(x, eps)
+            q = rope(F.linear(h, wq).view(n_heads, d), pos)
+            kc[b][:, pos] = rope(F.linear(h, wk).view(n_kv_heads, d), pos)
+            vc[b][:, pos] = F.linear(h, wv).view(n_kv_heads, d)
+            k = kc[b][:, :pos + 1].repeat_interleave(rep, 0)
+            v = vc[b][:, :pos + 1].repeat_interleave(rep, 0)
+            p = torch.softmax(torch.einsum("hd,htd->ht", q.float(), k.float()) / d ** 0.5, -1).to(torch.float16)
+            a = torch.einsum("ht,htd->hd", p.float(), v.float()).to(torch.float16).reshape(1, H)
+            x = x + F.linear(a, wo)
+            h2 = _rmsnorm(x, eps)
+            x = x + F.linear(F.silu(F.linear(h2, wg)) * F.linear(h2, wu), wd)
+        return int(F.linear(_rmsnorm(x, eps), lm_head).float().argmax())
+
+    times, toks = [], []
+    with torch.inference_mode():
+        tok = step(prompt_token, 0)                      # un-timed: first touch of every page
+        for i in range(tokens):
+            t0 = time.perf_counter()
+            tok = step(tok, i + 1)
+            times.append(time.perf_counter() - t0)
+            toks.append(tok)
+    return times, toks
+
+
 def time_decode_linears(layers, n_block_total, tokens=3, extra_dense=None, sample_blocks=4, thread_counts=None,
-                        budget_s=25.0):
+                        budget_s=25.0, full_model=None, full_tokens=8):
     """layers: list of dicts {W_q, scale, zero, nbits, shape} (torch CPU tensors) = ONE decoder block's seven linears in
     forward order, real HQQ payloads (the port is checked against the numpy oracle on them).  ``sample_blocks`` blocks
     are timed per token: block 0 holds the dequantized weights of ``layers``; the others are distinct fp16 matrices of the
     same shapes (values do not affect the speed of a GEMV; distinct memory so that the CPU caches do not help), and the
     result is extrapolated to ``n_block_total`` blocks.  The thread count is SWEPT (an M = 1 fp16 GEMV does not scale to
     hundreds of threads: pinning os.cpu_count() threads on it measured 29 s per token on a 256-thread EPYC); the best
-    setting is reported, the whole sweep returned.  extra_dense: optional fp16 [N,K] (lm_head), added un-scaled."""
+    setting is reported, the whole sweep returned.  extra_dense: optional fp16 [N,K] (lm_head), added un-scaled.
+    full_model: (n_heads, n_kv_heads) -> at the best thread count the WHOLE model (``n_block_total`` blocks, each its own copy of the
+    dequantized block, + extra_dense as lm_head / embedding) decodes ``full_tokens`` greedy tokens (decode_full_model): ``tokens_per_s_full_model``."""
     ncpu = os.cpu_count() or 1
     if thread_counts is None:
         thread_counts = sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu})
@@ -97,7 +156,16 @@ def time_decode_linears(layers, n_block_total, tokens=3, extra_dense=None, sampl
             torch.matmul(x, dequantize_torch(l["W_q"], l["scale"], l["zero"], l["nbits"], l["shape"]).T)
         t_deq = time.perf_counter() - t0
         t_dense = _time_tokens([extra_dense], [xd], 1) if extra_dense is not None else 0.0
+    full = {}
+    if full_model is not None and extra_dense is not None:
+        t_tok, toks = decode_full_model(deq, n_block_total, full_model[0], full_model[1], extra_dense, tokens=full_tokens)
+        full = {"tokens_per_s_full_model": 1.0 / float(np.median(t_tok)), "full_model_tokens": len(t_tok),
+                "full_model_seconds_per_token": [round(t, 5) for t in t_tok],
+                "full_model_sample": f"{n_block_total} of {n_block_total} blocks, {len(t_tok)} greedy tokens after one un-timed token (pre-dequantized fp16 weights, "
+                                     f"{sum(w.numel() for w in deq) * 2 * n_block_total / 1e9:.1f} GB; whole decoder forward incl. norms, rotary embedding, attention over the "
+                                     f"cache, lm_head, arg-max), {best} threads; tokens/s = 1 / median token time"}
     return {
+        **full,
         "tokens_per_s_predequantized": sweep[best],
         "tokens_per_s_dequant_every_call": 1.0 / (t_deq * n_block_total + t_dense),
         "cores": best,

@@ -30,15 +30,20 @@ def test_header_symbols_exported_and_bound():
     assert sorted(_lib.AB_SIGNATURES) == ab and len(ab) == 6
     for s in ab:
         assert not hasattr(lib, s), f"{s} is an A/B route and must not be exported by the product library"
-    assert os.path.exists(_lib.AB_LIB_PATH), "run __graft_entry__.build() first (make ab)"
-    ablib = ctypes.CDLL(_lib.AB_LIB_PATH)
-    for s in ab + syms:
-        assert hasattr(ablib, s), f"{s} not exported by libamq_hip_ab.so"
+    if os.path.exists(_lib.AB_LIB_PATH):              # optional since round 6 (`make -C amq_amd/csrc ab`): not part of the default build
+        ablib = ctypes.CDLL(_lib.AB_LIB_PATH)
+        for s in ab + syms:
+            assert hasattr(ablib, s), f"{s} not exported by libamq_hip_ab.so"
+    # the conservative-waits twin (`make safe`, built by __graft_entry__.build()): same exports as the product library
+    assert os.path.exists(_lib.SAFE_LIB_PATH), "run __graft_entry__.build() first (make safe)"
+    safe = ctypes.CDLL(_lib.SAFE_LIB_PATH)
+    for s in syms:
+        assert hasattr(safe, s), f"{s} not exported by libamq_hip_safe.so"
 
 
 def test_version_sizes_and_validation():
     lib = _lib.load()
-    assert lib.amq_version() == 510 == _lib.ABI_VERSION
+    assert lib.amq_version() == 520 == _lib.ABI_VERSION
     # native sizes: N*K*bits/8 payload, 4 B of (scale, zero) per (row, group)
     for bits in (2, 3, 4):
         assert lib.amq_native_qweight_bytes(bits, 4096, 4096) == 4096 * 4096 * bits // 8
@@ -136,6 +141,7 @@ def test_finer_groups_host_side():
     assert lib.amq_gemm_xfrag_f16(4, 0, one, one, one, None, None, None, one, 17, N, K, 64, 0, None) == -2
 
 
+@pytest.mark.skipif(not os.path.exists(_lib.AB_LIB_PATH), reason="libamq_hip_ab.so not built (make -C amq_amd/csrc ab): A/B routes only")
 def test_decode_engine_host_side():
     """the one-launch-per-token engine (an A/B route, libamq_hip_ab.so): sizes, the host-side table builder and argument validation
     (no GPU needed)"""

@@ -263,3 +263,45 @@ def test_bf16_module_drop_in():
     assert mod.to_kernel_arithmetic() is mod and mod.mode == 0   # (a no-op for bf16 modules)
     from amq_amd import patching
     assert not patching._fusable(mod)
+
+
+def test_bf16_layers_through_prepare_for_inference(tmp_path):
+    """a model quantized with compute_dtype = bfloat16 becomes fp16 modules under prepare_for_inference by default -- what the
+    reference's patch_hqq_to_gptq / patch_hqq_to_ft make of every layer (ft.py:62) -- so it keeps the grouped / fused fp16 launches, and layers
+    with groups of 64 (which the bf16 kernels do not serve) convert at all; ``keep_bf16=True`` keeps HQQ's bf16 arithmetic where the kernels serve
+    the layer, through the cache file as well; dequantize() of a bfloat16 module returns the bf16 weights"""
+    from amq_amd import patching
+    from amq_amd.hqq_format import random_hqq, HQQWeights
+    from amq_amd.quant_linear import HIPQuantLinear
+
+    def model(group):
+        m = torch.nn.Module()
+        att = torch.nn.Module()
+        for i, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+            h = random_hqq(256, 512, 4, seed=20 + i, group=group)
+            hb = HQQWeights(h.W_q, h.scale.float().to(torch.bfloat16), h.zero.float().to(torch.bfloat16), 4, (256, 512), group, None, nm)
+            setattr(att, nm, patching.HQQWeightsModule(hb.to(_dev())))
+        m.self_attn = att
+        return m
+
+    x = torch.randn(1, 512, generator=torch.Generator().manual_seed(1)).to(torch.float16).to(_dev())
+    for group in (128, 64):
+        m = patching.prepare_for_inference(model(group))
+        mods = [m.self_attn.q_proj, m.self_attn.k_proj, m.self_attn.v_proj]
+        assert all(isinstance(q, HIPQuantLinear) and not q.is_bf16 and q.meta.dtype == torch.float16 for q in mods)
+        assert all("_group" in q.__dict__ for q in mods)            # grouped like any fp16 model
+        assert mods[0](x).dtype == torch.float16
+    # opt-in: bf16 kept at groups of 128, fp16 fallback at 64
+    mk = patching.prepare_for_inference(model(128), keep_bf16=True)
+    assert mk.self_attn.q_proj.is_bf16
+    wb = mk.self_attn.q_proj.dequantize()
+    assert wb.dtype == torch.bfloat16 and wb.shape == (256, 512)
+    assert not patching.prepare_for_inference(model(64), keep_bf16=True).self_attn.q_proj.is_bf16
+    # cache file: written from bf16 modules, read back into bf16 modules (not value-cast into fp16 meta)
+    path = str(tmp_path / "bf16_cache.pt")
+    m1 = patching.prepare_for_inference(model(128), keep_bf16=True, load_path=path)
+    m2 = patching.prepare_for_inference(model(128), keep_bf16=True, load_path=path)
+    assert m2.self_attn.q_proj.is_bf16
+    xb = x.to(torch.bfloat16)
+    assert torch.equal(m1.self_attn.q_proj(xb), m2.self_attn.q_proj(xb))
+    assert torch.equal(m1.self_attn.q_proj.dequantize(), wb)

@@ -661,6 +661,33 @@ def test_gemv_rows_staged_by_dma(bits, m, k, n):
     del junk
 
 
+@pytest.mark.parametrize("m,k,ok", [(2, 4096, True), (6, 4096, True), (8, 4096, True), (6, 11008, True), (8, 11008, False), (7, 11008, False)])
+def test_gemv_strided_x_through_the_c_abi(m, k, ok):
+    """x rows that are not K apart (include/amq_hip.h: x_stride): the row kernels' LDS-DMA staging takes dense rows only, so a strided launch runs
+    the generic staging with the same bits -- and where rows would only fit LDS in two K phases (7 - 8 rows of K = 11008), which needs dense rows,
+    the call is refused with AMQ_ESHAPE instead of returning AMQ_OK with y unwritten."""
+    from amq_amd import ops, _lib
+    dev = _dev()
+    bits, n = 3, 512
+    h, qn, mn, w_ref = _random_case(bits, n, k, seed=3 * m + 1)
+    xs = k + 64
+    xbuf = torch.randn(m, xs, generator=torch.Generator().manual_seed(m + k)).to(torch.float16).to(dev)
+    y = torch.full((m, n), float("nan"), dtype=torch.float16, device=dev)
+    lib = _lib.load()
+    rc = lib.amq_gemv_f16(bits, ops.MODE_HQQ, _lib.ptr(xbuf), _lib.ptr(qn), _lib.ptr(mn), None, _lib.ptr(y), m, n, k, 128, xs, n, _lib.current_stream())
+    if not ok:
+        assert rc == -2 and b"strided" in lib.amq_last_error()
+        assert torch.isnan(y).all()
+        return
+    assert rc == 0, lib.amq_last_error()
+    xd = xbuf[:, :k].contiguous()
+    yd = torch.empty(m, n, dtype=torch.float16, device=dev)
+    ops.gemv_grouped(xd, [dict(qn=qn, mn=mn, bits=bits, mode=ops.MODE_HQQ, N=n, y=yd)], k)
+    assert not torch.isnan(y).any()
+    _assert_close(y.cpu().numpy(), linear_ref.linear_f16(xd.cpu().numpy(), w_ref), "strided x")
+    _assert_close(y.cpu().numpy(), yd.cpu().numpy(), "strided vs dense")
+
+
 def test_results_do_not_depend_on_cache_state():
     """every kernel that waits for its loads with COUNTED waits (register rings, LDS-DMA pieces) against operands that are cold in HBM: a cache-flushing
     fill in front of each launch makes every transfer take microseconds to land, so a wait that does not cover what the next instruction reads shows

@@ -6,7 +6,14 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+def _ab_built():
+    from amq_amd import _lib
+    import os
+    return os.path.exists(_lib.AB_LIB_PATH)
+
+
+# the A/B routes (include/amq_hip_ab.h: measured negatives) live in libamq_hip_ab.so, which the default build no longer makes (`make -C amq_amd/csrc ab`)
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _ab_built(), reason="libamq_hip_ab.so not built (make -C amq_amd/csrc ab): A/B routes only")]
 
 
 def _dev():

@@ -64,6 +64,72 @@ print(f"built {args.model} HF model with {sum(isinstance(m, HIPQuantLinear) for 
 tok = SyntheticTokenizer(cfg["vocab_size"])
 sizes = [1, args.seq, args.gen]
 result = {}
+
+# ---- the reference's own loops over the HF OBJECT (amq/utils/speed.py:22-46 TPS, 50-127 GeMV / GeMM with wrapped_ft, 186-239 TTFT): the caller's
+# model.generate(...) and model(ids, start_pos=..., use_cache=False), every timed region bracketed by synchronize + perf_counter, medians as there
+import gc
+import numpy as np
+
+
+def _cleanup():
+    torch.cuda.empty_cache()
+    gc.collect()
+
+
+@torch.inference_mode()
+def hf_object_rates(model, seq, gen, it_tok=5, it_gemm=20):
+    ids = torch.randint(0, cfg["vocab_size"] - 1, (1, seq), dtype=torch.long).to(dev)
+    mask = torch.ones_like(ids)
+    model.generation_config.pad_token_id = model.generation_config.eos_token_id
+    row = {}
+    # TPS: gen / median(time of generate)
+    ts = []
+    for i in range(it_tok + 1):
+        _cleanup()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _ = model.generate(ids, min_new_tokens=gen, max_new_tokens=gen, do_sample=False, num_beams=1, attention_mask=mask)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    row["tps"] = {f"1.{seq}.{gen}": float(gen / np.median(ts[1:]))}              # (first pass: runner build + graph capture, as the reference's first pass pays its JIT)
+    # GeMM: 1 / median(prompt forward); GeMV: 1 / median(one-token forward), each token timed on its own
+    tm, tv = [], []
+    for i in range(it_gemm):
+        _cleanup()
+        start_pos = 0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = model(ids, start_pos=start_pos, use_cache=False)
+        torch.cuda.synchronize(); tm.append(time.perf_counter() - t0)
+        if i >= it_tok:
+            continue
+        start_pos += out.logits.shape[1]
+        nxt = torch.as_tensor([[out.logits[:, -1].max(1)[1].unsqueeze(1)]], device=dev)
+        for _ in range(gen):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            out = model(nxt, start_pos=start_pos, use_cache=False)
+            torch.cuda.synchronize(); tv.append(time.perf_counter() - t0)
+            start_pos += out.logits.shape[1]
+            nxt = torch.as_tensor([[out.logits[:, -1].max(1)[1].unsqueeze(1)]], device=dev)
+    row["gemm"] = {f"1.{seq}.{gen}": float(1 / np.median(tm[1:]))}
+    row["gemv"] = {f"1.{seq}.{gen}": float(1 / np.median(tv))}
+    # TTFT: tokenizer encode + prompt forward + arg-max + tokenizer decode, ms
+    text = tok.decode(ids[0])
+    tt = []
+    for _ in range(it_gemm):
+        _cleanup()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        i2 = tok(text, return_tensors="pt", truncation=True, max_length=seq).input_ids.to(dev)
+        out = model(i2, start_pos=0, use_cache=False)
+        first = out.logits[:, -1].max(1)[1].unsqueeze(1)
+        _ = tok.decode(first[0])
+        torch.cuda.synchronize(); tt.append((time.perf_counter() - t0) * 1000)
+    row["ttft"] = {f"1.{seq}.{gen}": float(np.median(tt[1:]))}
+    return row
+
+
+from amq_amd.hf_fast import convert_model_to_hip, revert_model_to_hf
+convert_model_to_hip(model)                                                        # convert_model_to_ft + replace_generate_functions of the reference's driver
+result["3.0bit HF object, converted"] = hf_object_rates(model, args.seq, args.gen)
+print(result["3.0bit HF object, converted"], flush=True)
+revert_model_to_hf(model)
 for use_ft in (True, False):
     row = result[f"3.0bit use_ft={'true' if use_ft else 'false'}"] = {}
     for mode, it in (("TPS", 5), ("GeMM", 20), ("GeMV", 5), ("TTFT", 20)):
@@ -73,6 +139,7 @@ for use_ft in (True, False):
         print(row, flush=True)
 result["args"] = {"model_name": args.model, "seq_length": args.seq, "gen_length": args.gen, "batch_size": 1, "bits_usage": usage,
                   "object": "transformers LlamaForCausalLM with HIPQuantLinear decoder linears after prepare_for_inference(backend='hip')",
+                  "HF object, converted": "hf_fast.convert_model_to_hip(model): the reference's own loops -- model.generate(...), model(ids, start_pos=, use_cache=False) -- on the HF object",
                   "use_ft=true": "QuantLlama.from_hf: hipGraph token step over the model's own buffers",
                   "use_ft=false": "HF's forward / generate() over the fused modules (eager, DynamicCache, sdpa attention)"}
 print(json.dumps(result))
