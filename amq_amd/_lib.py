@@ -98,12 +98,14 @@ SIGNATURES = {
     "amq_attn_prefill_xfrag_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 5 + [_vp]),
     "amq_gemv_f16w_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp]),
     "amq_decode_tail_batch_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "amq_decode_tail_suppress_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "amq_attn_prefill_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 10 + [_vp]),
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_cache_batch_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_silu_mul_f16": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "amq_gemv_grouped_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, ctypes.POINTER(GemvOpts), _vp]),
+    "amq_gemv_grouped_sums_f16": (_i, [ctypes.POINTER(Segment), _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
     "amq_gemm_f16w_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amq_gemm_route_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "amq_gemm_route_workspace_bytes_g": (_sz, [_i, _i, _i, _i, _i]),

@@ -176,6 +176,39 @@ int amq_gemv_grouped_f16(const amq_segment* segs, int nseg, const void* x, const
     return check_hip(amq::launch_gemv(a, (hipStream_t)stream), "gemv");
 }
 
+int amq_gemv_grouped_sums_f16(const amq_segment* segs, int nseg, const void* x, const void* gamma, float eps, const float* sums_in,
+                              float* sums_out, int M, int K, int group, void* stream) {
+    if (!segs || nseg < 1 || nseg > AMQ_MAX_SEGMENTS) return fail(AMQ_EINVAL, "nseg must be 1..%d (got %d)", AMQ_MAX_SEGMENTS, nseg);
+    if (!x) return fail(AMQ_EINVAL, "null x");
+    if ((sums_in != nullptr) != (gamma != nullptr)) return fail(AMQ_EINVAL, "sums_in (the partial sums of squares of x) and gamma go together");
+    if (M < 5 || M > 8) return fail(AMQ_ESHAPE, "the partial-sum forms live in the 5 .. 8-row kernels (got M=%d); fewer rows: amq_gemv_grouped_f16 with AMQ_PRO_RMSNORM", M);
+    if (amq::meta_pairs(group) != 1) return fail(AMQ_ESHAPE, "groups of 128 (and multiples) only (got %d)", group);
+    if (K < 2048) return fail(AMQ_ESHAPE, "K >= 2048 (the 5 .. 8-row kernels run 8 or 16 waves per workgroup; got K=%d)", K);
+    if (sums_out && nseg != 1) return fail(AMQ_EINVAL, "sums_out describes ONE output: nseg must be 1");
+    if (sums_in && K > 8192) return fail(AMQ_ESHAPE, "sums_in: K <= 8192 (K / 16 <= 512 partials per row; got K=%d)", K);
+    const bool phased = amq::gemv_rows_phased(M, K, true, sums_in != nullptr);
+    if (sums_in && phased) return fail(AMQ_ESHAPE, "M=%d rows of K=%d are staged in two K phases: no fused norm there", M, K);
+    if (amq::gemv_min_lds_bytes(M, K, true, sums_in != nullptr) > LDS_LIMIT)
+        return fail(AMQ_ESHAPE, "M=%d rows of K=%d do not fit LDS for the GEMV path", M, K);
+    amq::GemvArgs a{};
+    for (int i = 0; i < nseg; ++i) {
+        const amq_segment& s = segs[i];
+        if (int rc = check_shape(s.bits, s.N, K, group)) return rc;
+        if (int rc = check_mode(s.mode)) return rc;
+        if (!s.qweight_native || !s.meta_native || !s.y) return fail(AMQ_EINVAL, "segment %d: null pointer", i);
+        amq::GemvSeg& d = a.seg[i];
+        d.qweight = s.qweight_native; d.meta = s.meta_native; d.bias = s.bias; d.residual = s.residual; d.y = s.y;
+        d.N = s.N; d.bits = s.bits; d.mode = s.mode;
+        d.y_stride = s.y_stride ? s.y_stride : s.N;
+    }
+    a.nseg = nseg; a.M = M; a.K = K; a.x_stride = K;
+    a.x = x; a.x2 = nullptr; a.gamma = gamma; a.eps = eps;
+    a.prologue = sums_in ? amq::PRO_RMSNORM_SUMS : amq::PRO_NONE;
+    a.sums_in = sums_in; a.sums_out = sums_out;
+    a.gp = 1;
+    return check_hip(amq::launch_gemv(a, (hipStream_t)stream), "gemv_sums");
+}
+
 int amq_gemv_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, void* y,
                  int M, int N, int K, int group, int x_stride, int y_stride, void* stream) {
     amq_segment s{};
@@ -786,6 +819,19 @@ int amq_decode_tail_batch_f16(const void* logits, int vocab, const void* embed, 
     if (batch < 1 || batch > 65535) return fail(AMQ_ESHAPE, "bad batch %d", batch);
     if (batch > 1 && (vocab % 8) != 0) return fail(AMQ_ESHAPE, "batched rows need vocab %% 8 == 0 (16-byte aligned logits rows)");
     return check_hip(amq::launch_decode_tail(logits, vocab, embed, hidden, token, pos, x, rope_table, rope_cur, rope_rows, (hipStream_t)stream, batch), "decode_tail_batch");
+}
+
+int amq_decode_tail_suppress_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
+                                 const void* rope_table, void* rope_cur, int rope_rows, int batch, const int* suppress_ids, void* stream) {
+    if (!logits || !embed || !token || !pos || !x) return fail(AMQ_EINVAL, "null pointer");
+    if (!suppress_ids) return fail(AMQ_EINVAL, "suppress_ids: a device array of 8 int32 token ids (-1 = unused slot) is required");
+    if ((rope_table == nullptr) != (rope_cur == nullptr)) return fail(AMQ_EINVAL, "rope_table and rope_cur go together");
+    if (rope_cur && rope_rows < 1) return fail(AMQ_EINVAL, "rope_rows must be the number of rows of rope_table");
+    if (vocab < 1 || hidden < 8 || (hidden % 8) != 0) return fail(AMQ_ESHAPE, "need vocab >= 1 and hidden %% 8 == 0 (got %d, %d)", vocab, hidden);
+    if (batch < 1 || batch > 65535) return fail(AMQ_ESHAPE, "bad batch %d", batch);
+    if (batch > 1 && (vocab % 8) != 0) return fail(AMQ_ESHAPE, "batched rows need vocab %% 8 == 0 (16-byte aligned logits rows)");
+    return check_hip(amq::launch_decode_tail(logits, vocab, embed, hidden, token, pos, x, rope_table, rope_cur, rope_rows, (hipStream_t)stream, batch,
+                                             suppress_ids), "decode_tail_suppress");
 }
 
 int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream) {

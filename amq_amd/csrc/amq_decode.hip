@@ -210,9 +210,13 @@ hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void
 // torch.argmax), pos += 1, x = embed[token].
 // Batched decode: one workgroup per sequence (logits / token / x rows of blockIdx.x); the shared position and the cos/sin row are
 // advanced by workgroup 0 only (nobody else reads them here).
+// suppress: up to 8 token ids (device int32, -1 = unused slot) that are never chosen -- what HF's MinNewTokensLengthLogitsProcessor does to the EOS
+// ids while min_new_tokens has not been reached (generate(min_new_tokens = max_new_tokens = n): speed.py:31-36): their logits count as -inf.
+// Checked only where a thread finds a new maximum (a handful of times per thread), not per element.
+constexpr int TAIL_MAX_SUPPRESS = 8;
 __global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logits, int vocab, const _Float16* embed, int hidden,
                                                             long long* token, int* pos, _Float16* x, const _Float16* rope_table,
-                                                            _Float16* rope_cur, int rope_rows) {
+                                                            _Float16* rope_cur, int rope_rows, const int* suppress) {
     __shared__ float smax[16];
     __shared__ int sidx[16];
     __shared__ int stok, spos;
@@ -223,18 +227,27 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logit
     if (blockIdx.x != 0) rope_cur = nullptr;
     float best = -INFINITY;
     int bi = 0x7fffffff;
+    int sup[TAIL_MAX_SUPPRESS];
+#pragma unroll
+    for (int j = 0; j < TAIL_MAX_SUPPRESS; ++j) sup[j] = suppress ? suppress[j] : -1;
+    auto allowed = [&](int idx) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < TAIL_MAX_SUPPRESS; ++j) ok = ok && idx != sup[j];
+        return ok;
+    };
     const int chunks = vocab >> 3;
     for (int c = tid; c < chunks; c += 1024) {
         const h8 v = *(const h8*)(logits + 8 * c);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float f = (float)v[e];
-            if (f > best) { best = f; bi = 8 * c + e; }          // ascending index inside a thread: first maximum kept
+            if (f > best && (!suppress || allowed(8 * c + e))) { best = f; bi = 8 * c + e; }   // ascending index inside a thread: first maximum kept
         }
     }
     for (int i = 8 * chunks + tid; i < vocab; i += 1024) {       // vocab % 8 tail
         const float f = (float)logits[i];
-        if (f > best || (f == best && i < bi)) { best = f; bi = i; }
+        if ((f > best || (f == best && i < bi)) && (!suppress || allowed(i))) { best = f; bi = i; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -268,9 +281,9 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const _Float16* logit
 }
 
 hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, int hidden, void* token, void* pos, void* x,
-                              const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st, int batch) {
+                              const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st, int batch, const void* suppress) {
     hipLaunchKernelGGL(decode_tail_kernel, dim3(batch), dim3(1024), 0, st, (const _Float16*)logits, vocab, (const _Float16*)embed, hidden,
-                       (long long*)token, (int*)pos, (_Float16*)x, (const _Float16*)rope_table, (_Float16*)rope_cur, rope_rows);
+                       (long long*)token, (int*)pos, (_Float16*)x, (const _Float16*)rope_table, (_Float16*)rope_cur, rope_rows, (const int*)suppress);
     return hipGetLastError();
 }
 

@@ -65,12 +65,23 @@ struct GemvKArgs {
     const void* residual[GEMV_MAX_SEG];
     void* y[GEMV_MAX_SEG];
     int y_stride[GEMV_MAX_SEG];
+    float* sums_out;                       // (5 .. 8-row kernels, one segment) per-row-tile sums of squares of the rows written: [M][sums_stride], or null
+    int sums_stride;                       // = N / 16
 #ifdef AMQ_STAMP
     unsigned long long* stamps;
 #endif
 };
 
-struct SegOut { const _Float16* bias; const _Float16* residual; _Float16* y; int y_stride; };
+struct SegOut { const _Float16* bias; const _Float16* residual; _Float16* y; int y_stride; float* sums; int sums_stride; };
+
+// sum over the 16 lanes of a DPP row (every lane of the row gets it; fixed order)
+__device__ __forceinline__ float row16_total(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
+}
 
 // register-resident view of the launch-wide arguments (built from the preloaded kernel arguments)
 struct GemvHot {
@@ -238,7 +249,8 @@ __device__ __forceinline__ void stage_x(const GemvHot& a, _Float16* xl, float* x
 // in issue order, so staging behind the primed weight tiles (the previous arrangement) made every workgroup wait
 // for its first tiles -- 2-4 us under load (profiles/r01b_gemv_stamps.txt) -- before x could be written to LDS.
 constexpr int XC_MAX = 4;            // 16-byte chunks of x per thread held in registers at most (K <= 32 * threads)
-struct XRegs { h8 v[XC_MAX]; h8 w[XC_MAX]; };   // w: up (SiLU*mul) or gamma (RMSNorm)
+constexpr int SUMS_PER_LANE = 8;     // PRO_RMSNORM_SUMS: partial sums of squares a lane fetches for its wave's row (K / 16 <= 512 partials: K <= 8192)
+struct XRegs { union { h8 v[XC_MAX]; float f[4 * XC_MAX]; }; h8 w[XC_MAX]; };   // w: up (SiLU*mul) or gamma (RMSNorm); f: the row's partial sums of squares (PRO_RMSNORM_SUMS)
 // chunks actually held: two only in the 16-wave workgroups (one per CU, 128 VGPRs available); the 8-wave ones must
 // stay under 80 VGPRs for three workgroups per CU, and K <= 4096 needs one chunk per thread there
 template <int NW> struct XCfg { static constexpr int XC = NW == 16 ? 2 : 1; };
@@ -350,13 +362,26 @@ __device__ __forceinline__ void x_dma_rows(const GemvHot& a, _Float16* xl, int x
             if (c < chunks) gv_glds16(row, 16u * (unsigned)c, lds0 + (unsigned)(m * xs) * 2u + (unsigned)(i * THREADS + wave * 64) * 16u);
         }
     }
-    if (PRO == PRO_RMSNORM) {
+    if (PRO == PRO_RMSNORM || PRO == PRO_RMSNORM_SUMS) {
         const int last = chunks - 1;
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             int c = (int)threadIdx.x + i * THREADS;
             c = c < last ? c : last;
             xr.w[i] = *(const h8*)((const _Float16*)a.gamma + 8 * c);
+        }
+    }
+    if (PRO == PRO_RMSNORM_SUMS) {
+        // the rows' sums of squares arrive as K / 16 partials per row (one per row-tile of the launch that wrote x: its epilogue, AMQ_FINISH): wave m
+        // fetches row m's (SUMS_PER_LANE per lane, unconditional -- indices clamped, the surplus zeroed in x_finish_dma) into the registers the one-row
+        // path keeps x in; they are older than the ring's loads, like gamma's
+        const int P = a.K >> 4;
+        const float* ss = (const float*)a.x2 + (size_t)(wave < a.M ? wave : a.M - 1) * P;
+        const int lane = (int)threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < SUMS_PER_LANE; ++j) {
+            const int idx = lane + 64 * j;
+            xr.f[j] = ss[idx < P ? idx : P - 1];
         }
     }
 }
@@ -426,6 +451,36 @@ __device__ __forceinline__ void x_finish_dma(const GemvHot& a, const XRegs& xr, 
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { _Float16 nrm = (_Float16)((float)v[m * XCH + i][e] * rstd); r[e] = xr.w[i][e] * nrm; }
                         *(h8*)(xl + (size_t)m * xs + 8 * c) = r;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    if (PRO == PRO_RMSNORM_SUMS) {
+        // rstd of row `wave` from its partials (fixed order: a lane's SUMS_PER_LANE in index order, then the wave's DPP tree), one barrier, then only the
+        // transform gamma * fp16(x * rstd) on this thread's own chunks of every row -- no pass over x for the statistic, no per-row reduction
+        const int P = a.K >> 4, lane = tid & 63, wave = tid >> 6;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < SUMS_PER_LANE; ++j) s += (lane + 64 * j < P) ? xr.f[j] : 0.f;
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = rsqrtf(MeanDiv(a.K)(s) + a.eps);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < a.M) {
+                const float rstd = red[m];
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) {
+                    const int c = tid + i * THREADS;
+                    if (c < chunks) {
+                        _Float16* p = xl + (size_t)m * xs + 8 * c;
+                        const h8 v = *(const h8*)p;
+                        h8 r;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { _Float16 nrm = (_Float16)((float)v[e] * rstd); r[e] = xr.w[i][e] * nrm; }
+                        *(h8*)p = r;
                     }
                 }
             }
@@ -538,7 +593,8 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int G = a.K >> 7;
     const int r = lane & 15, o = lane >> 4;
-    static_assert(PH == 1 || (RS != 256 && PRO != PRO_RMSNORM && MATH != MATH_LINEAR && MATH != MATH_DOT), "K phases: the row kernels, no full-row statistic");
+    static_assert(PH == 1 || (RS != 256 && PRO != PRO_RMSNORM && PRO != PRO_RMSNORM_SUMS && MATH != MATH_LINEAR && MATH != MATH_DOT), "K phases: the row kernels, no full-row statistic");
+    static_assert(PRO != PRO_RMSNORM_SUMS || (RS == 128 && MATH == MATH_EXACT && GP == 1), "partial-sum RMSNorm: the 5 .. 8-row kernels");
     const int Gp = G / PH;                                        // tiles of one K phase of a row-tile
     const int nt = (Gp - wave + NW - 1) / NW;                     // tiles of one (row-tile, phase) owned by this wave: g = phase * Gp + wave + i*NW
     // this workgroup's row-tiles: rt0 .. rt0 + n_my - 1 (contiguous bytes).  seg_split = gemv_split(): the segment's first `rem` workgroups walk
@@ -609,6 +665,8 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     so.residual = (const _Float16*)blk.residual[sidx];
     so.y = (_Float16*)blk.y[sidx];
     so.y_stride = blk.y_stride[sidx];
+    so.sums = RS == 128 ? blk.sums_out : nullptr;                // (the 5 .. 8-row kernels: what a PRO_RMSNORM_SUMS launch over y will read)
+    so.sums_stride = blk.sums_stride;
 #ifndef AMQ_ABL_NOSTAGE
     // xmode: 1 = one row held in registers (x_issue ran), 2 = rows on their way into LDS (x_dma_rows ran; the <= 8-row kernels, RS != 256), 0 = generic
     if (xmode == 1) x_finish<PRO, NW, XCH, MATH == MATH_LINEAR>(a, xr, lds_x, xg, red);
@@ -678,6 +736,12 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
             if (SC1) __hip_atomic_store((unsigned short*)(so.y + (size_t)e_m * so.y_stride + rt_ * 16 + e_c),          \
                                         __builtin_bit_cast(unsigned short, y_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
             else so.y[(size_t)e_m * so.y_stride + rt_ * 16 + e_c] = y_;                          \
+            if constexpr (RS == 128) {                        /* sum of squares of this row-tile's 16 values of row e_m (one DPP row: fixed order) */ \
+                if (so.sums) {                                                                   \
+                    const float q_ = row16_total((float)y_ * (float)y_);                         \
+                    if (e_c == 0) so.sums[(size_t)e_m * so.sums_stride + rt_] = q_;              \
+                }                                                                                \
+            }                                                                                    \
         }                                                                                        \
         if (cj / PH + 1 < n_my) AMQ_EPI_PREFETCH(rt_ + 1);                                       \
         par ^= 1;                                                                                \
@@ -908,6 +972,7 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_R(NW, GP, MATH, XCH, RS)) voi
 #endif
     GemvHot a;
     a.x = p_x; a.x2 = p_xw; a.gamma = p_xw;
+    if (PRO == PRO_RMSNORM_SUMS) a.x2 = blk.x2;                   // (gamma arrives preloaded; the partial sums' address is one scalar load from the argument block)
     a.K = p_K; a.M = p_m_nseg & 0xFF; a.rpt = p_rpt; a.eps = p_eps;
     const int nseg = p_m_nseg >> 16;
     const bool dense = (p_m_nseg >> 8) & 1;                       // x rows are K apart: the register-held paths need no argument-block fetch for the stride
@@ -916,6 +981,7 @@ __global__ __launch_bounds__(NW * 64, AMQ_LB_WAVES_R(NW, GP, MATH, XCH, RS)) voi
     int xmode = (a.M == 1 && fits && PH == 1) ? 1 : 0;
     if (RS != 256 && MATH != MATH_LINEAR && fits && dense && a.M >= 2 && a.M <= RowsCfg<RS>::MRMAX) xmode = 2;
     if (PH > 1 && xmode != 2) return;                             // (launch_gemv only sends what the phased form takes)
+    if (PRO == PRO_RMSNORM_SUMS && xmode != 2) return;            // (... and the partial-sum prologue: 5 .. 8 dense rows that fit LDS)
     const bool slow_x = xmode == 0;                               // generic staging path
     a.x_stride = slow_x ? blk.x_stride : a.K;
     const int xs = Kst + XPAD;
@@ -996,7 +1062,7 @@ inline hipError_t launch_one(const GemvKArgs& a, int total_wg, size_t lds, hipSt
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const void* xw = PRO == PRO_SILU_MUL ? a.x2 : a.gamma;
+    const void* xw = PRO == PRO_SILU_MUL ? a.x2 : a.gamma;       // (PRO_RMSNORM_SUMS: gamma; the kernel reads x2 = the partial sums from the block)
     hipLaunchKernelGGL(kern, dim3(total_wg), dim3(NW * 64), lds, st, a.x, xw, a.qweight[0], a.meta[0], a.K,
                        a.M | ((a.x_stride == a.K ? 1 : 0) << 8) | (a.nseg << 16), a.rpt, a.n_rt[0], a.key[0], a.eps, a);
     return hipGetLastError();
@@ -1031,6 +1097,9 @@ inline hipError_t launch_nw(const GemvKArgs& a, int flags, int depth, int total_
     if (flags & GEMV_FLAG_GS) return launch_std<PRO, NW, MATH_GS>(a, flags, total_wg, lds, st);
     return launch_std<PRO, NW, MATH_EXACT>(a, flags, total_wg, lds, st);
 }
+
+// (RMSNorm from partial sums, PRO_RMSNORM_SUMS: its two kernels -- the 5 .. 8-row geometry, RS = 128, default arithmetic -- are instantiated in
+//  amq_gemv_pro3.hip alone; a non-template launcher here would instantiate them in every translation unit that includes this header)
 
 // groups of 64 / 32 (GP = 2 / 4 meta pairs per tile): the default geometry of the exact-math body (two tile loads in flight, generic x staging
 // beyond its register-held chunks)

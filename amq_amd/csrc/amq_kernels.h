@@ -38,7 +38,8 @@ struct StreamDevice {
     StreamDevice& operator=(const StreamDevice&) = delete;
 };
 
-enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILU_MUL = 2 };
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_SILU_MUL = 2,
+       PRO_RMSNORM_SUMS = 3 /* internal (amq_gemv_grouped_sums_f16): RMSNorm whose sums of squares arrive as per-row-tile partials from the launch that produced x */ };
 enum { FMT_HQQ = 0, FMT_GPTQ = 1, FMT_AWQ = 2 };
 constexpr int GEMV_MAX_SEG = 4;
 
@@ -72,6 +73,8 @@ struct GemvArgs {
     int force_depth;       // 0 = auto, else 2 / 4 tile loads in flight per wave
     int force_rpt;         // 0 = auto, else row-tiles per workgroup
     int gp;                // (scale, zero) pairs per (row, tile) of every segment's meta: 0 / 1 (groups of 128), 2 (64), 4 (32)
+    const void* sums_in;   // PRO_RMSNORM_SUMS: fp32 [M][K / 16] partial sums of squares of the x rows (one per 16 columns: what the producing launch's row-tiles left)
+    void* sums_out;        // 5 .. 8-row launches of ONE segment: fp32 [M][N / 16], partial sums of squares of the y rows this launch writes (or null)
 };
 // how a segment's row-tiles are dealt to its workgroups: the first n_rt % wg_count workgroups walk one row-tile more than the others
 // (packed base | rem << 12: base <= 4095 row-tiles per workgroup, rem < 2^19 workgroups -- launch_gemv refuses what does not fit)
@@ -174,7 +177,7 @@ hipError_t launch_rope_rows(void* q, void* k, const void* rope_table, int rope_r
                             int n_kv_heads, hipStream_t st);
 hipError_t launch_silu_mul(const void* gate, const void* up, void* out, long n, hipStream_t st);
 hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, int hidden, void* token, void* pos, void* x,
-                              const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st, int batch = 1);
+                              const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st, int batch = 1, const void* suppress = nullptr);
 hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                             int N, int K, hipStream_t st, int M = 1);      // x [M, K], y [M, N], M <= 8
 

@@ -24,8 +24,18 @@ import weakref
 
 import torch
 
+try:
+    from transformers.modeling_outputs import CausalLMOutputWithPast
+except Exception:                                   # (transformers is needed only once a model is converted)
+    CausalLMOutputWithPast = None
+
 _RUNNERS = weakref.WeakKeyDictionary()      # model -> {batch: QuantLlama}
 _BUCKETS = (256, 512, 1024, 2048, 4096, 8192, 16384, 32768)
+# generation_config fields that make HF add a logits processor / warper / constraint to a greedy run: any of them set -> HF's own generate
+_GC_PROCESSORS = ("repetition_penalty", "encoder_repetition_penalty", "no_repeat_ngram_size", "encoder_no_repeat_ngram_size", "bad_words_ids",
+                  "force_words_ids", "constraints", "forced_bos_token_id", "forced_eos_token_id", "exponential_decay_length_penalty", "suppress_tokens",
+                  "begin_suppress_tokens", "sequence_bias", "guidance_scale", "watermarking_config", "renormalize_logits", "remove_invalid_values",
+                  "penalty_alpha", "dola_layers", "prompt_lookup_num_tokens", "num_beam_groups", "diversity_penalty")
 MAX_BATCH = 8
 
 
@@ -91,10 +101,12 @@ def _fast_forward(self, input_ids=None, attention_mask=None, position_ids=None, 
                              "(no mask with holes, past_key_values, labels, inputs_embeds or extra outputs); drop start_pos for HF's own forward")
         return orig(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, past_key_values=past_key_values,
                     inputs_embeds=inputs_embeds, labels=labels, use_cache=use_cache, **kwargs)
-    from transformers.modeling_outputs import CausalLMOutputWithPast
     B, S = input_ids.shape
     start_pos = int(start_pos)
-    r = _runner(self, B, max(start_pos + S + 1, 2 * (start_pos + S) if start_pos + S <= 2048 else start_pos + S + 1024))
+    # room for the tokens that usually follow (a rebuilt runner re-captures its step): twice the context, at most 1024 more, never past the model's limit
+    limit = int(getattr(self.config, "max_position_embeddings", 1 << 30) or (1 << 30))
+    end = start_pos + S
+    r = _runner(self, B, max(end, min(limit, max(end + 1, 2 * end if end <= 1024 else end + 1024))))
     ids = input_ids if B > 1 else input_ids[0]
     if S == 1 and start_pos == r.host_pos and start_pos > 0:
         r.set_token(input_ids.reshape(-1))
@@ -123,24 +135,31 @@ def _fast_generate(self, inputs=None, generation_config=None, logits_processor=N
     ids = inputs if inputs is not None else kw.pop("input_ids", None)
     if inputs is not None and "input_ids" in kw:
         return fall()
+    gc = getattr(self, "generation_config", None)
     n = kw.pop("max_new_tokens", None)
     nmin = kw.pop("min_new_tokens", None)
-    greedy = kw.pop("do_sample", False) in (False, None) and kw.pop("num_beams", 1) in (1, None)
+    greedy = kw.pop("do_sample", getattr(gc, "do_sample", False)) in (False, None) and kw.pop("num_beams", getattr(gc, "num_beams", 1)) in (1, None)
     mask = kw.pop("attention_mask", None)
+    eos = kw.pop("eos_token_id", getattr(gc, "eos_token_id", None))
+    kw.pop("pad_token_id", None)                             # (fixed-length greedy decoding never pads)
     for k in ("return_dict_in_generate", "output_scores", "output_logits", "output_attentions", "output_hidden_states", "use_cache"):
         if kw.get(k) in (None, False) or (k == "use_cache" and kw.get(k) is True):
             kw.pop(k, None)
     others = [generation_config, logits_processor, stopping_criteria, prefix_allowed_tokens_fn, assistant_model, streamer, negative_prompt_ids,
               negative_prompt_attention_mask, custom_generate]
+    eos = [] if eos is None else ([int(e) for e in eos] if isinstance(eos, (list, tuple)) else [int(eos)])
     if (kw or any(o is not None and (not hasattr(o, "__len__") or len(o)) for o in others) or synced_gpus or not greedy or n is None or nmin != n
-            or not _plain_ids(ids) or not ids.is_cuda or int(n) < 1 or not _mask_is_full(mask, ids)):
+            or not _plain_ids(ids) or not ids.is_cuda or int(n) < 1 or len(eos) > 8 or not _mask_is_full(mask, ids)):
         return fall()
-    gc = getattr(self, "generation_config", None)
-    if gc is not None and (getattr(gc, "do_sample", False) or (getattr(gc, "num_beams", 1) or 1) != 1 or getattr(gc, "repetition_penalty", None) not in (None, 1.0)):
-        return fall()                                        # (the model's own defaults ask for something else than plain greedy)
+    # the model's own generation defaults must ask for plain greedy decoding too (any logits processor HF would add changes the tokens)
+    if gc is not None and any(getattr(gc, k, None) not in (None, False, 0, 1, 1.0, [], ()) for k in _GC_PROCESSORS):
+        return fall()
     B, S = ids.shape
     n = int(n)
     r = _runner(self, B, S + n)
+    # min_new_tokens = max_new_tokens: HF never lets an EOS id through (MinNewTokensLengthLogitsProcessor sets their logits to -inf on every step)
+    if tuple(eos) != getattr(r, "_suppressed", ()):
+        r.set_suppressed(eos)
     new = r.generate(ids if B > 1 else ids[0], n)
     return torch.cat([ids, new.view(B, n).to(ids.dtype)], dim=1)
 

@@ -58,6 +58,47 @@ def _synthetic_linear(n, k, bits, gen, device, group=128):
     return _Lin(qn, meta.reshape(-1).contiguous(), bits, ops.MODE_HQQ, n, k)
 
 
+_GRAPH_STATE_PRIMED = set()
+
+
+class _no_gc:
+    """no cyclic garbage collection while a hipGraph is being captured: a collection that happens to run inside the capture may finalise a DEAD runner
+    (HF models sit in reference cycles: they die only when the collector runs) -- its hipGraph and pool memory are then destroyed in the middle of the
+    stream capture, which HIP answers by aborting the process.  (``torch.cuda.graph`` collects once on entry; this keeps it from happening again
+    before the capture has ended.)"""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
+def _prime_graph_state(dev):
+    """torch allocates the per-device tensors its hipGraph captures keep the RNG seed / offset in at the FIRST capture, in whatever mode is current, and
+    updates them in place at every later capture.  A first capture under ``torch.inference_mode()`` (the reference's harness decorates every loop with
+    it, amq/utils/speed.py:14, 21, 49, 129) makes them inference tensors, and the next capture outside it raises "Inplace update to inference tensor":
+    one empty capture outside inference mode, once per device, before any runner captures."""
+    key = (dev.type, dev.index)
+    if key in _GRAPH_STATE_PRIMED or dev.type != "cuda":
+        return
+    with torch.inference_mode(False):
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            keep = torch.zeros(1, device=dev)
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                keep += 1
+        side.synchronize()
+    _GRAPH_STATE_PRIMED.add(key)
+
+
 class QuantLlama:
     # decode steps run as ONE persistent launch per token (ops.DecodeEngine) when the runner is batch 1 and its KV cache is in the
     # single-workgroup-per-head attention regime (the same bound as ops.ATTN_SPLIT_FROM); otherwise, and with engine=False, as
@@ -69,6 +110,7 @@ class QuantLlama:
     DOWN_FUSED_ROWS = 1
     # rows up to which the two RMSNorms stay fused into the q/k/v and gate/up launches (beyond: one rmsnorm launch + the grouped GEMV without a prologue)
     NORM_FUSED_ROWS = 4
+    NORM_SUMS = True            # (A/B switch of the partial-sum RMSNorm at 5 .. 8 rows: False = one rmsnorm launch per norm)
     # q/k/v + attention of a block as ONE launch (ops.gemv_qkv_attn; batch 1, short cache, hidden <= 8192): 4 launches per block
     # instead of 5.  Built, bit-identical (tests/test_gpu_qkv_attn.py) and SLOWER -- 15.7 us per fused launch against 9.2 + 5.1,
     # 755 vs 830 tokens/s (profiles/r03_qkv_attn_fused_negative.txt) -- so it is off unless a caller sets fuse_qkv_attn.
@@ -98,6 +140,7 @@ class QuantLlama:
         self.B = int(batch)
         self.cfg = config
         self.dev = torch.device(device)
+        _prime_graph_state(self.dev)
         self.H = config["hidden_size"]
         self.I = config["intermediate_size"]
         self.nh, self.nkv = config["num_heads"], config["num_kv_heads"]
@@ -188,6 +231,9 @@ class QuantLlama:
         self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
         self.host_pos = 0          # host mirror of self.pos (decode_step refuses to run past the cache without a device sync)
+        # token ids the greedy choice never takes (8 slots, -1 = unused; read by the step's tail kernel): what HF's min_new_tokens does to the EOS ids
+        # (set_suppressed; the values may change between replays of the captured step)
+        self.suppress = torch.full((8,), -1, dtype=torch.int32, device=dev)
         self.has_bias = any(blk[n].bias is not None for blk in self.blocks for n in config["linear"])
         # down_proj's launch: the GEMV with the fused SiLU*mul prologue while the rows' x fits LDS whole; past that (7B: 7 - 8 rows of 11008) one
         # silu_mul launch + the GEMV without a prologue, x staged in two K phases (fusing the prologue there would make every workgroup take in gate
@@ -197,6 +243,11 @@ class QuantLlama:
         self.can_fuse_qkv_attn = self.B == 1 and max_seq <= ops.ATTN_SPLIT_FROM and self.H <= 8192 and not self.fine and not self.has_bias
         self.fuse_qkv_attn = self.FUSE_QKV_ATTN and self.can_fuse_qkv_attn
         self._tickets = torch.zeros(max(self.nh, 64), dtype=torch.int32, device=dev)
+        # 5 .. 8 sequences: the RMSNorms ride on per-row-tile sums of squares that o_proj / down_proj leave in their epilogues (ops.gemv_grouped_sums:
+        # no pass over x for the statistic, no rmsnorm launch); the first norm of block 0 (its x comes from the embedding) stays a launch
+        self._norm_sums = (self.NORM_SUMS and self.NORM_FUSED_ROWS < self.B <= 8 and not self.fine and 2048 <= self.H <= 8192 and self.I >= 2048
+                           and self.B <= ops.gemv_max_rows(self.H, plain=True))
+        self.ss = torch.zeros(self.B, self.H // 16, dtype=torch.float32, device=dev) if self._norm_sums else None
         eligible = self.B == 1 and max_seq <= self.ENGINE_MAX_SEQ and self.H == self.nh * 128 and not self.fine and not self.has_bias
         if engine and not eligible:
             raise ValueError("the decode engine needs batch 1 and max_seq <= %d" % self.ENGINE_MAX_SEQ)
@@ -294,8 +345,9 @@ class QuantLlama:
         if self.engine is not None:
             self.engine.step()
             ops.gemv_f16w(self.x.reshape(-1), self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
-            ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
+            ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur, suppress=self.suppress)
             return
+        have_sums = False                       # self.ss holds the sums of squares of self.x's rows (written by the launch that produced them)
         for blk in self.blocks:
             if self.fuse_qkv_attn:
                 ops.gemv_qkv_attn(self.x, [blk["self_attn.q_proj"].seg(self.q.view(-1)), blk["self_attn.k_proj"].seg(self.k.view(-1)),
@@ -303,14 +355,23 @@ class QuantLlama:
                                   self.att.view(-1), self.rope_cur, self.nh, self.nkv, self._tickets)
             else:
                 qkv = [blk["self_attn.q_proj"].seg(self.q), blk["self_attn.k_proj"].seg(self.k), blk["self_attn.v_proj"].seg(self.v)]
-                if self.B > self.NORM_FUSED_ROWS:
+                if self._norm_sums and have_sums:
+                    ops.gemv_grouped_sums(self.x, qkv, H, gamma=blk["ln1"], eps=self.eps, sums_in=self.ss)
+                elif self.B > self.NORM_FUSED_ROWS:
                     ops.gemv_grouped(ops.rmsnorm(self.x, blk["ln1"], self.eps, out=self.xn), qkv, H)
                 else:
                     ops.gemv_grouped(self.x, qkv, H, prologue=ops.PRO_RMSNORM, gamma=blk["ln1"], eps=self.eps)
                 ops.attn_decode(self.q, self.k, self.v, blk["kc"], blk["vc"], self.att, self.pos, self.nh, self.nkv, self.theta,
                                 cur=self.rope_cur)
-            ops.gemv_grouped(self.att, [blk["self_attn.o_proj"].seg(self.x, residual=self.x)], H)
-            if self.B > self.NORM_FUSED_ROWS:
+            if self._norm_sums:
+                ops.gemv_grouped_sums(self.att, [blk["self_attn.o_proj"].seg(self.x, residual=self.x)], H, sums_out=self.ss)
+                ops.gemv_grouped_sums(self.x, [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H,
+                                      gamma=blk["ln2"], eps=self.eps, sums_in=self.ss)
+            else:
+                ops.gemv_grouped(self.att, [blk["self_attn.o_proj"].seg(self.x, residual=self.x)], H)
+            if self._norm_sums:
+                pass                            # (gate / up were launched above, behind o_proj's sums)
+            elif self.B > self.NORM_FUSED_ROWS:
                 ops.gemv_grouped(ops.rmsnorm(self.x, blk["ln2"], self.eps, out=self.xn), [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H)
             else:
                 ops.gemv_grouped(self.x, [blk["mlp.gate_proj"].seg(self.gate), blk["mlp.up_proj"].seg(self.up)], H,
@@ -318,14 +379,36 @@ class QuantLlama:
             if self._down_rows_fit:
                 ops.gemv_grouped(self.gate, [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I,
                                  prologue=ops.PRO_SILU_MUL, x2=self.up)
+            elif self._down_rows_phased and self._norm_sums:
+                ops.gemv_grouped_sums(ops.silu_mul(self.gate, self.up, out=self.gate), [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I,
+                                      sums_out=self.ss)
+                have_sums = True
             elif self._down_rows_phased:
                 ops.gemv_grouped(ops.silu_mul(self.gate, self.up, out=self.gate), [blk["mlp.down_proj"].seg(self.x, residual=self.x)], self.I)
             else:       # batch x intermediate size past the GEMV kernel's LDS stage: few-row MFMA kernel
                 d = blk["mlp.down_proj"]
                 ops.gemm(ops.silu_mul(self.gate, self.up, out=self.gate), d.qn, d.mn, d.bits, d.mode, d.N, d.K, bias=d.bias, residual=self.x, out=self.x)
+                have_sums = False
         ops.gemv_f16w(self.x.reshape(-1) if self.B == 1 else self.x, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         # argmax, pos += 1, x = embed[token], rope_cur = cos/sin row of the new position (per sequence; the position is shared)
-        ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
+        ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur, suppress=self.suppress)
+
+    def set_suppressed(self, ids=()):
+        """token ids greedy decoding must not pick (at most 8; () = none): HF's generate(min_new_tokens = max_new_tokens) never emits an EOS id.
+        Takes effect from the next step / prompt pass, captured or not."""
+        ids = [int(i) for i in ids]
+        if len(ids) > 8:
+            raise ValueError("at most 8 suppressed token ids")
+        self.suppress.copy_(torch.tensor(ids + [-1] * (8 - len(ids)), dtype=torch.int32))
+        self._suppressed = tuple(ids)
+
+    def _argmax(self, logits, dim, keepdim=False):
+        """arg-max over the vocabulary (the last dimension) of a prompt pass with the suppressed ids left out, as the captured step's tail kernel
+        does; no host synchronisation (unused slots are pointed at a spare element behind the vocabulary)"""
+        assert dim in (-1, logits.dim() - 1)
+        m = torch.zeros(self.vocab + 1, dtype=torch.float32, device=logits.device)
+        m.index_fill_(0, torch.where(self.suppress >= 0, self.suppress, self.vocab).to(torch.int64), float("-inf"))
+        return torch.argmax(logits.float() + m[:self.vocab], dim=dim, keepdim=keepdim)
 
     def set_pos(self, pos):
         """set the position of the next decode step (device state + its host mirror); follow with set_token()"""
@@ -374,7 +457,7 @@ class QuantLlama:
             side.synchronize()
             self.pos.copy_(saved[1]); self.set_token(saved[0])
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            with _no_gc(), torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 self._step()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
@@ -431,7 +514,7 @@ class QuantLlama:
                 self._prefill_rows(static_ids, start_pos)      # warm-up outside capture (allocator, lazy init)
                 side.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                with _no_gc(), torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     self._prefill_rows(static_ids, start_pos)
             torch.cuda.current_stream(self.dev).wait_stream(side)
             ent = cache[(S, start_pos)] = (g, static_ids, self.__dict__.get("logits_rows"))
@@ -458,11 +541,12 @@ class QuantLlama:
             return self._prefill_eager(ids[0], start_pos)
         B, S = ids.shape
         last = self._rows_pass(ids, start_pos, cache=True)
-        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         if self.all_logits:
             self.logits_rows = self._logits_of_rows(self.__dict__.pop("_rows_x"), B, S, self.logits)
+        else:
+            ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         self.set_pos(start_pos + S)
-        self.set_token(torch.argmax(self.logits, dim=1))
+        self.set_token(self._argmax(self.logits, 1))
         return self.logits
 
     def _rows_pass(self, ids, start_pos, cache):
@@ -493,10 +577,20 @@ class QuantLlama:
         return x.view(B, S, H)[:, S - 1].contiguous()
 
     def _logits_of_rows(self, x, B, S, last_logits):
-        """logits of every prompt row, [B, S, vocab] fp16: final RMSNorm + one fp16 GEMM against the lm_head; each sequence's LAST row is the
-        weight-streaming kernel's result (what the decode steps and the runner's own token choice use), so that the two agree bit for bit"""
-        rows = ops.gemm_f16w(ops.rmsnorm(x, self.norm, self.eps), self.lm_head).view(B, S, self.vocab)
-        rows[:, S - 1].copy_(last_logits.view(B, self.vocab))
+        """logits of every prompt row, [B, S, vocab] fp16: final RMSNorm + ONE pass over the lm_head for all rows (fp16 MFMA GEMM); each sequence's
+        last row is copied into ``last_logits`` (the runner's token choice), instead of a second pass over the lm_head for it"""
+        if self.vocab % 16 == 0:
+            rows = ops.gemm_f16w(ops.rmsnorm(x, self.norm, self.eps), self.lm_head).view(B, S, self.vocab)
+        else:                                   # (the fp16 GEMM writes 16-column blocks; odd vocabularies -- test models -- go through the weight-streaming kernel, 8 rows a launch)
+            rows = torch.empty(B * S, self.vocab, dtype=torch.float16, device=x.device)
+            for r0 in range(0, B * S, 8):
+                r1 = min(B * S, r0 + 8)
+                if r1 - r0 == 1:
+                    ops.gemv_f16w(x[r0], self.lm_head, gamma=self.norm, eps=self.eps, out=rows[r0])
+                else:
+                    ops.gemv_f16w(x[r0:r1], self.lm_head, gamma=self.norm, eps=self.eps, out=rows[r0:r1])
+            rows = rows.view(B, S, self.vocab)
+        last_logits.view(B, self.vocab).copy_(rows[:, S - 1])
         return rows
 
     # prompt rows (exclusive, inclusive) served by the fragment-ordered few-row kernels with q/k/v and gate/up as grouped
@@ -614,11 +708,12 @@ class QuantLlama:
         if b is not None:                       # one sequence of a batch: its logits row; the caller sets position and tokens
             ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits[b])
             return self.logits[b]
-        ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         if self.all_logits:
             self.logits_rows = self._logits_of_rows(x, 1, S, self.logits)
+        else:
+            ops.gemv_f16w(last, self.lm_head, gamma=self.norm, eps=self.eps, out=self.logits)
         self.set_pos(start_pos + S)
-        self.set_token(torch.argmax(self.logits, dim=0, keepdim=True))
+        self.set_token(self._argmax(self.logits, 0, keepdim=True))
         return self.logits
 
     def _prefill_unfused(self, ids):
@@ -686,6 +781,7 @@ class DenseLlama(QuantLlama):
     def _dense_init(self, config, device, max_seq, seed):
         self.cfg = config
         self.dev = torch.device(device)
+        _prime_graph_state(self.dev)
         self.H, self.I = config["hidden_size"], config["intermediate_size"]
         self.nh, self.nkv = config["num_heads"], config["num_kv_heads"]
         self.kvd = self.nkv * 128
@@ -720,6 +816,7 @@ class DenseLlama(QuantLlama):
         self.rope_cur.copy_(self.rope_tab.view(max_seq, 128)[0])
         self.graph = None
         self.host_pos = 0
+        self.suppress = torch.full((8,), -1, dtype=torch.int32, device=dev)
         self.engine = None           # (the one-launch-per-token engine serves the quantized runner only)
 
     def linear_bytes_per_token(self):
@@ -740,7 +837,7 @@ class DenseLlama(QuantLlama):
                              blk["mlp.down_proj"])
         ops.gemv_f16w(x.reshape(-1).contiguous() if self.B == 1 else x.contiguous(), self.lm_head, gamma=self.norm, eps=self.eps,
                       out=self.logits)
-        ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
+        ops.decode_tail(self.logits, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur, suppress=self.suppress)
 
     def _rows_linear(self, w, inp, residual=None):
         if residual is None:

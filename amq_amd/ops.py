@@ -550,6 +550,34 @@ def gemv_grouped(x, segments, K, prologue=PRO_NONE, x2=None, gamma=None, eps=0.0
 
 
 # ---------------------------------------------------------------- decode-step surroundings
+def gemv_grouped_sums(x, segments, K, gamma=None, eps=0.0, sums_in=None, sums_out=None):
+    """5 .. 8 rows: :func:`gemv_grouped` whose RMSNorm takes the rows' sums of squares as per-16-column partials (``sums_in`` fp32 [M, K / 16], with
+    ``gamma``) from the launch that produced x, and / or that leaves such partials of ITS output rows in ``sums_out`` (fp32 [M, N / 16]; one segment):
+    include/amq_hip.h amq_gemv_grouped_sums_f16.  No pass over x for the statistic, no separate rmsnorm launch."""
+    xx = _prep_x(x, K)
+    M = xx.shape[0]
+    if not 1 <= len(segments) <= _lib.MAX_SEGMENTS:
+        raise ValueError(f"1..{_lib.MAX_SEGMENTS} segments")
+    arr = (Segment * len(segments))()
+    for i, s in enumerate(segments):
+        _check_shape(s["bits"], s["N"], K)
+        _check_native(s["qn"], s["mn"], s["bits"], s["N"], K)
+        _need(s["y"], torch.float16, "y", M * s["N"])
+        if s.get("bias") is not None:
+            _need(s["bias"], torch.float16, "bias", s["N"])
+        if s.get("residual") is not None:
+            _need(s["residual"], torch.float16, "residual", M * s["N"])
+        arr[i] = Segment(_lib.ptr(s["qn"]), _lib.ptr(s["mn"]), _lib.ptr(s.get("bias")), _lib.ptr(s.get("residual")),
+                         _lib.ptr(s["y"]), s["N"], s["bits"], s["mode"], 0)
+    if sums_in is not None:
+        _need(gamma, torch.float16, "gamma", K)
+        _need(sums_in, torch.float32, "sums_in", M * (K // 16))
+    if sums_out is not None:
+        _need(sums_out, torch.float32, "sums_out", M * (segments[0]["N"] // 16))
+    _lib.check(_lib.load().amq_gemv_grouped_sums_f16(arr, len(segments), _lib.ptr(xx), _lib.ptr(gamma) if sums_in is not None else None,
+                                                     ctypes.c_float(eps), _lib.ptr(sums_in), _lib.ptr(sums_out), M, K, GROUP, _lib.current_stream()))
+
+
 def rmsnorm(x, gamma, eps, out=None):
     K = x.shape[-1]
     x2 = _prep_x(x, K)
@@ -586,9 +614,10 @@ def gemv_f16w(x, W, bias=None, gamma=None, eps=0.0, out=None):
     return y
 
 
-def decode_tail(logits, embed, token, pos, x, table=None, cur=None):
+def decode_tail(logits, embed, token, pos, x, table=None, cur=None, suppress=None):
     """token = argmax(logits), pos += 1, x = embed[token] (and cur = table[pos], the next step's cos/sin row) -- one
-    launch (graph-capturable).  Batched decode: logits [B, vocab], token [B], x [B, hidden]; pos / cur advance once."""
+    launch (graph-capturable).  Batched decode: logits [B, vocab], token [B], x [B, hidden]; pos / cur advance once.
+    suppress: int32 [8] device tensor of token ids never chosen (-1 = unused slot): HF's min_new_tokens treatment of the EOS ids."""
     vocab, hidden = embed.shape
     B = token.numel()
     _need(logits, torch.float16, "logits", B * vocab)
@@ -601,6 +630,11 @@ def decode_tail(logits, embed, token, pos, x, table=None, cur=None):
         _need(table, torch.float16, "rope table")
     tab = _lib.ptr(table) if cur is not None else None
     rows = table.numel() // 128 if cur is not None else 0
+    if suppress is not None:
+        _need(suppress, torch.int32, "suppress", 8)
+        _lib.check(_lib.load().amq_decode_tail_suppress_f16(_lib.ptr(logits), vocab, _lib.ptr(embed), hidden, _lib.ptr(token), _lib.ptr(pos),
+                                                            _lib.ptr(x), tab, _lib.ptr(cur), rows, B, _lib.ptr(suppress), _lib.current_stream()))
+        return
     if B == 1:
         _lib.check(_lib.load().amq_decode_tail_f16(_lib.ptr(logits), vocab, _lib.ptr(embed), hidden, _lib.ptr(token), _lib.ptr(pos),
                                                    _lib.ptr(x), tab, _lib.ptr(cur), rows, _lib.current_stream()))

@@ -81,7 +81,7 @@ def pin_rank_cpus(local_rank=None, n_ranks=None):
     return cpus
 
 
-def launch_local(n, argv, env=None, timeout=None):
+def launch_local(n, argv, env=None, timeout=None, sys_root="/sys"):
     """Start ``n`` ranks of ``argv`` (a full command line) as fresh child processes of THIS process, one per GPU:
     RANK / LOCAL_RANK / WORLD_SIZE (and the rendezvous, below) are set per child, stdout / stderr are inherited (rank 0
     prints the result line).  The caller must not have touched the GPU: children are started with Popen, never by
@@ -89,7 +89,8 @@ def launch_local(n, argv, env=None, timeout=None):
     are terminated by PID.
     Rendezvous: a FILE store in a fresh private directory (AMQ_RENDEZVOUS_FILE, read by :class:`Replicas`) -- no TCP port is
     picked here, so there is no window in which another process can take it between the probe and rank 0's bind.
-    CPU placement: rank r runs on :func:`rank_cpu_set` (r, n) -- disjoint core sets, each inside the NUMA node of GPU r where sysfs says which."""
+    CPU placement: rank r runs on :func:`rank_cpu_set` (r, n) -- disjoint core sets, each inside the NUMA node of GPU r where sysfs says which
+    (``sys_root``: where to read the topology from; tests hand in a made-up tree)."""
     rdv_dir = tempfile.mkdtemp(prefix="amq_rdv_")
     rdv = os.path.join(rdv_dir, "store")
     procs = []
@@ -101,7 +102,7 @@ def launch_local(n, argv, env=None, timeout=None):
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # each rank is bound to the cores of its GPU's NUMA node (its even share of them) BEFORE its interpreter starts: threads torch / the HIP
         # runtime create later inherit the mask
-        cpus = rank_cpu_set(r, n, allowed) if n > 1 else None
+        cpus = rank_cpu_set(r, n, allowed, sys_root) if n > 1 else None
         procs.append(subprocess.Popen(list(argv), env=e, preexec_fn=(lambda c=cpus: os.sched_setaffinity(0, c)) if cpus else None))
     t_end = None if timeout is None else time.monotonic() + timeout
     rc, live = 0, list(procs)

@@ -165,6 +165,23 @@ def beyond_the_metric(dev):
                 "gbps": round(roof["gbps"], 1), "linear_gb_per_token": round(m.linear_bytes_per_token() / 1e9, 2), "bits_usage": round(usage, 3),
                 "steps": 24, "warmup": 8, "config": "BASELINE.json configs[4], one of its 8 independent streams"}
 
+    def family(model):
+        # the reference's other model families (README.md:90-92; amq/configs/llama.json:82+, mistral.json, qwen2.json) through the same runner: avg-3-bit
+        # arch, batch-1 decode after a 64-token prompt.  Their vocabularies make the fp16 lm_head a fifth of a token's bytes (128,256 x 4096 x 2 B =
+        # 1.05 GB; 152,064 x 3584 x 2 B = 1.09 GB): reported, and counted in whole_step_gbps
+        def run():
+            m, _, usage = build_model(dev, seed=0, max_seq=PROMPT + 96, model=model, pinned=())
+            tps = _decode_rate(dev, m, PROMPT, 8, 64)
+            roof = gemv_roofline(m, reps=10)
+            step_bytes = m.total_bytes_per_token(PROMPT + 40)
+            return {"tokens_per_s": round(tps, 1), "roofline_frac": round(roof["gbps"] / HBM_PEAK_GBPS, 3), "us_per_launch": round(roof["us_per_launch"], 2),
+                    "linear_gb_per_token": round(m.linear_bytes_per_token() / 1e9, 3), "lm_head_gb_per_token": round(m.lm_head.numel() * 2 / 1e9, 3),
+                    "whole_step_gbps": round(step_bytes * tps / 1e9, 1), "whole_step_frac": round(step_bytes * tps / 1e9 / HBM_PEAK_GBPS, 3),
+                    "bits_usage": round(usage, 3), "finite_logits": bool(torch.isfinite(m.logits.float()).all().item()),
+                    "shape": "hidden %d, mlp %d, %d q / %d kv heads, vocab %d%s%s" % (m.H, m.I, m.nh, m.nkv, m.vocab, ", q/k/v bias" if m.has_bias else "",
+                                                                                       ", llama3 rope scaling" if m.inv_freq is not None else "")}
+        return run
+
     def llama13b():
         # BASELINE.json configs[3] end to end (what `--config 4` prints as its own line): Llama-2-13B, one batched prompt pass of 16 x 2048 rows
         B, S = 16, 2048
@@ -225,6 +242,9 @@ def beyond_the_metric(dev):
     leg("decode_tokens_per_s_groupscale_math", groupscale)
     leg("llama70b_one_replica", llama70b)
     leg("llama13b_prompt_pass", llama13b)
+    leg("llama31_8b", family("Llama-3.1-8B"))
+    leg("qwen25_7b", family("Qwen2.5-7B"))
+    leg("mistral_7b_v03", family("Mistral-7B-v0.3"))
     leg("bf16_variant", bf16_variant)
     return out
 
@@ -645,6 +665,33 @@ def run_gemm_mode(args, rep, dev):
     print(json.dumps(out), flush=True)
 
 
+def rehearse_ranks(args):
+    """``--rehearse-ranks``: everything of an N-rank run EXCEPT the GPU work, on host cores with the gloo backend standing in for RCCL -- the launch path
+    (launch_local or an outer launcher), each rank's CPU placement, the rendezvous, ``rep.timed`` (barrier, max over ranks), the gather of per-rank
+    rates, rank 0 alone printing, the closing barrier.  The step is a 2 ms sleep; the line says so (``rehearsal``: true, ``value``: null): it is a test
+    of the plumbing an 8-GPU node will run (tests/test_replicas_cpu.py), never a number."""
+    import time
+    from amq_amd.replicas import Replicas
+    rep = Replicas(backend="gloo")
+    try:
+        for _ in range(args.warmup):
+            time.sleep(0.002)
+        elapsed = rep.timed(lambda: time.sleep(0.002 * (1 + rep.rank % 2)), args.steps)
+        per_rank = rep.gather(args.steps / rep.last_local)
+        cpus = rep.gather(float(len(os.sched_getaffinity(0))))
+        if rep.rank == 0:
+            print(json.dumps({
+                "metric": "REHEARSAL of the %d-rank plumbing (no GPU work): not a measurement" % rep.world, "value": None, "unit": "tokens/s",
+                "rehearsal": True, "n_gpus": rep.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "scaling": "weak", "data": "none (a 2 ms sleep per step)", "config": {"workload": "BASELINE.json configs[%d] launch path" % (args.config - 1),
+                                                                                         "parallelism": "replicas x%d" % rep.world},
+                "rccl_world_size": rep.live_world_size(), "rccl_backend": rep.live_backend() + " (stand-in for nccl = RCCL)",
+                "per_rank_tokens_per_s": [round(v, 2) for v in per_rank], "per_rank_host_cores": [int(c) for c in cpus]}), flush=True)
+        rep.barrier()
+    finally:
+        rep.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -660,6 +707,9 @@ def main():
     ap.add_argument("--five-launch", action="store_true",
                     help="A/B: decode steps as five launches per block instead of the one-launch-per-token engine")
     ap.add_argument("--no-mfma", action="store_true", help="skip the batched-path (MFMA) roofline and the dequantize rows")
+    ap.add_argument("--rehearse-ranks", action="store_true",
+                    help="NOT a measurement: rehearse the N-rank plumbing of this script on host cores -- launch, CPU placement, gloo rendezvous, barrier / "
+                         "max-over-ranks / gather, rank 0's line -- with a sleep in place of the decode step (no model, no kernels; value is null)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {3: 256, 5: 64}.get(args.config, 3)
@@ -681,6 +731,8 @@ def main():
         # computing the share again over the narrowed mask would divide it among the node's peers a second time
         from amq_amd.replicas import pin_rank_cpus
         pin_rank_cpus()
+    if args.rehearse_ranks:
+        return rehearse_ranks(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     local = int(os.environ.get("LOCAL_RANK", "0"))

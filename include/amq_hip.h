@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define AMQ_VERSION 520            /* 0.5.2: amq_rope_table_freqs_f16 added (rope_scaling), nothing else changed.  0.5.1: the bfloat16 entry points
+#define AMQ_VERSION 520            /* 0.5.2: amq_rope_table_freqs_f16 (rope_scaling) and amq_decode_tail_suppress_f16 added, nothing else changed.  0.5.1: the bfloat16 entry points
                                     * (amq_*_bf16) added.  0.5.0: amq_gemv_opts.math renumbered
                                     * (0 = the build's default), amq_default_gemv_math added; the decode-engine and fused q/k/v-attention entry points live in
                                     * libamq_hip_ab.so (include/amq_hip_ab.h) since 0.4 */
@@ -190,6 +190,17 @@ int amq_gemv_grouped_f16(const amq_segment* segments /* host */, int nseg,
                          const void* x, const void* x2, const void* gamma, float eps, int prologue,
                          int M, int K, int group, int x_stride, const amq_gemv_opts* opts /* host, may be NULL */,
                          void* stream);
+/* 5 .. 8 rows (sequences decoded together), RMSNorm WITHOUT a pass over x for its statistic: a launch that writes a hidden state (o_proj, down_proj:
+ * ONE segment, residual in the epilogue) also leaves, per row, one sum of squares per 16 output columns in sums_out (fp32 [M][N / 16], written
+ * whole by every launch); the launch that normalises that hidden state takes them as sums_in (fp32 [M][K / 16]) with gamma and eps, adds them
+ * in a fixed order and only applies gamma * fp16(x * rstd) while staging x -- LlamaRMSNorm's value up to the summation order of its fp32
+ * mean (the fused AMQ_PRO_RMSNORM prologue repeats the whole statistic in every workgroup: at 5 .. 8 rows that costs more than a separate
+ * amq_rmsnorm_f16 launch; this form costs less than either).  sums_in == NULL: no prologue (then gamma must be NULL too); sums_out == NULL: none
+ * written.  x dense [M][K], groups of 128, default arithmetic; K <= 8192 with sums_in.  Replaces layernorm.cu:25-51 + the GEMV behind it in the
+ * reference's FT step (ftllama_modeling.py:39-46) for Batch 5 .. 8 (gemv_cuda.cu:381-437 makes batches first-class). */
+int amq_gemv_grouped_sums_f16(const amq_segment* segs, int nseg, const void* x, const void* gamma, float eps, const float* sums_in,
+                              float* sums_out, int M, int K, int group, void* stream);
+
 
 /* ---- entry points shaped like the reference's pybind functions ------------------------------------
  * They take the reference's own buffers (Format B / Format C) unchanged.  The HIP kernels read the native layout,
@@ -278,6 +289,11 @@ int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hi
                         const void* rope_table, void* rope_cur, int rope_rows, void* stream);
 /* Batched decode (several sequences at the SAME position, one step state): logits fp16 [batch, vocab], token int64 [batch],
  * x fp16 [batch, hidden]; pos / rope_cur are advanced once. */
+/* The same with up to 8 token ids that are never chosen: suppress_ids = device int32 [8], -1 = unused slot (the values may change between replays
+ * of a captured step; the pointer may not).  What HF's MinNewTokensLengthLogitsProcessor does to the EOS ids while min_new_tokens has not been
+ * reached -- generate(min_new_tokens = max_new_tokens = n), amq/utils/speed.py:31-36 -- i.e. on every step of the reference's TPS loop. */
+int amq_decode_tail_suppress_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
+                                 const void* rope_table, void* rope_cur, int rope_rows, int batch, const int* suppress_ids, void* stream);
 int amq_decode_tail_batch_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
                               const void* rope_table, void* rope_cur, int rope_rows, int batch, void* stream);
 

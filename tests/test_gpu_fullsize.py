@@ -14,6 +14,11 @@ SHAPES = [  # (N, K) from amq/configs/llama.json linear_shape
     (4096, 4096), (11008, 4096), (4096, 11008),            # 7B
     (5120, 5120), (13824, 5120), (5120, 13824),            # 13B
     (8192, 8192), (1024, 8192), (28672, 8192), (8192, 28672),   # 70B
+    # the reference's other families (amq/configs/llama.json:82+, mistral.json, qwen2.json)
+    (14336, 4096), (4096, 14336), (1024, 4096),            # Llama-3.x-8B / Mistral-7B (GQA 4: k/v 1024 x 4096)
+    (3584, 3584), (512, 3584), (18944, 3584), (3584, 18944),    # Qwen2.5-7B (GQA 7, hidden 28 x 128)
+    (27648, 5120), (5120, 27648),                          # Qwen2.5-32B
+    (29568, 8192), (8192, 29568),                          # Qwen2.5-72B
 ]
 
 
@@ -188,13 +193,15 @@ def test_fullsize_reference_formats_fma_arithmetic(fmt, bits, n, k):
         assert mod.mode in (ops.MODE_FMA, ops.MODE_FMA1) and torch.equal(mod(x), y)
 
 
-@pytest.mark.parametrize("bits,n,k", [(3, 13824, 5120), (4, 5120, 13824), (2, 1024, 8192), (3, 8192, 28672)])
+@pytest.mark.parametrize("bits,n,k", [(3, 13824, 5120), (4, 5120, 13824), (2, 1024, 8192), (3, 8192, 28672),
+                                      (3, 14336, 4096), (2, 4096, 14336), (4, 18944, 3584), (3, 3584, 18944), (2, 512, 3584), (3, 29568, 8192)])
 def test_13b_70b_shapes_meet_the_oracle_directly(bits, n, k):
     """VERDICT r4 (parity soft spot): "no 13B / 70B shape ever meets the oracle directly" -- the property tests above trust the HIP dequantize
     kernel.  Here one layer per large shape class (13B gate_proj and down_proj, 70B GQA k_proj and down_proj: 28672 columns) goes through the
     ORACLE on the host (numpy restatement of Quantizer.dequantize, hqq/core/quantize.py:184-199; ~20 s for the 235 M weights of the last case):
     the repacked payload dequantizes to the oracle's weights bit for bit, and the GEMV (1 and 5 rows) and the few-row GEMM (40 rows) match
-    nn.Linear on those weights within the bar."""
+    nn.Linear on those weights within the bar.  Round 6: the shape classes of the reference's other families too -- Llama-3.x / Mistral
+    (14336-wide MLP), Qwen2.5-7B (K = 3584 = 28 x 128, 18944-wide MLP, 512-row k/v), Qwen2.5-72B (29568 x 8192)."""
     import numpy as np
     from amq_amd import ops
     from amq_amd.hqq_format import random_hqq
@@ -215,3 +222,77 @@ def test_13b_70b_shapes_meet_the_oracle_directly(bits, n, k):
         y = (ops.gemv(xg, qn, mn, bits, ops.MODE_HQQ, n, k) if few else ops.gemm(xg, qn, mn, bits, ops.MODE_HQQ, n, k)).float().cpu().numpy()
         rms = float(np.sqrt(np.mean(y_ref.astype(np.float64) ** 2)))
         assert np.all(np.abs(y - y_ref) <= 1e-3 * np.abs(y_ref) + 1e-3 * rms), (rows, float(np.abs(y - y_ref).max()))
+
+
+@pytest.mark.parametrize("name", ["Llama-3.1-8B", "Mistral-7B-v0.3", "Qwen2.5-7B"])
+def test_family_block_at_real_width(name):
+    """One decoder block of the reference's other families at the models' REAL widths and vocabularies (Llama-3.1-8B: 14336-wide MLP, GQA 4,
+    llama3 rope scaling, 128,256 tokens; Mistral-7B-v0.3: theta 1e6, 32,768 tokens; Qwen2.5-7B: hidden 3584, GQA 7, q / k / v bias, eps 1e-6,
+    152,064 tokens): the runner's prompt pass and captured token step against the same block computed with torch ops on the weights the
+    bit-exact dequantize kernel returns (HF's formulas: fp32 norm statistics, fp16 rotation from the fp32 cos / sin of the rotary embedding's
+    own frequencies, softmax in fp32)."""
+    from amq_amd import arch, ops
+    from amq_amd.llama import QuantLlama
+    dev = torch.device("cuda:0")
+    cfg = dict(arch.MODEL_CONFIGS[name])
+    cfg["n_block"] = 1
+    al = {n_: [b] for n_, b in zip(cfg["linear"], [4, 2, 3, 3, 2, 4, 3])}
+    m = QuantLlama(cfg, al, max_seq=640, seed=3)
+    assert (m.inv_freq is not None) == (name == "Llama-3.1-8B") and m.has_bias == (name == "Qwen2.5-7B")
+    blk = m.blocks[0]
+    W = {n_: ops.dequantize(blk[n_].qn, blk[n_].mn, blk[n_].bits, blk[n_].mode, blk[n_].N, blk[n_].K).float() for n_ in cfg["linear"]}
+    H, nh, nkv, eps = m.H, m.nh, m.nkv, m.eps
+    inv = m.inv_freq.to(dev) if m.inv_freq is not None else 1.0 / (m.theta ** (torch.arange(0, 128, 2, device=dev).float() / 128))
+
+    def lin(x, n_):
+        y = (x.float() @ W[n_].t()).half()
+        return y if blk[n_].bias is None else y + blk[n_].bias
+
+    def norm(x, g):
+        xf = x.float()
+        return g * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).half()
+
+    def rope(t, pos):
+        fr = pos.float()[:, None] * inv[None, :]
+        emb = torch.cat([fr, fr], -1)
+        cos, sin = emb.cos().half()[:, None, :], emb.sin().half()[:, None, :]
+        return t * cos + torch.cat([-t[..., 64:], t[..., :64]], -1) * sin
+
+    def reference(ids, pos0=0):
+        S = ids.numel()
+        x = m.embed[ids]
+        pos = torch.arange(pos0, pos0 + S, device=dev)
+        h = norm(x, blk["ln1"])
+        q = rope(lin(h, "self_attn.q_proj").view(S, nh, 128), pos)
+        k = rope(lin(h, "self_attn.k_proj").view(S, nkv, 128), pos)
+        v = lin(h, "self_attn.v_proj").view(S, nkv, 128)
+        kk, vv = k.repeat_interleave(nh // nkv, 1), v.repeat_interleave(nh // nkv, 1)
+        sc = torch.einsum("shd,thd->hst", q.float(), kk.float()) / 128 ** 0.5
+        sc = sc + torch.full((S, S), float("-inf"), device=dev).triu(1)
+        p = torch.softmax(sc, -1).half()
+        a = torch.einsum("hst,thd->shd", p.float(), vv.float()).half().reshape(S, H)
+        x = x + lin(a, "self_attn.o_proj")
+        h2 = norm(x, blk["ln2"])
+        x = x + lin(torch.nn.functional.silu(lin(h2, "mlp.gate_proj")) * lin(h2, "mlp.up_proj"), "mlp.down_proj")
+        return (norm(x, m.norm).float() @ m.lm_head.float().t())
+
+    S = 600 if name == "Llama-3.1-8B" else 48              # (Llama-3.1: positions where the scaled and the plain frequencies have drifted apart)
+    ids = torch.randint(0, m.vocab, (S + 3,), generator=torch.Generator().manual_seed(5)).to(dev)
+    want = reference(ids)                                   # logits of every row of the (S + 3)-token sequence
+    scale = want[S - 1:].abs().max()
+    lg = m.prefill(ids[:S]).float()
+    assert torch.isfinite(lg).all() and (lg - want[S - 1]).abs().max() <= 1e-2 * scale
+    for i in range(3):                                      # three captured token steps, fed the sequence's own tokens
+        m.set_token(int(ids[S + i]))
+        m.decode_step()
+        assert (m.logits.float() - want[S + i]).abs().max() <= 1e-2 * scale, i
+    assert m.graph is not None
+    if name == "Llama-3.1-8B":
+        # the table the rotating kernels read IS the scaled one: against torch on the same frequencies (HF's expression: fp32 product, fp32 cos / sin,
+        # one rounding to fp16) and against the plain rope_theta table, which differs wherever the scaled wavelengths apply
+        tab = m.rope_tab.view(640, 64, 2).float()
+        fr = torch.arange(640, device=dev).float()[:, None] * inv[None, :]
+        assert (tab[..., 0] - fr.cos().half().float()).abs().max() <= 2.0 ** -10 and (tab[..., 1] - fr.sin().half().float()).abs().max() <= 2.0 ** -10
+        assert ((tab[..., 0] != fr.cos().half().float()).float().mean()) < 2e-3
+        plain = ops.rope_table(640, m.theta, dev).view(640, 64, 2).float()
+        assert (tab - plain).abs().max() > 0.1

@@ -90,6 +90,26 @@ def _hf_generate(model, ids, n):
                           pad_token_id=0)
 
 
+def _assert_same_tokens_or_a_tie(model, fast, slow, n_prompt, eos=None):
+    """two fp16 implementations of one function decode greedily: equal tokens, or -- at the first step where they part -- a near-tie under HF's own
+    logits for the common prefix (the tiny random models settle into flat, repetitive distributions where the two best logits are rounding apart);
+    what follows a parted step is not comparable"""
+    if torch.equal(fast, slow):
+        return
+    for b in range(fast.shape[0]):
+        diff = (fast[b] != slow[b]).nonzero()
+        if len(diff) == 0:
+            continue
+        t = int(diff[0])
+        assert t >= n_prompt
+        with torch.inference_mode():
+            lg = model(slow[b:b + 1, :t]).logits[0, -1].float()          # (no start_pos: HF's own forward over the same modules)
+            if eos is not None:
+                lg[eos] = float("-inf")
+        gap = float(lg.max() - lg[int(fast[b, t])])
+        assert gap <= 4e-3 * float(lg[torch.isfinite(lg)].abs().max()), (b, t, gap, fast[b, n_prompt:].tolist(), slow[b, n_prompt:].tolist())
+
+
 def _golden_hf(bits=3):
     """an HF LlamaForCausalLM over a tiny checkpoint the REFERENCE wrote (tests/golden/ckpt: quantize_model + save_quantized)"""
     from transformers import LlamaConfig, LlamaForCausalLM
@@ -131,10 +151,25 @@ def test_generate_on_the_converted_object_equals_hf_eager_generate():
                 fast2 = _hf_generate(model, ids, 12)
             assert fast.shape == (B, 21) and fast.dtype == ids.dtype and torch.equal(fast[:, :9], ids)
             assert torch.equal(fast, fast2)
-            assert torch.equal(fast, slow), (fast[:, 9:].tolist(), slow[:, 9:].tolist())
+            _assert_same_tokens_or_a_tie(model, fast, slow, 9, model.generation_config.eos_token_id)
+            assert torch.equal(fast[:, :9 + 3], slow[:, :9 + 3])
             assert B in hf_fast._RUNNERS[model]                                   # (it really was the runner)
             hf_fast.revert_model_to_hf(model)
             assert "forward" not in model.__dict__ and "generate" not in model.__dict__ and model not in hf_fast._RUNNERS
+            # min_new_tokens = max_new_tokens: HF never emits an EOS id (MinNewTokensLengthLogitsProcessor); declare a token the free run DID pick
+            # as EOS -- both paths must now avoid it, in the same way
+            eos = int(slow[0, 9 + 3])
+            model.generation_config.eos_token_id = eos
+            with torch.inference_mode():
+                slow_e = _hf_generate(model, ids, 12)
+            hf_fast.convert_model_to_hip(model)
+            with torch.inference_mode():
+                fast_e = _hf_generate(model, ids, 12)
+            assert eos not in fast_e[:, 9:].tolist()[0] and eos not in slow_e[:, 9:].tolist()[0] and not torch.equal(fast_e, fast)
+            _assert_same_tokens_or_a_tie(model, fast_e, slow_e, 9, eos)
+            assert torch.equal(fast_e[:, :9 + 4], slow_e[:, :9 + 4])                # (incl. the step where the free run picked `eos`)
+            model.generation_config.eos_token_id = None
+            hf_fast.revert_model_to_hf(model)
 
 
 def test_forward_with_start_pos_is_the_fast_step():
@@ -159,6 +194,7 @@ def test_forward_with_start_pos_is_the_fast_step():
     with torch.inference_mode():
         o = model(ids, use_cache=True)
         past, tok = o.past_key_values, o.logits[:, -1].max(1)[1].unsqueeze(1)
+        slow_first = int(tok)
         slow_toks, slow_lg = [], []
         for _ in range(6):
             o = model(tok, past_key_values=past, use_cache=True)
@@ -170,16 +206,17 @@ def test_forward_with_start_pos_is_the_fast_step():
     with torch.inference_mode():
         o = model(ids, start_pos=0, use_cache=False)
         start = o.logits.shape[1]
-        tok = torch.as_tensor([[int(o.logits[:, -1].max(1)[1])]], device=DEV)
+        assert int(o.logits[:, -1].max(1)[1]) == slow_first
         fast_toks = []
         for i in range(6):
+            # (fed HF's own greedy token, so that both sides see the same prefix even where a near-tie flips a choice)
+            tok = torch.as_tensor([[slow_first if i == 0 else slow_toks[i - 1]]], device=DEV)
             o = model(tok, start_pos=start, use_cache=False)
             assert o.logits.shape == (1, 1, 1000)
-            assert (o.logits[:, -1] - slow_lg[i]).abs().max() <= 6e-3 * scale
+            assert (o.logits[:, -1] - slow_lg[i]).abs().max() <= 6e-3 * scale, i
             start += o.logits.shape[1]
-            tok = torch.as_tensor([[int(o.logits[:, -1].max(1)[1])]], device=DEV)
-            fast_toks.append(int(tok))
-    assert fast_toks == slow_toks
+            fast_toks.append(int(o.logits[:, -1].max(1)[1]))
+    assert sum(a_ == b_ for a_, b_ in zip(fast_toks, slow_toks)) >= 5, (fast_toks, slow_toks)
     r = hf_fast._RUNNERS[model][1]
     assert r.graph is not None and r.host_pos == 30                                # the one-token calls replayed the captured step
     # chunked prompt: rows 0..15 then 16..23 behind them
@@ -234,11 +271,12 @@ def test_what_the_fast_path_does_not_serve_falls_through_or_says_so():
         tok = torch.as_tensor([[int(o.logits[:, -1].max(1)[1])]], device=DEV)
         o2 = model(tok, start_pos=7, use_cache=False)
         assert hf_fast._RUNNERS[model][1] is r0
-    # an unsupported family is refused by name at convert time
-    model.config.model_type = "gemma"
+    # a decoder the runner's block does not describe (per-head q / k norms: Qwen3, Gemma) is refused at convert time, with the reason
     hf_fast.revert_model_to_hf(model)
-    with pytest.raises(ValueError, match="model_type"):
+    model.model.layers[0].self_attn.q_norm = torch.nn.Identity()
+    with pytest.raises(ValueError, match="q / k norms"):
         hf_fast.convert_model_to_hip(model)
+    assert "forward" not in model.__dict__
 
 
 @pytest.mark.parametrize("family", ["llama3.1", "mistral", "qwen2"])
@@ -265,7 +303,8 @@ def test_model_families_through_the_swap_and_the_runner(family):
         lg = model(ids, start_pos=0, use_cache=False).logits
         fast = _hf_generate(model, ids[:, :20], 10)
     assert (lg - y_ref).abs().max() <= 6e-3 * scale
-    assert torch.equal(fast, slow), (fast[:, 20:].tolist(), slow[:, 20:].tolist())
+    _assert_same_tokens_or_a_tie(model, fast, slow, 20)
+    assert torch.equal(fast[:, :20 + 3], slow[:, :20 + 3])
     r = hf_fast._RUNNERS[model][1]
     if family == "llama3.1":
         assert r.inv_freq is not None and not torch.allclose(r.inv_freq.cpu(), 1.0 / (500000.0 ** (torch.arange(0, 128, 2).float() / 128)))

@@ -688,6 +688,63 @@ def test_gemv_strided_x_through_the_c_abi(m, k, ok):
     _assert_close(y.cpu().numpy(), yd.cpu().numpy(), "strided vs dense")
 
 
+@pytest.mark.parametrize("m", [5, 6, 8])
+@pytest.mark.parametrize("k,n_prod", [(4096, 4096), (3584, 3584), (8192, 8192)])
+def test_gemv_rmsnorm_from_partial_sums(m, k, n_prod):
+    """amq_gemv_grouped_sums_f16 (5 .. 8 sequences): a launch that writes a hidden state leaves one sum of squares per row and 16 output columns
+    (sums_out); the launch that normalises it adds them in a fixed order and applies gamma * fp16(x * rstd) while staging x (sums_in) -- against
+    the oracle on LlamaRMSNorm's formula, against the unfused pair (amq_rmsnorm_f16 + plain GEMV: same value up to the order of the fp32 mean), and
+    bit for bit against itself; grouped consumers of several bit-widths; K = 3584 (224 partials: not a multiple of 64) and 8192 (512: the limit)."""
+    from amq_amd import ops
+    dev = _dev()
+    if m > ops.gemv_max_rows(k, plain=True):
+        pytest.skip("rows do not fit LDS whole")
+    gen = torch.Generator().manual_seed(m * 100 + k)
+    # producer: o_proj-like, ONE segment with a residual: y = res + W1 . a
+    h1, q1, m1, w1 = _random_case(3, n_prod, k, seed=m)
+    a_in = torch.randn(m, k, generator=gen).to(torch.float16)
+    res = torch.randn(m, n_prod, generator=gen).to(torch.float16)
+    y1 = torch.empty(m, n_prod, dtype=torch.float16, device=dev)
+    ss = torch.full((m, n_prod // 16), float("nan"), dtype=torch.float32, device=dev)
+    ops.gemv_grouped_sums(a_in.to(dev), [dict(qn=q1, mn=m1, bits=3, mode=ops.MODE_HQQ, N=n_prod, y=y1, residual=res.to(dev))], k, sums_out=ss)
+    y1_plain = torch.empty_like(y1)
+    ops.gemv_grouped(a_in.to(dev), [dict(qn=q1, mn=m1, bits=3, mode=ops.MODE_HQQ, N=n_prod, y=y1_plain, residual=res.to(dev))], k)
+    assert torch.equal(y1, y1_plain)                                              # the epilogue's extra output changes nothing else
+    want_ss = y1.float().pow(2).view(m, n_prod // 16, 16).sum(-1)
+    assert not torch.isnan(ss).any() and torch.allclose(ss, want_ss, rtol=1e-5, atol=1e-6)
+    # consumer: gate/up-like, two segments of different bit-widths over x = y1 (K of the consumer = N of the producer)
+    kc = n_prod
+    gamma = (1.0 + 0.1 * torch.randn(kc, generator=gen)).to(torch.float16)
+    segs = [(b,) + _random_case(b, nn, kc, seed=7 * b + m)[1:] + (nn,) for b, nn in ((2, 512), (4, 256))]
+    eps = 1e-6
+
+    def consumer(sums):
+        ys = [torch.empty(m, nn, dtype=torch.float16, device=dev) for *_, nn in segs]
+        sg = [dict(qn=q, mn=mt, bits=b, mode=ops.MODE_HQQ, N=nn, y=y) for (b, q, mt, _, nn), y in zip(segs, ys)]
+        if sums is not None:
+            ops.gemv_grouped_sums(y1, sg, kc, gamma=gamma.to(dev), eps=eps, sums_in=sums)
+        else:
+            ops.gemv_grouped(ops.rmsnorm(y1, gamma.to(dev), eps), sg, kc)
+        return ys
+    got = consumer(ss)
+    unfused = consumer(None)
+    xin = _rmsnorm_ref(y1.cpu(), gamma, eps)
+    for (b, q, mt, w_ref, nn), y, yu in zip(segs, got, unfused):
+        ref = linear_ref.linear_f16(xin.numpy(), w_ref)
+        _assert_close(y.cpu().numpy(), ref, f"partial-sum rmsnorm, {b} bit")
+        _assert_close(y.cpu().numpy(), yu.cpu().numpy(), "partial sums vs rmsnorm launch + GEMV")
+    again = consumer(ss)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(got, again))
+    # what the entry point refuses
+    from amq_amd import _lib
+    with pytest.raises(_lib.AmqError):
+        ops.gemv_grouped_sums(y1[:4], [dict(qn=segs[0][1], mn=segs[0][2], bits=2, mode=ops.MODE_HQQ, N=512, y=got[0][:4])], kc, gamma=gamma.to(dev),
+                              eps=eps, sums_in=ss[:4])                               # 4 rows: the fused AMQ_PRO_RMSNORM prologue serves those
+    with pytest.raises(_lib.AmqError):
+        ops.gemv_grouped_sums(y1, [dict(qn=q, mn=mt, bits=b, mode=ops.MODE_HQQ, N=nn, y=y) for (b, q, mt, _, nn), y in zip(segs, got)], kc,
+                              sums_out=torch.empty(m, 512 // 16, dtype=torch.float32, device=dev))      # sums_out describes ONE output
+
+
 def test_results_do_not_depend_on_cache_state():
     """every kernel that waits for its loads with COUNTED waits (register rings, LDS-DMA pieces) against operands that are cold in HBM: a cache-flushing
     fill in front of each launch makes every transfer take microseconds to land, so a wait that does not cover what the next instruction reads shows

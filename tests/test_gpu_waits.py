@@ -62,6 +62,19 @@ def _corpus():
                          prologue=ops.PRO_RMSNORM, gamma=g8, eps=1e-5)
         return torch.cat(ys, dim=1)
     cases.append(("gemv grouped 2/3/4 bit, 8 rows, rmsnorm", grouped))
+    # the partial-sum RMSNorm of the 5 .. 8-row steps: producer (sums_out in the epilogue) and consumer (sums_in: rows by LDS-DMA, partials, transform)
+    qo, mo = _layer(3, 4096, 4096, seed=55)
+    a8, r8 = rnd(8, 4096), rnd(8, 4096)
+
+    def sums_pair():
+        y1 = torch.empty(8, 4096, dtype=torch.float16, device=dev)
+        ss = torch.empty(8, 256, dtype=torch.float32, device=dev)
+        ops.gemv_grouped_sums(a8, [dict(qn=qo, mn=mo, bits=3, mode=ops.MODE_HQQ, N=4096, y=y1, residual=r8)], 4096, sums_out=ss)
+        ys = [torch.empty(8, nn, dtype=torch.float16, device=dev) for _, _, _, nn in segs]
+        ops.gemv_grouped_sums(y1, [dict(qn=q, mn=mt, bits=b, mode=ops.MODE_HQQ, N=nn, y=y) for (b, q, mt, nn), y in zip(segs, ys)], 4096,
+                              gamma=g8, eps=1e-5, sums_in=ss)
+        return torch.cat([y1] + ys, dim=1)
+    cases.append(("gemv partial-sum rmsnorm, 8 rows", sums_pair))
 
     # ---- few-row launches over fragment-ordered x: the tile form and the streaming form (3 / 6 column blocks per workgroup)
     k2, n2 = 4096, 2048

@@ -201,3 +201,86 @@ def test_bench_extras_run_after_the_timed_region():
         assert src.index(leg) > timed, leg
     # ... and only rank 0 at N = 1 runs them
     assert "if rank != 0:\n        return" in src and src.count("n_gpus == 1") >= 3
+
+
+_RANK8_SCRIPT = """
+import json, os, sys, time
+sys.path.insert(0, {root!r})
+from amq_amd.replicas import Replicas
+r = Replicas(backend="gloo")
+t = r.timed(lambda: time.sleep(0.005 * (1 + r.rank % 3)), steps=3)
+left_timed = time.time()
+per = r.gather(3 / r.last_local)
+ends = r.gather(left_timed)
+if r.rank == 0:
+    extras_start = time.time()                      # (bench.py: rank 0's CPU-baseline / parity / extras legs start here)
+    time.sleep(0.05)
+r.barrier()                                         # the closing barrier: nobody tears the group down under rank 0's extras
+closed = time.time()
+print(json.dumps({{"rank": r.rank, "world": r.live_world_size(), "cpus": sorted(os.sched_getaffinity(0)), "per_rank": per, "t": t,
+                  "ends": ends, "extras_start": extras_start if r.rank == 0 else None, "closed": closed}}), flush=True)
+r.close()
+"""
+
+
+def test_eight_ranks_over_a_two_socket_node(tmp_path):
+    """BASELINE.json configs[4] is 8 decode streams on 8 GPUs of one node; no such node was offered to any round, so the launch path is
+    rehearsed here at its real width: launch_local starts 8 ranks over a made-up sysfs of 8 amdgpu cards on two sockets -- every rank bound inside
+    its GPU's NUMA node, masks disjoint -- they meet through the file-store rendezvous (gloo standing in for RCCL), the timed region reports the
+    slowest rank's time on every rank, the gather returns 8 rates in rank order, and rank 0's extra legs start only after every rank has left
+    the timed region and finish before anybody passes the closing barrier."""
+    import json, subprocess, sys
+    host = sorted(os.sched_getaffinity(0))
+    if len(host) < 8:
+        import pytest
+        pytest.skip("needs eight cores")
+    host = host[:8]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "sys"
+    lst = lambda cs: ",".join(str(c) for c in cs)
+    _fake_sysfs(fake, [0, 0, 0, 0, 1, 1, 1, 1], {0: lst(host[:4]), 1: lst(host[4:])})
+    script = tmp_path / "rank8.py"
+    script.write_text(_RANK8_SCRIPT.format(root=root))
+    drv = tmp_path / "drv.py"
+    drv.write_text(f"import os, sys; sys.path.insert(0, {root!r})\nos.sched_setaffinity(0, {set(host)!r})\nfrom amq_amd.replicas import launch_local\n"
+                   f"sys.exit(launch_local(8, [sys.executable, {str(script)!r}], timeout=240, sys_root={str(fake)!r}))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(drv)], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = sorted((json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    assert [d["rank"] for d in rows] == list(range(8)) and all(d["world"] == 8 for d in rows)
+    masks = [set(d["cpus"]) for d in rows]
+    assert all(len(m) == 1 for m in masks) and len(set().union(*masks)) == 8           # one core each, disjoint
+    assert all((m <= set(host[:4])) == (r < 4) for r, m in enumerate(masks))           # ranks 0-3 on socket 0's cores, 4-7 on socket 1's
+    assert all(len(d["per_rank"]) == 8 and d["per_rank"] == rows[0]["per_rank"] for d in rows)
+    assert all(abs(d["t"] - rows[0]["t"]) < 1e-9 for d in rows) and rows[0]["t"] >= 3 * 0.015   # the slowest rank's time, on every rank
+    pr = rows[0]["per_rank"]
+    assert pr[0] > pr[2] and pr[3] > pr[5]                                             # rank order kept (ranks 2, 5 sleep 3 x longer)
+    assert rows[0]["extras_start"] >= max(rows[0]["ends"]) - 1e-3                      # extras begin after EVERY rank left the timed region
+    assert all(d["closed"] >= rows[0]["extras_start"] + 0.05 - 1e-3 for d in rows)     # ... and end before anyone passes the closing barrier
+
+
+def test_bench_rehearses_the_n_rank_launch_path():
+    """`bench.py --gpus N --config 5 --rehearse-ranks`: the script's own launch path at N ranks (launch_local children, placement, rendezvous,
+    timed region, gather, rank 0's line) with gloo standing in for RCCL and a sleep for the decode step -- the line says it is a rehearsal and
+    carries no value; what is checked is what an 8-GPU node will need: one line, N per-rank rates, a live process group of N ranks"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "AMQ_RENDEZVOUS_FILE")}
+    for n in (2, 8):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--config", "5", "--steps", "4", "--warmup", "1",
+                              "--rehearse-ranks"], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["rehearsal"] is True and d["value"] is None and d["n_gpus"] == n
+        assert d["rccl_world_size"] == n and len(d["per_rank_tokens_per_s"]) == n and len(d["per_rank_host_cores"]) == n
+        assert d["config"]["parallelism"] == f"replicas x{n}" and "configs[4]" in d["config"]["workload"]
+    # under an outer launcher (torch.distributed.run sets WORLD_SIZE / RANK / MASTER_*): the existing ranks are used, a mismatch is an error
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29591", os.path.join(root, "bench.py"), "--gpus", "2", "--config", "5", "--steps", "3", "--warmup", "0",
+                          "--rehearse-ranks"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["rccl_world_size"] == 2 and len(d["per_rank_tokens_per_s"]) == 2

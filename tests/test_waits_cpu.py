@@ -79,9 +79,11 @@ def test_counted_waits_match_the_isa():
         assert all(r["min"] == r["want"] for r in by[site]), site
     # the GEMV row kernels: every body of every (prologue, rows, waves) instantiation stages its rows behind exactly 2 U loads of the ring
     gx = by["gemv.xrows"]
-    assert len(gx) >= 100 and all(r["min"] == r["n"] for r in gx)
+    assert len(gx) >= 100 and all(r["min"] == r["n"] for r in gx if r["file"] != "amq_gemv_pro3.s")
+    # (the partial-sum prologue puts its 8 loads of partials and gamma's between the transfers and the ring: stricter than counted, by design)
+    assert all(r["min"] > r["n"] for r in gx if r["file"] == "amq_gemv_pro3.s")
     files_with = {r["file"] for r in gx}
-    assert {"amq_gemv_pro0.s", "amq_gemv_pro1.s", "amq_gemv_pro2.s"} <= files_with
+    assert files_with == {"amq_gemv_pro0.s", "amq_gemv_pro1.s", "amq_gemv_pro2.s", "amq_gemv_pro3.s"}
     # the ping-pong GEMM: 3 pieces behind X's reads, 5 behind Y's, in both instantiations (fp16, bf16)
     assert {(r["frm"], r["min"], r["max"]) for r in by["f16pp.x"]} == {("f16pp.y", 3, 3), ("f16pp.pro", 3, 3), ("f16pp.drain", 3, 3)}
     assert {(r["min"], r["max"]) for r in by["f16pp.y"]} == {(5, 5)}

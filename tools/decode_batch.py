@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """decode throughput against the batch (graph replay, 64-token prompts, Llama-2-7B avg-3 synthetic weights): sequences per step
-share one pass over the weights.  usage: decode_batch.py [batches, comma separated] [steps]"""
+share one pass over the weights.  usage: decode_batch.py [batches, comma separated] [steps]
+(NORM_SUMS=0: the 5 .. 8-row steps with one rmsnorm launch per norm instead of the partial-sum RMSNorm, A/B)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +11,8 @@ if os.environ.get("GEMV_WAVES") or os.environ.get("GEMV_DEPTH") or os.environ.ge
     ops.DEFAULT_GEMV_OPTS = ops.GemvOpts(waves=int(os.environ.get("GEMV_WAVES", "0")), depth=int(os.environ.get("GEMV_DEPTH", "0")),
                                          dot=int(os.environ.get("GEMV_DOT", "0")))   # A/B: waves per workgroup, ring depth, v_dot2 body at one row
 
+if os.environ.get("NORM_SUMS") == "0":
+    QuantLlama.NORM_SUMS = False
 batches = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,4,8".split(","))]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 name = os.environ.get("SWEEP_MODEL", "Llama-2-7b-hf")
