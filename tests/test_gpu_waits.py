@@ -141,6 +141,7 @@ def test_product_equals_its_conservative_twin_quiet_and_perturbed():
     dev = _dev()
     cases = _corpus()
     assert len(cases) >= 60
+    print(f"twin corpus: {len(cases)} cases x {REPS} repetitions x 2 modes x 2 libraries")
     side = torch.cuda.Stream(device=dev)
     big_a = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     big_b = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
