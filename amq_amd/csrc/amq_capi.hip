@@ -181,10 +181,11 @@ int amq_gemv_grouped_sums_f16(const amq_segment* segs, int nseg, const void* x, 
     if (!segs || nseg < 1 || nseg > AMQ_MAX_SEGMENTS) return fail(AMQ_EINVAL, "nseg must be 1..%d (got %d)", AMQ_MAX_SEGMENTS, nseg);
     if (!x) return fail(AMQ_EINVAL, "null x");
     if ((sums_in != nullptr) != (gamma != nullptr)) return fail(AMQ_EINVAL, "sums_in (the partial sums of squares of x) and gamma go together");
-    if (M < 5 || M > 8) return fail(AMQ_ESHAPE, "the partial-sum forms live in the 5 .. 8-row kernels (got M=%d); fewer rows: amq_gemv_grouped_f16 with AMQ_PRO_RMSNORM", M);
+    if (M < 2 || M > 8) return fail(AMQ_ESHAPE, "the partial-sum forms live in the 2 .. 8-row kernels (got M=%d); one row: amq_gemv_grouped_f16 with AMQ_PRO_RMSNORM", M);
     if (amq::meta_pairs(group) != 1) return fail(AMQ_ESHAPE, "groups of 128 (and multiples) only (got %d)", group);
-    if (K < 2048) return fail(AMQ_ESHAPE, "K >= 2048 (the 5 .. 8-row kernels run 8 or 16 waves per workgroup; got K=%d)", K);
+    if (K < 2048) return fail(AMQ_ESHAPE, "K >= 2048 (the 2 .. 8-row kernels run 8 or 16 waves per workgroup; got K=%d)", K);
     if (sums_out && nseg != 1) return fail(AMQ_EINVAL, "sums_out describes ONE output: nseg must be 1");
+    if (sums_out && sums_in) return fail(AMQ_EINVAL, "sums_out is written by launches without a prologue (o_proj, down_proj): not together with sums_in");
     if (sums_in && K > 8192) return fail(AMQ_ESHAPE, "sums_in: K <= 8192 (K / 16 <= 512 partials per row; got K=%d)", K);
     const bool phased = amq::gemv_rows_phased(M, K, true, sums_in != nullptr);
     if (sums_in && phased) return fail(AMQ_ESHAPE, "M=%d rows of K=%d are staged in two K phases: no fused norm there", M, K);

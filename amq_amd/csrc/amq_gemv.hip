@@ -63,7 +63,7 @@ AMQ_GEMV_EXTERN(PRO_NONE)
 AMQ_GEMV_EXTERN(PRO_RMSNORM)
 AMQ_GEMV_EXTERN(PRO_SILU_MUL)
 #undef AMQ_GEMV_EXTERN
-hipError_t launch_pro_sums_entry(const GemvKArgs&, int, int, size_t, hipStream_t);     // amq_gemv_pro3.hip
+hipError_t launch_pro_sums_entry(const GemvKArgs&, int nw, int rs, int, size_t, hipStream_t);     // amq_gemv_pro3.hip
 
 // Fills the per-segment workgroup ranges and launches.  rpt = row-tiles per workgroup.
 #ifndef AMQ_RS128_THREE
@@ -138,10 +138,10 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
     const bool lin = (a.flags & GEMV_FLAG_LINEAR) && !((a.flags & GEMV_FLAG_DOT) && a.M == 1);
     (void)lin; (void)mask;
     const size_t lds = ph2 ? gemv_lds_bytes_rows(a.M, a.K / 2, 16) : (rs128 || rs64) ? gemv_lds_bytes_rows(a.M, a.K, nw) : gemv_lds_bytes(a.M, a.K, a.M > 1 ? nw : 16);     // (one-row launches keep the allocation they were tuned with)
-    // the partial-sum forms exist in the 5 .. 8-row kernels only (amq_gemv_grouped_sums_f16 checks the same and says why)
-    if ((a.prologue == PRO_RMSNORM_SUMS || a.sums_out) && !rs128) return hipErrorInvalidValue;
+    // the partial-sum forms exist in the 2 .. 8-row kernels only (amq_gemv_grouped_sums_f16 checks the same and says why)
+    if ((a.prologue == PRO_RMSNORM_SUMS || a.sums_out) && !(rs128 || rs64)) return hipErrorInvalidValue;
     if (a.prologue == PRO_RMSNORM_SUMS && (ph2 || !a.sums_in || (a.K >> 4) > 64 * SUMS_PER_LANE || a.x_stride != a.K)) return hipErrorInvalidValue;
-    if (a.sums_out && a.nseg != 1) return hipErrorInvalidValue;
+    if (a.sums_out && (a.nseg != 1 || a.prologue != PRO_NONE)) return hipErrorInvalidValue;
     GemvKArgs k{};
     k.x = a.x; k.x2 = a.prologue == PRO_RMSNORM_SUMS ? a.sums_in : a.x2; k.gamma = a.gamma;
     k.sums_out = (float*)a.sums_out; k.sums_stride = a.seg[0].n_rt;
@@ -172,7 +172,7 @@ hipError_t launch_gemv(GemvArgs& a, hipStream_t st) {
             default: return launch_pro_g<PRO_SILU_MUL, 4>(k, nw, wg, lds, st);
         }
     }
-    if (a.prologue == PRO_RMSNORM_SUMS) return launch_pro_sums_entry(k, nw, wg, lds, st);
+    if (a.prologue == PRO_RMSNORM_SUMS) return launch_pro_sums_entry(k, nw, rs64 ? 64 : 128, wg, lds, st);
     switch (a.prologue) {
         case PRO_NONE: return launch_pro<PRO_NONE>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0) | (ph2 ? GEMV_FLAG_PH2 : 0), a.force_depth, nw, wg, lds, st);
         case PRO_RMSNORM: return launch_pro<PRO_RMSNORM>(k, a.flags | (rs128 ? GEMV_FLAG_RS128 : 0) | (rs64 ? GEMV_FLAG_RS64 : 0) | (ph2 ? GEMV_FLAG_PH2 : 0), a.force_depth, nw, wg, lds, st);

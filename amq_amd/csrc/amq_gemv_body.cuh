@@ -594,7 +594,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     const int G = a.K >> 7;
     const int r = lane & 15, o = lane >> 4;
     static_assert(PH == 1 || (RS != 256 && PRO != PRO_RMSNORM && PRO != PRO_RMSNORM_SUMS && MATH != MATH_LINEAR && MATH != MATH_DOT), "K phases: the row kernels, no full-row statistic");
-    static_assert(PRO != PRO_RMSNORM_SUMS || (RS == 128 && MATH == MATH_EXACT && GP == 1), "partial-sum RMSNorm: the 5 .. 8-row kernels");
+    static_assert(PRO != PRO_RMSNORM_SUMS || (RS != 256 && MATH == MATH_EXACT && GP == 1), "partial-sum RMSNorm: the 2 .. 8-row kernels");
     const int Gp = G / PH;                                        // tiles of one K phase of a row-tile
     const int nt = (Gp - wave + NW - 1) / NW;                     // tiles of one (row-tile, phase) owned by this wave: g = phase * Gp + wave + i*NW
     // this workgroup's row-tiles: rt0 .. rt0 + n_my - 1 (contiguous bytes).  seg_split = gemv_split(): the segment's first `rem` workgroups walk
@@ -665,7 +665,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
     so.residual = (const _Float16*)blk.residual[sidx];
     so.y = (_Float16*)blk.y[sidx];
     so.y_stride = blk.y_stride[sidx];
-    so.sums = RS == 128 ? blk.sums_out : nullptr;                // (the 5 .. 8-row kernels: what a PRO_RMSNORM_SUMS launch over y will read)
+    so.sums = (RS != 256 && PRO == PRO_NONE) ? blk.sums_out : nullptr;   // (the 2 .. 8-row kernels without a prologue -- o_proj, down_proj: what a PRO_RMSNORM_SUMS launch over y will read)
     so.sums_stride = blk.sums_stride;
 #ifndef AMQ_ABL_NOSTAGE
     // xmode: 1 = one row held in registers (x_issue ran), 2 = rows on their way into LDS (x_dma_rows ran; the <= 8-row kernels, RS != 256), 0 = generic
@@ -736,7 +736,7 @@ __device__ __forceinline__ void gemv_body(const GemvHot& a, const GemvKArgs& blk
             if (SC1) __hip_atomic_store((unsigned short*)(so.y + (size_t)e_m * so.y_stride + rt_ * 16 + e_c),          \
                                         __builtin_bit_cast(unsigned short, y_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
             else so.y[(size_t)e_m * so.y_stride + rt_ * 16 + e_c] = y_;                          \
-            if constexpr (RS == 128) {                        /* sum of squares of this row-tile's 16 values of row e_m (one DPP row: fixed order) */ \
+            if constexpr (RS != 256 && PRO == PRO_NONE) {     /* sum of squares of this row-tile's 16 values of row e_m (one DPP row: fixed order) */ \
                 if (so.sums) {                                                                   \
                     const float q_ = row16_total((float)y_ * (float)y_);                         \
                     if (e_c == 0) so.sums[(size_t)e_m * so.sums_stride + rt_] = q_;              \

@@ -110,7 +110,7 @@ class QuantLlama:
     DOWN_FUSED_ROWS = 1
     # rows up to which the two RMSNorms stay fused into the q/k/v and gate/up launches (beyond: one rmsnorm launch + the grouped GEMV without a prologue)
     NORM_FUSED_ROWS = 4
-    NORM_SUMS = True            # (A/B switch of the partial-sum RMSNorm at 5 .. 8 rows: False = one rmsnorm launch per norm)
+    NORM_SUMS = True            # (A/B switch of the partial-sum RMSNorm at 2 .. 8 rows: False = fused prologue up to NORM_FUSED_ROWS, one rmsnorm launch per norm beyond)
     # q/k/v + attention of a block as ONE launch (ops.gemv_qkv_attn; batch 1, short cache, hidden <= 8192): 4 launches per block
     # instead of 5.  Built, bit-identical (tests/test_gpu_qkv_attn.py) and SLOWER -- 15.7 us per fused launch against 9.2 + 5.1,
     # 755 vs 830 tokens/s (profiles/r03_qkv_attn_fused_negative.txt) -- so it is off unless a caller sets fuse_qkv_attn.
@@ -243,9 +243,10 @@ class QuantLlama:
         self.can_fuse_qkv_attn = self.B == 1 and max_seq <= ops.ATTN_SPLIT_FROM and self.H <= 8192 and not self.fine and not self.has_bias
         self.fuse_qkv_attn = self.FUSE_QKV_ATTN and self.can_fuse_qkv_attn
         self._tickets = torch.zeros(max(self.nh, 64), dtype=torch.int32, device=dev)
-        # 5 .. 8 sequences: the RMSNorms ride on per-row-tile sums of squares that o_proj / down_proj leave in their epilogues (ops.gemv_grouped_sums:
-        # no pass over x for the statistic, no rmsnorm launch); the first norm of block 0 (its x comes from the embedding) stays a launch
-        self._norm_sums = (self.NORM_SUMS and self.NORM_FUSED_ROWS < self.B <= 8 and not self.fine and 2048 <= self.H <= 8192 and self.I >= 2048
+        # 2 .. 8 sequences: the RMSNorms ride on per-row-tile sums of squares that o_proj / down_proj leave in their epilogues (ops.gemv_grouped_sums:
+        # no pass over x for the statistic -- which a fused prologue repeats in every workgroup --, no rmsnorm launch); the first norm of block 0 (its x
+        # comes from the embedding) keeps the fused prologue (2 .. 4 rows) / a launch of its own (5 .. 8)
+        self._norm_sums = (self.NORM_SUMS and 2 <= self.B <= 8 and not self.fine and 2048 <= self.H <= 8192 and self.I >= 2048
                            and self.B <= ops.gemv_max_rows(self.H, plain=True))
         self.ss = torch.zeros(self.B, self.H // 16, dtype=torch.float32, device=dev) if self._norm_sums else None
         eligible = self.B == 1 and max_seq <= self.ENGINE_MAX_SEQ and self.H == self.nh * 128 and not self.fine and not self.has_bias

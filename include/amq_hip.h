@@ -190,14 +190,14 @@ int amq_gemv_grouped_f16(const amq_segment* segments /* host */, int nseg,
                          const void* x, const void* x2, const void* gamma, float eps, int prologue,
                          int M, int K, int group, int x_stride, const amq_gemv_opts* opts /* host, may be NULL */,
                          void* stream);
-/* 5 .. 8 rows (sequences decoded together), RMSNorm WITHOUT a pass over x for its statistic: a launch that writes a hidden state (o_proj, down_proj:
+/* 2 .. 8 rows (sequences decoded together), RMSNorm WITHOUT a pass over x for its statistic: a launch that writes a hidden state (o_proj, down_proj:
  * ONE segment, residual in the epilogue) also leaves, per row, one sum of squares per 16 output columns in sums_out (fp32 [M][N / 16], written
  * whole by every launch); the launch that normalises that hidden state takes them as sums_in (fp32 [M][K / 16]) with gamma and eps, adds them
  * in a fixed order and only applies gamma * fp16(x * rstd) while staging x -- LlamaRMSNorm's value up to the summation order of its fp32
- * mean (the fused AMQ_PRO_RMSNORM prologue repeats the whole statistic in every workgroup: at 5 .. 8 rows that costs more than a separate
- * amq_rmsnorm_f16 launch; this form costs less than either).  sums_in == NULL: no prologue (then gamma must be NULL too); sums_out == NULL: none
+ * mean (the fused AMQ_PRO_RMSNORM prologue repeats the whole statistic in every workgroup -- ~90 VALU instructions per row and thread: at 5 .. 8
+ * rows that costs more than a separate amq_rmsnorm_f16 launch; this form costs less than either, from 2 rows on).  sums_in == NULL: no prologue (then gamma must be NULL too); sums_out == NULL: none
  * written.  x dense [M][K], groups of 128, default arithmetic; K <= 8192 with sums_in.  Replaces layernorm.cu:25-51 + the GEMV behind it in the
- * reference's FT step (ftllama_modeling.py:39-46) for Batch 5 .. 8 (gemv_cuda.cu:381-437 makes batches first-class). */
+ * reference's FT step (ftllama_modeling.py:39-46) for Batch 2 .. 8 (gemv_cuda.cu:381-437 makes batches first-class). */
 int amq_gemv_grouped_sums_f16(const amq_segment* segs, int nseg, const void* x, const void* gamma, float eps, const float* sums_in,
                               float* sums_out, int M, int K, int group, void* stream);
 

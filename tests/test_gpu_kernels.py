@@ -688,10 +688,10 @@ def test_gemv_strided_x_through_the_c_abi(m, k, ok):
     _assert_close(y.cpu().numpy(), yd.cpu().numpy(), "strided vs dense")
 
 
-@pytest.mark.parametrize("m", [5, 6, 8])
+@pytest.mark.parametrize("m", [2, 3, 4, 5, 6, 8])
 @pytest.mark.parametrize("k,n_prod", [(4096, 4096), (3584, 3584), (8192, 8192)])
 def test_gemv_rmsnorm_from_partial_sums(m, k, n_prod):
-    """amq_gemv_grouped_sums_f16 (5 .. 8 sequences): a launch that writes a hidden state leaves one sum of squares per row and 16 output columns
+    """amq_gemv_grouped_sums_f16 (2 .. 8 sequences): a launch that writes a hidden state leaves one sum of squares per row and 16 output columns
     (sums_out); the launch that normalises it adds them in a fixed order and applies gamma * fp16(x * rstd) while staging x (sums_in) -- against
     the oracle on LlamaRMSNorm's formula, against the unfused pair (amq_rmsnorm_f16 + plain GEMV: same value up to the order of the fp32 mean), and
     bit for bit against itself; grouped consumers of several bit-widths; K = 3584 (224 partials: not a multiple of 64) and 8192 (512: the limit)."""
@@ -738,8 +738,8 @@ def test_gemv_rmsnorm_from_partial_sums(m, k, n_prod):
     # what the entry point refuses
     from amq_amd import _lib
     with pytest.raises(_lib.AmqError):
-        ops.gemv_grouped_sums(y1[:4], [dict(qn=segs[0][1], mn=segs[0][2], bits=2, mode=ops.MODE_HQQ, N=512, y=got[0][:4])], kc, gamma=gamma.to(dev),
-                              eps=eps, sums_in=ss[:4])                               # 4 rows: the fused AMQ_PRO_RMSNORM prologue serves those
+        ops.gemv_grouped_sums(y1[:1], [dict(qn=segs[0][1], mn=segs[0][2], bits=2, mode=ops.MODE_HQQ, N=512, y=got[0][:1])], kc, gamma=gamma.to(dev),
+                              eps=eps, sums_in=ss[:1])                               # one row: the fused AMQ_PRO_RMSNORM prologue serves it
     with pytest.raises(_lib.AmqError):
         ops.gemv_grouped_sums(y1, [dict(qn=q, mn=mt, bits=b, mode=ops.MODE_HQQ, N=nn, y=y) for (b, q, mt, _, nn), y in zip(segs, got)], kc,
                               sums_out=torch.empty(m, 512 // 16, dtype=torch.float32, device=dev))      # sums_out describes ONE output

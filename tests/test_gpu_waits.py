@@ -76,6 +76,16 @@ def _corpus():
         return torch.cat([y1] + ys, dim=1)
     cases.append(("gemv partial-sum rmsnorm, 8 rows", sums_pair))
 
+    def sums_pair3():
+        y1 = torch.empty(3, 4096, dtype=torch.float16, device=dev)
+        ss = torch.empty(3, 256, dtype=torch.float32, device=dev)
+        ops.gemv_grouped_sums(a8[:3], [dict(qn=qo, mn=mo, bits=3, mode=ops.MODE_HQQ, N=4096, y=y1, residual=r8[:3])], 4096, sums_out=ss)
+        ys = [torch.empty(3, nn, dtype=torch.float16, device=dev) for _, _, _, nn in segs]
+        ops.gemv_grouped_sums(y1, [dict(qn=q, mn=mt, bits=b, mode=ops.MODE_HQQ, N=nn, y=y) for (b, q, mt, nn), y in zip(segs, ys)], 4096,
+                              gamma=g8, eps=1e-5, sums_in=ss)
+        return torch.cat([y1] + ys, dim=1)
+    cases.append(("gemv partial-sum rmsnorm, 3 rows", sums_pair3))
+
     # ---- few-row launches over fragment-ordered x: the tile form and the streaming form (3 / 6 column blocks per workgroup)
     k2, n2 = 4096, 2048
     for bits in (3, 4):
