@@ -494,8 +494,8 @@ def gemv_math_name():
 
 def load_traffic():
     """HBM bytes per GEMV launch from this round's committed rocprofv3 PMC pass over the CURRENT kernels
-    (profiles/r05_gemv_pmc.json, tools/collect_round.sh r05), or None -- never a stale constant."""
-    p = os.path.join(ROOT, "profiles", "r05_gemv_pmc.json")
+    (profiles/r06_gemv_pmc.json, tools/collect_round.sh r06), or None -- never a stale constant."""
+    p = os.path.join(ROOT, "profiles", "r06_gemv_pmc.json")
     if os.path.exists(p):
         try:
             return json.load(open(p)).get("hbm_bytes_per_launch")
@@ -584,8 +584,8 @@ def run_decode(args, rep, dev):
         gate_ok = out["parity"]["ok"]
         cb = cpu_baseline()
         cpu_model, physical = host_cpu_info()
-        out["cpu_baseline"] = {"value": cb["tokens_per_s_full_model"], "unit": "tokens/s", "cores": cb["cores"],
-                               "best_threads": cb["cores"], "physical_cores": physical, "cpu_model": cpu_model,
+        out["cpu_baseline"] = {"value": cb["tokens_per_s_full_model"], "unit": "tokens/s", "cores": cb["full_model_threads"],
+                               "best_threads": cb["full_model_threads"], "whole_model_thread_probe_tokens_per_s": cb["full_model_thread_probe"], "physical_cores": physical, "cpu_model": cpu_model,
                                "kind": "port", "sample": cb["full_model_sample"], "host_threads": cb["host_threads"],
                                "seconds_per_token": cb["full_model_seconds_per_token"],
                                "linears_only_sample_tokens_per_s": cb["tokens_per_s_predequantized"], "thread_sweep_sample": cb["sample"],

@@ -63,51 +63,73 @@ def _rmsnorm(x, eps):
     return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(torch.float16)        # (gamma = 1: synthetic)
 
 
-def decode_full_model(block, n_block, n_heads, n_kv_heads, lm_head, tokens=8, eps=1e-5, theta=10000.0, prompt_token=1):
-    """``tokens`` greedy decode tokens of a whole decoder on the host cores (torch CPU ops, the current thread count), after one un-timed token.
-    block: the seven pre-dequantized fp16 matrices of ONE block in forward order (q, k, v, o, gate, up, down); every one of the ``n_block`` blocks gets
-    its own copy (distinct memory: the weights of a token do not fit any cache), the embedding is the lm_head's rows (synthetic model).
-    Returns (seconds per token: list, tokens: list)."""
-    F = torch.nn.functional
-    blocks = [block] + [[w.clone() for w in block] for _ in range(n_block - 1)]
-    H = block[0].shape[1]
-    d = H // n_heads
-    ctx = tokens + 2
-    kc = [torch.zeros(n_kv_heads, ctx, d, dtype=torch.float16) for _ in range(n_block)]
-    vc = [torch.zeros(n_kv_heads, ctx, d, dtype=torch.float16) for _ in range(n_block)]
-    inv = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
-    rep = n_heads // n_kv_heads
+class FullModel:
+    """A whole synthetic decoder on the host: ``n_block`` blocks, each with its OWN copy of the seven pre-dequantized fp16 matrices of ``block`` (forward
+    order q, k, v, o, gate, up, down; distinct memory: a token's weights fit no cache), gamma = 1, the embedding = the lm_head's rows.  ``step`` is the
+    forward the reference's CPU model runs for one new token: RMSNorm, q / k / v, rotary embedding, cache append, softmax attention over the cache,
+    o_proj + residual, RMSNorm, SiLU-gated MLP + residual; ``next_token`` adds the final norm, the lm_head and the arg-max."""
 
-    def rope(t, pos):
-        fr = pos * inv
+    def __init__(self, block, n_block, n_heads, n_kv_heads, lm_head, max_ctx=64, eps=1e-5, theta=10000.0):
+        self.blocks = [block] + [[w.clone() for w in block] for _ in range(n_block - 1)]
+        self.nh, self.nkv, self.lm_head, self.eps = n_heads, n_kv_heads, lm_head, eps
+        self.H = block[0].shape[1]
+        self.d = self.H // n_heads
+        self.kc = [torch.zeros(n_kv_heads, max_ctx, self.d, dtype=torch.float16) for _ in range(n_block)]
+        self.vc = [torch.zeros(n_kv_heads, max_ctx, self.d, dtype=torch.float16) for _ in range(n_block)]
+        self.inv = 1.0 / (theta ** (torch.arange(0, self.d, 2, dtype=torch.float32) / self.d))
+        self.pos, self.tok = 0, 1
+
+    def _rope(self, t, pos):
+        fr = pos * self.inv
         cos, sin = torch.cat([fr, fr]).cos().to(torch.float16), torch.cat([fr, fr]).sin().to(torch.float16)
-        return t * cos + torch.cat([-t[..., d // 2:], t[..., :d // 2]], -1) * sin
+        return t * cos + torch.cat([-t[..., self.d // 2:], t[..., :self.d // 2]], -1) * sin
 
-    def step(tok, pos):
-        x = lm_head[tok:tok + 1].clone()
-        for b, (wq, wk, wv, wo, wg, wu, wd) in enumerate(blocks):
-            h = _rmsnorm(x, eps)
-            q = rope(F.linear(h, wq).view(n_heads, d), pos)
-            kc[b][:, pos] = rope(F.linear(h, wk).view(n_kv_heads, d), pos)
-            vc[b][:, pos] = F.linear(h, wv).view(n_kv_heads, d)
-            k = kc[b][:, :pos + 1].repeat_interleave(rep, 0)
-            v = vc[b][:, :pos + 1].repeat_interleave(rep, 0)
+    def next_token(self):
+        F = torch.nn.functional
+        pos, d, rep = self.pos, self.d, self.nh // self.nkv
+        x = self.lm_head[self.tok:self.tok + 1].clone()
+        for b, (wq, wk, wv, wo, wg, wu, wd) in enumerate(self.blocks):
+            h = _rmsnorm(x, self.eps)
+            q = self._rope(F.linear(h, wq).view(self.nh, d), pos)
+            self.kc[b][:, pos] = self._rope(F.linear(h, wk).view(self.nkv, d), pos)
+            self.vc[b][:, pos] = F.linear(h, wv).view(self.nkv, d)
+            k = self.kc[b][:, :pos + 1].repeat_interleave(rep, 0)
+            v = self.vc[b][:, :pos + 1].repeat_interleave(rep, 0)
             p = torch.softmax(torch.einsum("hd,htd->ht", q.float(), k.float()) / d ** 0.5, -1).to(torch.float16)
-            a = torch.einsum("ht,htd->hd", p.float(), v.float()).to(torch.float16).reshape(1, H)
+            a = torch.einsum("ht,htd->hd", p.float(), v.float()).to(torch.float16).reshape(1, self.H)
             x = x + F.linear(a, wo)
-            h2 = _rmsnorm(x, eps)
+            h2 = _rmsnorm(x, self.eps)
             x = x + F.linear(F.silu(F.linear(h2, wg)) * F.linear(h2, wu), wd)
-        return int(F.linear(_rmsnorm(x, eps), lm_head).float().argmax())
+        self.tok = int(F.linear(_rmsnorm(x, self.eps), self.lm_head).float().argmax())
+        self.pos += 1
+        return self.tok
 
-    times, toks = [], []
-    with torch.inference_mode():
-        tok = step(prompt_token, 0)                      # un-timed: first touch of every page
-        for i in range(tokens):
-            t0 = time.perf_counter()
-            tok = step(tok, i + 1)
-            times.append(time.perf_counter() - t0)
-            toks.append(tok)
-    return times, toks
+    def timed_tokens(self, n):
+        """seconds of each of ``n`` greedy tokens"""
+        out = []
+        with torch.inference_mode():
+            for _ in range(n):
+                t0 = time.perf_counter()
+                self.next_token()
+                out.append(time.perf_counter() - t0)
+        return out
+
+
+def decode_full_model(block, n_block, n_heads, n_kv_heads, lm_head, tokens=8, thread_counts=None, probe_tokens=2):
+    """``tokens`` greedy decode tokens of the whole model at the best of ``thread_counts`` (each probed with ``probe_tokens`` tokens after one un-timed
+    token that touches every page: the whole forward -- small normalisation / attention ops between the GEMVs -- does not peak where a GEMV alone does).
+    Returns (seconds per token: list, threads used, {threads: probe tokens/s})."""
+    thread_counts = list(thread_counts or [torch.get_num_threads()])
+    m = FullModel(block, n_block, n_heads, n_kv_heads, lm_head, max_ctx=2 + len(thread_counts) * probe_tokens + tokens)
+    torch.set_num_threads(thread_counts[0])
+    m.timed_tokens(1)                                   # un-timed: first touch of every page
+    probe = {}
+    for nt in thread_counts:
+        torch.set_num_threads(nt)
+        probe[nt] = 1.0 / float(np.median(m.timed_tokens(probe_tokens)))
+    best = max(probe, key=probe.get)
+    torch.set_num_threads(best)
+    return m.timed_tokens(tokens), best, probe
 
 
 def time_decode_linears(layers, n_block_total, tokens=3, extra_dense=None, sample_blocks=4, thread_counts=None,
@@ -158,12 +180,17 @@ def time_decode_linears(layers, n_block_total, tokens=3, extra_dense=None, sampl
         t_dense = _time_tokens([extra_dense], [xd], 1) if extra_dense is not None else 0.0
     full = {}
     if full_model is not None and extra_dense is not None:
-        t_tok, toks = decode_full_model(deq, n_block_total, full_model[0], full_model[1], extra_dense, tokens=full_tokens)
-        full = {"tokens_per_s_full_model": 1.0 / float(np.median(t_tok)), "full_model_tokens": len(t_tok),
+        del mats, xs                                    # (the sample's matrices: 1.6 GB the whole model does not need)
+        cand = sorted(sweep, key=sweep.get, reverse=True)[:3]
+        t_tok, full_threads, probe = decode_full_model(deq, n_block_total, full_model[0], full_model[1], extra_dense, tokens=full_tokens, thread_counts=cand)
+        torch.set_num_threads(best)
+        full = {"tokens_per_s_full_model": 1.0 / float(np.median(t_tok)), "full_model_tokens": len(t_tok), "full_model_threads": full_threads,
+                "full_model_thread_probe": {str(k): round(v, 3) for k, v in probe.items()},
                 "full_model_seconds_per_token": [round(t, 5) for t in t_tok],
-                "full_model_sample": f"{n_block_total} of {n_block_total} blocks, {len(t_tok)} greedy tokens after one un-timed token (pre-dequantized fp16 weights, "
+                "full_model_sample": f"{n_block_total} of {n_block_total} blocks, {len(t_tok)} greedy tokens (pre-dequantized fp16 weights, "
                                      f"{sum(w.numel() for w in deq) * 2 * n_block_total / 1e9:.1f} GB; whole decoder forward incl. norms, rotary embedding, attention over the "
-                                     f"cache, lm_head, arg-max), {best} threads; tokens/s = 1 / median token time"}
+                                     f"cache, lm_head, arg-max) at {full_threads} threads = the best of {sorted(probe)} probed on the whole model (2 tokens each, after one "
+                                     f"un-timed token); tokens/s = 1 / median token time"}
     return {
         **full,
         "tokens_per_s_predequantized": sweep[best],
