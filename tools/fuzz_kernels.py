@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random-shape sweep of the C-ABI matmul entry points against the CPU oracle (GPU box; test infrastructure, not product): random (rows, N, K, bits,
-prologue, bias / residual, strided x, segments) for the GEMV family, random (rows, N, K, bits, route) for the GEMM family, the tests' parity bar.
+prologue, bias / residual, strided x, segments) for the GEMV family (incl. the partial-sum RMSNorm pair of the 2 .. 8-row steps), random (rows, N, K, bits, route) for the GEMM family, the tests' parity bar.
 usage: fuzz_kernels.py [cases=150] [seed=0]   -- prints every failing case and exits non-zero if there was one."""
 import os, sys, random
 import numpy as np
@@ -48,7 +48,42 @@ for c in range(cases):
     K = 128 * rng.choice([1, 2, 3, 5, 8, 11, 16, 24, 32, 33, 40, 43, 64, 86])
     what = None
     try:
-        if rng.random() < 0.6:          # ---- GEMV family
+        if rng.random() < 0.15:         # ---- 2 .. 8 rows, RMSNorm from partial sums: producer (sums_out) + consumer (sums_in) against the oracle
+            K = 128 * rng.choice([16, 24, 28, 32, 40, 43, 64])
+            m = rng.choice([2, 3, 4, 5, 6, 7, 8])
+            if m > ops.gemv_max_rows(K, plain=True):
+                m = 2
+            bits_p = rng.choice([2, 3, 4])
+            qn, mn, w = layer(bits_p, K, K, 11 * c)                       # producer: K -> K with a residual (an o_proj)
+            a_in = torch.randn(m, K, generator=gen).to(torch.float16)
+            res = torch.randn(m, K, generator=gen).to(torch.float16)
+            y1 = torch.empty(m, K, dtype=torch.float16, device=dev)
+            ss = torch.empty(m, K // 16, dtype=torch.float32, device=dev)
+            what = f"gemv_sums m={m} K={K} bits={bits_p}"
+            ops.gemv_grouped_sums(a_in.to(dev), [dict(qn=qn, mn=mn, bits=bits_p, mode=ops.MODE_HQQ, N=K, y=y1, residual=res.to(dev))], K, sums_out=ss)
+            r1 = (res.numpy() + linear_ref.linear_f16(a_in.numpy(), w)).astype(np.float16)
+            ok, worst = close(y1.cpu().numpy(), r1, np.abs(linear_ref.linear_f16(a_in.numpy(), w).astype(np.float32)))
+            want_ss = y1.float().pow(2).view(m, K // 16, 16).sum(-1)
+            ok = ok and bool(torch.allclose(ss, want_ss, rtol=1e-5, atol=1e-6))
+            gamma = (1.0 + 0.1 * torch.randn(K, generator=gen)).to(torch.float16)
+            nseg = rng.choice([1, 2, 3])
+            segs, refs = [], []
+            xin = rms_ref(y1.cpu(), gamma, 1e-5)
+            for sgi in range(nseg):
+                bits = rng.choice([2, 3, 4])
+                n = 16 * rng.choice([2, 7, 33, 64, 256])
+                q2, m2, w2 = layer(bits, n, K, 17 * c + sgi)
+                y = torch.empty(m, n, dtype=torch.float16, device=dev)
+                segs.append(dict(qn=q2, mn=m2, bits=bits, mode=ops.MODE_HQQ, N=n, y=y))
+                refs.append(linear_ref.linear_f16(xin.numpy(), w2))
+            ops.gemv_grouped_sums(y1, segs, K, gamma=gamma.to(dev), eps=1e-5, sums_in=ss)
+            for sg, r in zip(segs, refs):
+                o2, w2_ = close(sg["y"].cpu().numpy(), r, None)
+                ok, worst = ok and o2, max(worst, w2_)
+            if not ok:
+                fails += 1
+                print("FAIL", what, "worst/bar", worst, flush=True)
+        elif rng.random() < 0.6:        # ---- GEMV family
             m = rng.choice([1, 1, 1, 2, 3, 4, 5, 7, 8, 9, 12, 16])
             nseg = rng.choice([1, 1, 2, 3])
             pro = rng.choice([ops.PRO_NONE, ops.PRO_RMSNORM, ops.PRO_SILU_MUL])
@@ -100,7 +135,7 @@ for c in range(cases):
                     y_, r_ = sg["y"].float().cpu().numpy(), np.asarray(r, np.float32)
                     rms_ = float(np.sqrt(np.mean(r_.astype(np.float64) ** 2)))
                     # (AMQ_MATH_LINEAR's tested bound is one ulp + 2e-3 rms: no per-weight rounding at all)
-                    bar_ = (2.0 ** -9 * np.abs(r_) + 1.25e-3 * rms_ if math == ops.MATH_GROUPSCALE else 2.0 ** -10 * np.abs(r_) + 2e-3 * rms_) + (0 if b is None else 2.0 ** -10 * b)
+                    bar_ = (2.0 ** -9 * np.abs(r_) + 1.25e-3 * rms_ if math == ops.MATH_GROUPSCALE else 2.0 ** -10 * np.abs(r_) + 2e-3 * rms_) + (0 if b is None else 2.0 ** -9 * b)      # (bias AND residual behind an opt-in arithmetic: two more fp16 roundings of intermediates that may differ by an ulp each)
                     e_ = np.abs(y_ - r_)
                     ok, worst = not (e_ > bar_).any(), float((e_ / bar_).max())
                 if not ok:
