@@ -99,6 +99,7 @@ SIGNATURES = {
     "amq_gemv_f16w_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp]),
     "amq_decode_tail_batch_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "amq_decode_tail_suppress_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "amq_set_token_f16": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "amq_attn_prefill_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 10 + [_vp]),
     "amq_rope_cache_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "amq_rope_cache_batch_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -835,6 +835,16 @@ int amq_decode_tail_suppress_f16(const void* logits, int vocab, const void* embe
                                              suppress_ids), "decode_tail_suppress");
 }
 
+int amq_set_token_f16(const long long* token_in, int n_in, const void* embed, int vocab, int hidden, long long* token, const int* pos, void* x,
+                      const void* rope_table, void* rope_cur, int rope_rows, int batch, void* stream) {
+    if (!token_in || !embed || !token || !pos || !x) return fail(AMQ_EINVAL, "null pointer");
+    if ((rope_table == nullptr) != (rope_cur == nullptr)) return fail(AMQ_EINVAL, "rope_table and rope_cur go together");
+    if (rope_cur && rope_rows < 1) return fail(AMQ_EINVAL, "rope_rows must be the number of rows of rope_table");
+    if (vocab < 1 || hidden < 8 || (hidden % 8) != 0) return fail(AMQ_ESHAPE, "need vocab >= 1 and hidden %% 8 == 0 (got %d, %d)", vocab, hidden);
+    if (batch < 1 || batch > 65535 || (n_in != 1 && n_in != batch)) return fail(AMQ_ESHAPE, "batch %d with %d input ids (1 or one per sequence)", batch, n_in);
+    return check_hip(amq::launch_set_token(token_in, n_in, embed, vocab, hidden, token, pos, x, rope_table, rope_cur, rope_rows, batch, (hipStream_t)stream), "set_token");
+}
+
 int amq_rope_table_f16(void* table, int max_seq, float rope_theta, void* stream) {
     if (!table || max_seq < 1) return fail(AMQ_EINVAL, "bad rope table request");
     return check_hip(amq::launch_rope_table(table, max_seq, rope_theta, (hipStream_t)stream), "rope_table");

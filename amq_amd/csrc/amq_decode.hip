@@ -287,6 +287,32 @@ hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, 
     return hipGetLastError();
 }
 
+// The step-state side of "this is the next input token" in one launch (what a caller that feeds tokens itself -- model(ids, start_pos=...) token by
+// token, speed.py:76-90 -- otherwise does with an index copy, an embedding gather and a table-row gather): token[b] = token_in[b] (one id broadcast
+// when n_in == 1), x[b] = embed[token[b]], rope_cur = rope_table[min(pos, rope_rows - 1)].  The position itself is not touched.
+__global__ __launch_bounds__(256) void set_token_kernel(const long long* token_in, int n_in, const _Float16* embed, int vocab, int hidden, long long* token,
+                                                         const int* pos, _Float16* x, const _Float16* rope_table, _Float16* rope_cur, int rope_rows) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    long long t = token_in[n_in == 1 ? 0 : b];
+    t = t < 0 ? 0 : t >= vocab ? vocab - 1 : t;                      // (an id outside the vocabulary must not become an out-of-bounds gather)
+    if (tid == 0) token[b] = t;
+    if (b == 0 && rope_cur && tid < 128) {
+        int p = pos[0];
+        p = p < 0 ? 0 : p < rope_rows ? p : rope_rows - 1;
+        rope_cur[tid] = rope_table[(size_t)p * 128 + tid];
+    }
+    const _Float16* row = embed + (size_t)t * hidden;
+    _Float16* xr = x + (size_t)b * hidden;
+    for (int c = tid; c < (hidden >> 3); c += 256) *(h8*)(xr + 8 * c) = *(const h8*)(row + 8 * c);
+}
+
+hipError_t launch_set_token(const void* token_in, int n_in, const void* embed, int vocab, int hidden, void* token, const void* pos, void* x,
+                            const void* rope_table, void* rope_cur, int rope_rows, int batch, hipStream_t st) {
+    hipLaunchKernelGGL(set_token_kernel, dim3(batch), dim3(256), 0, st, (const long long*)token_in, n_in, (const _Float16*)embed, vocab, hidden,
+                       (long long*)token, (const int*)pos, (_Float16*)x, (const _Float16*)rope_table, (_Float16*)rope_cur, rope_rows);
+    return hipGetLastError();
+}
+
 // ------------------------------------------ RoPE + KV append + attention
 // grid = (n_heads, batch); 512 threads; head_dim == 128.
 // KV cache layout: [batch][kv_head][max_seq][128] fp16 (keys already rotated).

@@ -178,6 +178,8 @@ hipError_t launch_rope_rows(void* q, void* k, const void* rope_table, int rope_r
 hipError_t launch_silu_mul(const void* gate, const void* up, void* out, long n, hipStream_t st);
 hipError_t launch_decode_tail(const void* logits, int vocab, const void* embed, int hidden, void* token, void* pos, void* x,
                               const void* rope_table, void* rope_cur, int rope_rows, hipStream_t st, int batch = 1, const void* suppress = nullptr);
+hipError_t launch_set_token(const void* token_in, int n_in, const void* embed, int vocab, int hidden, void* token, const void* pos, void* x,
+                            const void* rope_table, void* rope_cur, int rope_rows, int batch, hipStream_t st);
 hipError_t launch_gemv_f16w(const void* x, const void* W, const void* bias, void* y, const void* gamma, float eps,
                             int N, int K, hipStream_t st, int M = 1);      // x [M, K], y [M, N], M <= 8
 

@@ -436,6 +436,9 @@ class QuantLlama:
     def set_token(self, token):
         """make ``token`` (int or 1-element tensor) the input of the next decode step; also re-derives what the step
         reads besides the token (embedding row, cos/sin row of the current position) -- set_pos() first"""
+        if isinstance(token, torch.Tensor) and token.is_cuda and token.dtype is torch.int64 and token.numel() in (1, self.B) and token.is_contiguous():
+            # one launch instead of five framework ops (a caller that feeds every token itself pays this per token: hf_fast's forward)
+            return ops.set_token(token, self.embed, self.token, self.pos, self.x, table=self.rope_tab, cur=self.rope_cur)
         if isinstance(token, torch.Tensor):
             self.token.copy_(token.reshape(-1).expand(self.B) if token.numel() == 1 else token.reshape(self.B))
         else:

@@ -644,6 +644,24 @@ def decode_tail(logits, embed, token, pos, x, table=None, cur=None, suppress=Non
                                                          _lib.current_stream()))
 
 
+def set_token(token_in, embed, token, pos, x, table=None, cur=None):
+    """token = token_in (int64 CUDA tensor: one id, or one per sequence), x = embed[token], cur = table[pos] -- one launch (amq_set_token_f16); pos unchanged"""
+    vocab, hidden = embed.shape
+    B = token.numel()
+    n_in = token_in.numel()
+    _need(token_in, torch.int64, "token_in", n_in)
+    _need(embed, torch.float16, "embed", vocab * hidden)
+    _need(token, torch.int64, "token", B)
+    _need(pos, torch.int32, "pos", 1)
+    _need(x, torch.float16, "x", B * hidden)
+    if cur is not None:
+        _need(cur, torch.float16, "rope_cur", 128)
+        _need(table, torch.float16, "rope table")
+    _lib.check(_lib.load().amq_set_token_f16(_lib.ptr(token_in), n_in, _lib.ptr(embed), vocab, hidden, _lib.ptr(token), _lib.ptr(pos), _lib.ptr(x),
+                                             _lib.ptr(table) if cur is not None else None, _lib.ptr(cur), table.numel() // 128 if cur is not None else 0, B,
+                                             _lib.current_stream()))
+
+
 def rope_cache(q, k, v, kcache, vcache, table, pos0, n_heads, n_kv_heads):
     """Prefill glue: rotate q [S, n_heads*128] in place, rotate k [S, n_kv_heads*128] into kcache[h, pos0+s], copy v into
     vcache (both [n_kv_heads, max_seq, 128]); ``table`` from :func:`rope_table`.

@@ -292,6 +292,11 @@ int amq_decode_tail_f16(const void* logits, int vocab, const void* embed, int hi
 /* The same with up to 8 token ids that are never chosen: suppress_ids = device int32 [8], -1 = unused slot (the values may change between replays
  * of a captured step; the pointer may not).  What HF's MinNewTokensLengthLogitsProcessor does to the EOS ids while min_new_tokens has not been
  * reached -- generate(min_new_tokens = max_new_tokens = n), amq/utils/speed.py:31-36 -- i.e. on every step of the reference's TPS loop. */
+/* "This is the next input token" for a captured token step whose caller feeds the tokens itself (model(ids, start_pos=...) token by token,
+ * amq/utils/speed.py:76-90): token[b] = token_in[b] (n_in == batch) or token_in[0] (n_in == 1), clamped to the vocabulary; x[b] = embed[token[b]];
+ * rope_cur = rope_table[min(*pos, rope_rows - 1)] (both or neither, as above).  The position is not changed.  All pointers device. */
+int amq_set_token_f16(const long long* token_in, int n_in, const void* embed, int vocab, int hidden, long long* token, const int* pos, void* x,
+                      const void* rope_table, void* rope_cur, int rope_rows, int batch, void* stream);
 int amq_decode_tail_suppress_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,
                                  const void* rope_table, void* rope_cur, int rope_rows, int batch, const int* suppress_ids, void* stream);
 int amq_decode_tail_batch_f16(const void* logits, int vocab, const void* embed, int hidden, long long* token, int* pos, void* x,

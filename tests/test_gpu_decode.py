@@ -854,3 +854,28 @@ def test_attn_prefill_matches_eager_formula(S, nh, nkv, batch, pos0):
     again = ops.attn_prefill(q, kc if pos0 else k, vc if pos0 else v, torch.empty_like(q), S, nh, nkv, batch=batch, pos0=pos0,
                              kv_cache=bool(pos0))
     assert torch.equal(again, out)
+
+
+def test_set_token_kernel_equals_the_framework_ops():
+    """amq_set_token_f16 (next input token + embedding row + the position's cos/sin row in one launch: what hf_fast's forward pays per fed token) leaves the
+    step state the five framework ops leave; one id broadcast over a batch; ids outside the vocabulary are clamped, not gathered out of bounds"""
+    from amq_amd import arch
+    from amq_amd.llama import QuantLlama
+    cfg = dict(arch._cfg(1, 512, 1024, 4, 4, 1, vocab=1024))
+    for B in (1, 3):
+        m = QuantLlama(cfg, None, device="cuda:0", max_seq=64, seed=2, batch=B)
+        for pos, toks in ((0, [5] * B), (17, list(range(7, 7 + B))), (63, [1023] * B)):
+            m.set_pos(pos)
+            for t in (toks[0],) if B == 1 else ():
+                m.set_token(int(t))                                   # the framework-op path (a Python int)
+                want = (m.token.clone(), m.x.clone(), m.rope_cur.clone())
+                m.x.zero_(); m.token.zero_(); m.rope_cur.zero_()
+                m.set_token(torch.tensor([t], dtype=torch.int64, device="cuda:0"))      # the kernel
+                assert torch.equal(m.token, want[0]) and torch.equal(m.x, want[1]) and torch.equal(m.rope_cur, want[2])
+            tt = torch.tensor(toks, dtype=torch.int64, device="cuda:0")
+            m.set_token(tt)
+            assert torch.equal(m.token, tt) and torch.equal(m.x, m.embed[tt]) and torch.equal(m.rope_cur.view(-1), m.rope_tab.view(64, 128)[pos])
+            m.set_token(tt[:1])                                       # one id for every sequence
+            assert torch.equal(m.token, tt[:1].expand(B)) and torch.equal(m.x, m.embed[tt[:1]].expand(B, -1))
+        m.set_token(torch.tensor([5000] * B, dtype=torch.int64, device="cuda:0"))
+        assert int(m.token.max()) == 1023
