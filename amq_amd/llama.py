@@ -279,6 +279,9 @@ class QuantLlama:
         attn0 = model.model.layers[0].self_attn
         if any(hasattr(attn0, n) for n in ("q_norm", "k_norm")):
             raise ValueError("from_hf: per-head q / k norms are not part of the runner's block")
+        from .quant_linear import HIPQuantLinear
+        if not isinstance(getattr(attn0, "q_proj", None), HIPQuantLinear):
+            raise ValueError("from_hf: the decoder linears are not HIPQuantLinear modules: run prepare_for_inference(model, backend='hip') first")
         rp = hf.get("rope_parameters") or {}
         if hf.get("rope_theta") is None:
             hf["rope_theta"] = rp.get("rope_theta", 10000.0)
