@@ -14,6 +14,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_tree():
+    """a checkout without build products (libraries, kept device assembly) and with hipcc at hand: build once, as __graft_entry__.build() does.
+    Nothing is rebuilt when the products exist -- a stale build is for tests/test_waits_cpu.py to report, not to paper over."""
+    import glob
+    import shutil
+    import subprocess
+    pkg = os.path.join(ROOT, "amq_amd")
+    have = (os.path.exists(os.path.join(pkg, "libamq_hip.so")) and os.path.exists(os.path.join(pkg, "libamq_hip_safe.so"))
+            and glob.glob(os.path.join(pkg, "csrc", "asm", "*.s")))
+    if not have and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.run(["make", "-C", os.path.join(pkg, "csrc"), "-j", str(min(8, os.cpu_count() or 1)), "all", "safe"],
+                       check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
