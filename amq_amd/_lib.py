@@ -21,7 +21,7 @@ PRO_NONE, PRO_RMSNORM, PRO_SILU_MUL = 0, 1, 2
 MAX_SEGMENTS = 4
 MATH_DEFAULT, MATH_LINEAR, MATH_GROUPSCALE, MATH_EXACT = 0, 1, 2, 3
 FEWROW_AUTO, FEWROW_TILE, FEWROW_STREAM = 0, 1, 2      # kernel form of the grouped few-row launch (amq_gemm_xfrag_grouped_form_f16)
-ABI_VERSION = 520            # include/amq_hip.h AMQ_VERSION these bindings mirror (checked at load)
+ABI_VERSION = 521            # include/amq_hip.h AMQ_VERSION these bindings mirror (checked at load)
 GEMM_AUTO, GEMM_TILED, GEMM_SKINNY, GEMM_RING, GEMM_RING128, GEMM_WS, GEMM_DEQ = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -110,6 +110,7 @@ SIGNATURES = {
     "amq_gemm_f16w_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "amq_gemm_route_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "amq_gemm_route_workspace_bytes_g": (_sz, [_i, _i, _i, _i, _i]),
+    "amq_gemm_res_norm_xfrag_f16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _f, _vp, _vp]),
     "amq_gemm_route_f16": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 

@@ -278,9 +278,9 @@ static int check_fine_route(int route, int group, int M, int N, int K, const voi
     return AMQ_OK;
 }
 
-int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
-                       const void* residual, void* y, int M, int N, int K, int group, int x_stride, int y_stride,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+static int gemm_route_impl(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
+                           const void* residual, void* y, int M, int N, int K, int group, int x_stride, int y_stride,
+                           void* workspace, size_t workspace_bytes, void* stream, amq::GemmNorm* norm) {
     if (route < AMQ_GEMM_AUTO || route > AMQ_GEMM_DEQ) return fail(AMQ_EINVAL, "unknown GEMM route %d", route);
     if (int rc = check_shape(bits, N, K, group)) return rc;
     if (int rc = check_mode(mode)) return rc;
@@ -304,7 +304,22 @@ int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void*
                     use_ws && deq ? workspace : nullptr, amq::meta_pairs(group)};
     if ((route == AMQ_GEMM_DEQ || (fine && deq)) && !amq::gemm_f16w_ok(M, N, K, a.x_stride, a.y_stride))
         return fail(AMQ_ESHAPE, "AMQ_GEMM_DEQ: strides must be multiples of 8 (x) / 4 (y) halves and x, W must each span < 4 GiB");
-    return check_hip(amq::launch_gemm(a, (hipStream_t)stream, route), "gemm");
+    return check_hip(amq::launch_gemm(a, (hipStream_t)stream, route, norm), "gemm");
+}
+
+int amq_gemm_route_f16(int route, int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias,
+                       const void* residual, void* y, int M, int N, int K, int group, int x_stride, int y_stride,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_route_impl(route, bits, mode, x, qn, mn, bias, residual, y, M, N, K, group, x_stride, y_stride, workspace, workspace_bytes, stream, nullptr);
+}
+
+int amq_gemm_res_norm_xfrag_f16(int bits, int mode, const void* x, const void* qn, const void* mn, const void* bias, const void* residual,
+                                void* y, int M, int N, int K, int group, int x_stride, void* workspace, size_t workspace_bytes,
+                                const void* gamma, float eps, void* xf, void* stream) {
+    if (!gamma || !xf) return fail(AMQ_EINVAL, "null pointer");
+    if (N < 128 || (N % 128) != 0) return fail(AMQ_ESHAPE, "the normed rows are handed on in fragment order: N %% 128 == 0 (got N=%d)", N);
+    amq::GemmNorm norm{gamma, eps, xf, false};
+    return gemm_route_impl(AMQ_GEMM_AUTO, bits, mode, x, qn, mn, bias, residual, y, M, N, K, group, x_stride, 0, workspace, workspace_bytes, stream, &norm);
 }
 
 int amq_gemm_gated_fused_g(int route, int M, int N, int K, int use_workspace, int group) {

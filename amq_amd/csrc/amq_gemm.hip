@@ -198,6 +198,86 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, con
     *(h8*)(y + (size_t)m * y_stride + n) = o;
 }
 
+// The split-K reduce of a launch whose rows go straight into an RMSNorm (down_proj -> the next block's input norm on a short prompt pass): ONE launch
+// per 64-row group instead of two.  One workgroup per row of the padded groups: the row's sums over the splits (splitk_reduce_kernel's expression and
+// order), bias / residual, y stored; the sum of squares of the ROUNDED row taken from the registers that hold it, in rmsnorm_kernel's order (thread t:
+// chunks t, t + 256, ...; wave sums; the four waves in order), then gamma * fp16(y * rstd) in fragment order (rmsnorm_kernel<true>'s layout; rows
+// M .. 64 ceil(M / 64) - 1 as zeros).  Bit-identical to the two launches (tests/test_gpu_kernels.py::test_gemm_splitk_norm_xfrag_equals_two_launches).
+// Rows of up to 8192 columns (four 8-column chunks per thread); wider rows keep the two launches.
+constexpr int RN_CHUNKS = 4;
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* ws, const _Float16* bias, const _Float16* res, _Float16* y,
+                                                                int M, int N, int y_stride, int splits, const _Float16* gamma, float eps,
+                                                                _Float16* xf) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    const bool live = m < M;
+    const int nchunk = N >> 3;
+    h8 row[RN_CHUNKS];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < RN_CHUNKS; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < nchunk && live) {
+            const int n = c * 8;
+            // every split's partials requested before the first is added (gemm_pick_splits gives at most 8: one round trip instead of one per split)
+            f4 lo[8], hi[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int sc = s < splits ? s : splits - 1;
+                lo[s] = *(const f4*)(ws + ((size_t)sc * M + m) * N + n);
+                hi[s] = *(const f4*)(ws + ((size_t)sc * M + m) * N + n + 4);
+            }
+            h8 o, rv;
+            if (res) rv = *(const h8*)(res + (size_t)m * y_stride + n);
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < splits) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[e] += lo[s][e]; acc[4 + e] += hi[s][e]; }
+                }
+            for (int s = 8; s < splits; ++s) {                      // (not reached with today's policy)
+                const f4 l2 = *(const f4*)(ws + ((size_t)s * M + m) * N + n);
+                const f4 h2_ = *(const f4*)(ws + ((size_t)s * M + m) * N + n + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[e] += l2[e]; acc[4 + e] += h2_[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 v = (_Float16)acc[e];
+                if (bias) v = v + bias[n + e];
+                if (res) v = rv[e] + v;
+                o[e] = v;
+            }
+            *(h8*)(y + (size_t)m * y_stride + n) = o;
+            row[j] = o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { float f = (float)o[i]; ss += f * f; }
+        } else {
+            row[j] = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)N + eps);
+    const int G = N >> 7, gy = m >> 6, mb = (m & 63) >> 4, r = m & 15;
+#pragma unroll
+    for (int j = 0; j < RN_CHUNKS; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < nchunk) {
+            const h8 g = *(const h8*)(gamma + 8 * c);
+            h8 o8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { _Float16 nv = (_Float16)((float)row[j][i] * rstd); o8[i] = g[i] * nv; }
+            if (!live) o8 = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            const int kt = c >> 4, t = (c >> 2) & 3, o = c & 3;     // column 8c = kt*128 + 32t + 8o
+            *(h8*)(xf + ((((size_t)gy * G + kt) * 16 + mb * 4 + t) * 64 + o * 16 + r) * 8) = o8;
+        }
+    }
+}
+
 // ---- skinny GEMM: 9 .. 16*MB*gridDim.y rows -------------------------------------------------------------
 // A few dozen rows are neither GEMV- nor GEMM-shaped: the packed weights are a few MB (one pass, HBM-trivial) and x
 // (M x K fp16, <= 1 MB) lives in L2, so the launch is bound by latency and by how fast the CUs can pull x fragments.
@@ -628,8 +708,19 @@ static hipError_t gemm_launch_cfg(const GemmArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3(ntm * ntn, a.splits), dim3(GM_THREADS), lds, st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || a.splits <= 1) return e;
+    return hipGetLastError();               // (split-K partials: summed by launch_splitk_reduce, behind the tiled dispatch in launch_gemm_nogate)
+}
+
+// the second launch of a split-K GEMM: partials summed in split order (+ bias, + residual); with `norm` (and rows of at most 8 * 256 * RN_CHUNKS columns,
+// dense y) the RMSNorm into fragment order that the caller wants behind it is part of the same launch
+static hipError_t launch_splitk_reduce(const GemmArgs& a, hipStream_t st, GemmNorm* norm) {
+    if (norm && !norm->done && (a.N >> 3) <= 256 * RN_CHUNKS && (a.N & 127) == 0 && a.y_stride == a.N) {
+        hipLaunchKernelGGL(splitk_reduce_norm_kernel, dim3(((a.M + 63) / 64) * 64), dim3(256), 0, st, (const float*)a.ws, (const _Float16*)a.bias,
+                           (const _Float16*)a.residual, (_Float16*)a.y, a.M, a.N, a.y_stride, a.splits, (const _Float16*)norm->gamma, norm->eps,
+                           (_Float16*)norm->xf);
+        norm->done = true;
+        return hipGetLastError();
+    }
     const long items = (long)a.M * (a.N >> 3);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (const float*)a.ws,
                        (const _Float16*)a.bias, (const _Float16*)a.residual, (_Float16*)a.y, a.M, a.N, a.y_stride, a.splits);
@@ -667,7 +758,7 @@ static hipError_t tiled_launch_fine(const GemmArgs& a, hipStream_t st) {
 // 4096^2 M = 4096 876 | 1086, M = 2048 (128-row tiles) 814 | 910, M = 1024 615 | 531 -> stays tiled).
 bool gemm_takes_ring(int M, int N, int K) { return K >= 256 && gemm_many_rows_plan(M, N) != 0; }
 
-static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route);
+static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route, GemmNorm* norm);
 
 // GEMM_ROUTE_AUTO takes the dequantize-once route (amq_gemm_f16.hip behind the dequantize kernel) where the launch is MFMA-bound:
 // at least DEQ_MIN_ROWS rows and at least one full round of 256 x 256 tiles.  Below, the fused kernels win: they read 2-4 bit
@@ -700,17 +791,42 @@ bool gemm_gate_fused(const GemmArgs& a, int route) {
     return ring || gemm_is_skinny(a.M, a.N, a.K, route) || gemm_runs_deq(a, route);
 }
 
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route) {
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route, GemmNorm* norm) {
     StreamDevice sd_(st);                                  // ONE guard for the plan (CU counts), the kernel attributes and the launch itself
-    if (!a.gate) return launch_gemm_nogate(a, st, route);
-    if (gemm_gate_fused(a, route)) return launch_gemm_nogate(a, st, route);
-    GemmArgs b = a;
-    b.gate = nullptr;
-    if (hipError_t e = launch_gemm_nogate(b, st, route)) return e;
-    return launch_silu_mul(a.gate, a.y, a.y, (long)a.M * a.N, st);       // (contiguous y and gate: checked by the caller)
+    if (norm) norm->done = false;
+    hipError_t e;
+    if (!a.gate || gemm_gate_fused(a, route)) {
+        e = launch_gemm_nogate(a, st, route, norm);
+    } else {
+        GemmArgs b = a;
+        b.gate = nullptr;
+        e = launch_gemm_nogate(b, st, route, nullptr);
+        if (e == hipSuccess) e = launch_silu_mul(a.gate, a.y, a.y, (long)a.M * a.N, st);       // (contiguous y and gate: checked by the caller)
+    }
+    if (e != hipSuccess || !norm || norm->done) return e;
+    norm->done = true;                                     // no split-K reduce to carry it: the norm as its own launch (dense y: checked by the caller)
+    return launch_rmsnorm_xfrag(a.y, norm->gamma, norm->xf, a.M, a.N, norm->eps, st);
 }
 
-static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route) {
+static hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st) {
+    if (a.gp > 1) return a.gp == 2 ? tiled_launch_fine<2>(a, st) : tiled_launch_fine<4>(a, st);
+    if (a.mode == MODE_HQQ) {
+        if (a.bits == 4) return gemm_launch_bm<4, MODE_HQQ>(a, st);
+        if (a.bits == 3) return gemm_launch_bm<3, MODE_HQQ>(a, st);
+        return gemm_launch_bm<2, MODE_HQQ>(a, st);
+    }
+    if (a.bits == 4) return gemm_launch_bm<4, MODE_FMA>(a, st);
+    if (a.bits == 3) return gemm_launch_bm<3, MODE_FMA>(a, st);
+    return gemm_launch_bm<2, MODE_FMA>(a, st);
+}
+
+static hipError_t launch_gemm_tiled_reduced(const GemmArgs& a, hipStream_t st, GemmNorm* norm) {
+    const hipError_t e = launch_gemm_tiled(a, st);
+    if (e != hipSuccess || a.splits <= 1) return e;
+    return launch_splitk_reduce(a, st, norm);
+}
+
+static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int route, GemmNorm* norm) {
     if (gemm_runs_deq(a, route)) {
         // MFMA-bound launches: the exact fp16 weights once (amq_dequantize_f16's kernel), then a GEMM with no unpack in its loop
         if (hipError_t e = launch_dequantize(a.bits, a.mode, a.qweight, a.meta, a.N, a.K, a.w16, st, a.gp > 1 ? a.gp : 1)) return e;
@@ -719,8 +835,7 @@ static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int rout
     if (a.gp > 1) {
         if ((route == GEMM_ROUTE_AUTO || route == GEMM_ROUTE_SKINNY) && gemm_fine_takes_skinny(a.M))
             return a.gp == 2 ? skinny_launch_fine<2>(a, st) : skinny_launch_fine<4>(a, st);
-        if (route == GEMM_ROUTE_AUTO || route == GEMM_ROUTE_TILED)
-            return a.gp == 2 ? tiled_launch_fine<2>(a, st) : tiled_launch_fine<4>(a, st);
+        if (route == GEMM_ROUTE_AUTO || route == GEMM_ROUTE_TILED) return launch_gemm_tiled_reduced(a, st, norm);
         return hipErrorInvalidValue;                       // (amq_capi.hip refuses such a call with its reason before it gets here)
     }
     if (route == GEMM_ROUTE_RING && gemm_ring_ok(a)) return launch_gemm_ring(a, st);
@@ -740,14 +855,7 @@ static hipError_t launch_gemm_nogate(const GemmArgs& a, hipStream_t st, int rout
         if (a.bits == 3) return skinny_launch<3, MODE_FMA>(a, st);
         return skinny_launch<2, MODE_FMA>(a, st);
     }
-    if (a.mode == MODE_HQQ) {
-        if (a.bits == 4) return gemm_launch_bm<4, MODE_HQQ>(a, st);
-        if (a.bits == 3) return gemm_launch_bm<3, MODE_HQQ>(a, st);
-        return gemm_launch_bm<2, MODE_HQQ>(a, st);
-    }
-    if (a.bits == 4) return gemm_launch_bm<4, MODE_FMA>(a, st);
-    if (a.bits == 3) return gemm_launch_bm<3, MODE_FMA>(a, st);
-    return gemm_launch_bm<2, MODE_FMA>(a, st);
+    return launch_gemm_tiled_reduced(a, st, norm);
 }
 
 }  // namespace amq

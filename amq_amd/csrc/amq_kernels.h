@@ -106,7 +106,10 @@ struct GemmArgs {
 // route: which kernel family serves the launch (AUTO: by shape; the others force one for tests / A-B tools)
 enum { GEMM_ROUTE_AUTO = 0, GEMM_ROUTE_TILED = 1, GEMM_ROUTE_SKINNY = 2, GEMM_ROUTE_RING = 3, GEMM_ROUTE_RING128 = 4, GEMM_ROUTE_WS = 5,
        GEMM_ROUTE_DEQ = 6 /* launch_dequantize into a.w16, then launch_gemm_f16w */ };
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route = GEMM_ROUTE_AUTO);
+// an RMSNorm of the result rows into fragment order behind the GEMM (gamma [N], xf: amq_xfrag_bytes(M, N)); launch_gemm makes it part of the split-K
+// reduce where the launch has one (splitk_reduce_norm_kernel) and a launch of its own otherwise; `done` is launch_gemm's bookkeeping
+struct GemmNorm { const void* gamma; float eps; void* xf; bool done; };
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t st, int route = GEMM_ROUTE_AUTO, GemmNorm* norm = nullptr);
 bool gemm_gate_fused(const GemmArgs& a, int route);                 // a.gate applied in the kernel's epilogue (else: element-wise launch behind it)
 hipError_t launch_gemm_ring(const GemmArgs& a, hipStream_t st, int bm = 0);      // amq_gemm_ring.hip: 256 (or 128) x 256 tiles, LDS rings, counted waits; bm 0 = by shape
 bool gemm_ring_ok(const GemmArgs& a);

@@ -604,6 +604,7 @@ class QuantLlama:
     # launches.  7B avg-3, ms per prompt pass, this path | the row-major / tiled kernels: 16 rows 2.91 | 2.55, 24 3.03 | 3.13,
     # 32 3.06 | 3.28, 64 3.19 | 3.72, 256 6.74 | 7.32, 384 10.86 | 11.30, 512 12.58 | 11.26
     FRAG_ROWS = (16, 384)
+    FUSE_DOWN_NORM = True       # down_proj's split-K reduce also writes the next block's normed input (A/B: tools/prompt64_time.py)
 
     def _prefill_eager(self, ids, start_pos=0, b=None):
         """(b: sequence of a batched runner -- its slice of the caches and its logits row, position / token left to the caller)
@@ -635,9 +636,10 @@ class QuantLlama:
         # that way by the producing launch): 1.2-1.6x faster few-row GEMMs; down_proj (K = 11008: the
         # per-workgroup x stream is what bounds that kernel) and longer prompts stay on the tiled kernel
         frag = self.FRAG_ROWS[0] < S <= self.FRAG_ROWS[1] and not self.fine
-        for blk in self.blocks:
+        h_next = None                                # the next block's normed input, left behind by this block's down_proj (its split-K reduce carries the norm)
+        for bi, blk in enumerate(self.blocks):
             if frag:
-                h = ops.rmsnorm_xfrag(x, blk["ln1"], self.eps)
+                h = h_next if h_next is not None else ops.rmsnorm_xfrag(x, blk["ln1"], self.eps)
                 q, k, v = lin_xf_group([blk["self_attn." + n] for n in ("q_proj", "k_proj", "v_proj")], h)   # one launch
             else:
                 h = ops.rmsnorm(x, blk["ln1"], self.eps)
@@ -659,7 +661,12 @@ class QuantLlama:
                     act = ops.gemm(h2, u.qn, u.mn, u.bits, u.mode, u.N, u.K, bias=u.bias, gate=g, out=g)
                 else:
                     act = ops.silu_mul(g, lin(blk["mlp.up_proj"], h2), out=g)
-            x = lin(blk["mlp.down_proj"], act, residual=x)
+            if frag and self.FUSE_DOWN_NORM and bi + 1 < len(self.blocks):
+                l = blk["mlp.down_proj"]
+                x, h_next = ops.gemm_res_norm_xfrag(act, l.qn, l.mn, l.bits, l.mode, l.N, l.K, self.blocks[bi + 1]["ln1"], self.eps,
+                                                    bias=l.bias, residual=x, out=x)
+            else:
+                x = lin(blk["mlp.down_proj"], act, residual=x)
         return self._prefill_finish(x, S, start_pos, b)
 
     def _rows_linear(self, l, inp, residual=None):

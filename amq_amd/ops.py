@@ -333,6 +333,34 @@ def gemm(x, qn, mn, bits, mode, N, K, bias=None, out=None, residual=None, route=
     return y.reshape(*x.shape[:-1], N)
 
 
+def gemm_res_norm_xfrag(x, qn, mn, bits, mode, N, K, gamma, eps, bias=None, residual=None, out=None, xf_out=None):
+    """:func:`gemm` (``residual`` fused, dense result rows) followed by :func:`rmsnorm_xfrag` of the result, as one call: returns (y, xf).  Where the
+    GEMM runs split-K -- a short prompt's down_proj -- the sum over the splits and the norm are one launch (include/amq_hip.h:
+    amq_gemm_res_norm_xfrag_f16); same bits as the two calls."""
+    _check_shape(bits, N, K)
+    group = _check_native(qn, mn, bits, N, K, fine=True)
+    x2 = _prep_x(x, K)
+    M = x2.shape[0]
+    if bias is not None:
+        _need(bias, torch.float16, "bias", N)
+    if residual is not None:
+        _need(residual, torch.float16, "residual", M * N)
+    _need(gamma, torch.float16, "gamma", N)
+    y = out if out is not None else torch.empty(M, N, dtype=torch.float16, device=x.device)
+    _need(y, torch.float16, "y", M * N)
+    lib = _lib.load()
+    nbytes = lib.amq_xfrag_bytes(M, N)
+    if nbytes == 0:
+        raise ValueError(f"N = {N}: the normed rows are handed on in fragment order (N % 128 == 0)")
+    xf = xf_out if xf_out is not None else torch.empty(nbytes // 2, dtype=torch.float16, device=x.device)
+    _need(xf, torch.float16, "xf", nbytes // 2)
+    ws, ws_bytes = _route_workspace(lib, x.device, GEMM_AUTO, M, N, K, group)
+    _lib.check(lib.amq_gemm_res_norm_xfrag_f16(bits, mode, _lib.ptr(x2), _lib.ptr(qn), _lib.ptr(mn), _lib.ptr(bias), _lib.ptr(residual),
+                                               _lib.ptr(y), M, N, K, group, 0, _lib.ptr(ws), ws_bytes, _lib.ptr(gamma), float(eps),
+                                               _lib.ptr(xf), _lib.current_stream()))
+    return y.reshape(*x.shape[:-1], N), xf
+
+
 def gemm_f16w(x, w, bias=None, out=None, residual=None, gate=None):
     """y = x . w^T for DENSE fp16 weights w [N, K] (hand-written ping-pong MFMA kernel, amq_gemm_f16.hip): what GEMM_DEQ runs behind
     :func:`dequantize`; ``residual`` / ``gate`` as in :func:`gemm`."""

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define AMQ_VERSION 520            /* 0.5.2: amq_rope_table_freqs_f16 (rope_scaling) and amq_decode_tail_suppress_f16 added, nothing else changed.  0.5.1: the bfloat16 entry points
+#define AMQ_VERSION 521            /* 0.5.2: amq_rope_table_freqs_f16 (rope_scaling) and amq_decode_tail_suppress_f16 added, nothing else changed.  0.5.1: the bfloat16 entry points
                                     * (amq_*_bf16) added.  0.5.0: amq_gemv_opts.math renumbered
                                     * (0 = the build's default), amq_default_gemv_math added; the decode-engine and fused q/k/v-attention entry points live in
                                     * libamq_hip_ab.so (include/amq_hip_ab.h) since 0.4 */
@@ -312,6 +312,14 @@ int amq_decode_tail_batch_f16(const void* logits, int vocab, const void* embed, 
 int amq_gemm_res_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native,
                      const void* bias, const void* residual, void* y, int M, int N, int K, int group, int x_stride,
                      int y_stride, void* workspace, size_t workspace_bytes, void* stream);
+/* amq_gemm_res_f16 (dense y) followed by amq_rmsnorm_xfrag_f16 of its result rows -- y = residual + fp16(x . W^T (+ bias)), xf = the fragment-ordered
+ * gamma * fp16(y * rsqrt(mean(y^2) + eps)) -- as ONE call: where the GEMM runs split-K (few rows, a workspace given) the sum over the splits and the
+ * norm are one launch, otherwise the norm follows as its own.  Same bits as the two calls.  N % 128 == 0; xf: amq_xfrag_bytes(M, N) bytes.
+ * The hand-over between a decoder block's down_proj and the next block's input_layernorm on a short prompt pass (the reference runs both as
+ * separate framework ops: transformers LlamaDecoderLayer as driven by amq/utils/speed.py:150-200).  (ABI 521) */
+int amq_gemm_res_norm_xfrag_f16(int bits, int mode, const void* x, const void* qweight_native, const void* meta_native, const void* bias,
+                                const void* residual, void* y, int M, int N, int K, int group, int x_stride, void* workspace,
+                                size_t workspace_bytes, const void* gamma, float eps, void* xf, void* stream);
 /* The same with the kernel family chosen by the caller (tests, A/B tools); amq_gemm_route_workspace_bytes is the
  * matching workspace query (0: no workspace needed).  The workspace holds split-K partials (few rows) or the dequantized
  * fp16 weights (AMQ_GEMM_DEQ, and AUTO on MFMA-bound launches) -- never both; without it AUTO runs a fused kernel. */

@@ -43,7 +43,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_version_sizes_and_validation():
     lib = _lib.load()
-    assert lib.amq_version() == 520 == _lib.ABI_VERSION
+    assert lib.amq_version() == 521 == _lib.ABI_VERSION
     # native sizes: N*K*bits/8 payload, 4 B of (scale, zero) per (row, group)
     for bits in (2, 3, 4):
         assert lib.amq_native_qweight_bytes(bits, 4096, 4096) == 4096 * 4096 * bits // 8

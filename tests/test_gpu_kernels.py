@@ -1015,6 +1015,38 @@ def test_gemm_big_tiles(bits, m, n, k, route):
     assert torch.equal(inplace, res.to(dev) + y)
 
 
+@pytest.mark.parametrize("m,n,k,bits,bias", [(64, 4096, 11008, 3, False),        # 7B down_proj at the reference protocol's 64 prompt rows: split-K, one launch
+                                              (40, 1024, 2816, 4, True),           # ragged last row group (rows 40 .. 63 of the fragments are zeros), bias
+                                              (150, 5120, 1024, 2, False),         # three row groups, 2.5 chunks per thread
+                                              (64, 8192, 1024, 3, False),          # widest row the fused kernel takes
+                                              (64, 8320, 1024, 4, False),          # wider: the two launches
+                                              (600, 512, 512, 3, True)])           # no split-K (the rows fill the chip): GEMM, then the norm as its own launch
+def test_gemm_splitk_norm_xfrag_equals_two_launches(m, n, k, bits, bias):
+    """amq_gemm_res_norm_xfrag_f16 (a split-K GEMM whose reduce launch also takes the RMSNorm of the result rows into fragment order -- down_proj into the
+    next block's input norm on a short prompt pass) == amq_gemm_res_f16 followed by amq_rmsnorm_xfrag_f16, bit for bit: y and the fragments."""
+    from amq_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=gen).to(torch.float16).to(dev)
+    res = torch.randn(m, n, generator=gen).to(torch.float16).to(dev)
+    gamma = (1.0 + 0.1 * torch.randn(n, generator=gen)).to(torch.float16).to(dev)
+    h, qn, mn, _ = _random_case(bits, n, k, seed=7 * bits + n % 13, bias=bias)
+    b = h.bias.to(dev) if bias else None
+    y_two = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=b, residual=res.clone())
+    xf_two = ops.rmsnorm_xfrag(y_two, gamma, 1e-5)
+    y_one = res.clone()
+    y_ret, xf_one = ops.gemm_res_norm_xfrag(x, qn, mn, bits, ops.MODE_HQQ, n, k, gamma, 1e-5, bias=b, residual=y_one, out=y_one)
+    assert y_ret.data_ptr() == y_one.data_ptr()
+    assert torch.equal(y_one, y_two)
+    assert torch.equal(xf_one, xf_two)
+    # no residual, fresh output
+    y2, xf2 = ops.gemm_res_norm_xfrag(x, qn, mn, bits, ops.MODE_HQQ, n, k, gamma, 1e-5, bias=b)
+    y2_two = ops.gemm(x, qn, mn, bits, ops.MODE_HQQ, n, k, bias=b)
+    assert torch.equal(y2, y2_two) and torch.equal(xf2, ops.rmsnorm_xfrag(y2_two, gamma, 1e-5))
+    with pytest.raises(Exception):
+        ops.gemm_res_norm_xfrag(x, qn, mn, bits, ops.MODE_HQQ, n, k, gamma[: n - 1], 1e-5)
+
+
 @pytest.mark.parametrize("m,k,specs", [(64, 1024, [(4, 512), (2, 256), (3, 384)]),            # q/k/v-like, one column block per workgroup
                                        (40, 512, [(3, 4096), (4, 4096)]),                       # 512 blocks: two per workgroup
                                        (200, 768, [(2, 3072), (3, 1040), (4, 2064)]),           # four per workgroup, ragged last groups, 4 row groups

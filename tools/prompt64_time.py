@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""64-token prompt pass of the 7B avg-3-bit runner (hipGraph replay, HIP events): the harness's GeMM / TTFT shape.  usage: prompt64_time.py [rows]"""
+"""64-token prompt pass of the 7B avg-3-bit runner (hipGraph replay, HIP events): the harness's GeMM / TTFT shape.  usage: prompt64_time.py [rows]
+A/B (environment, this tool only): FUSE_DOWN_NORM=0 -- down_proj's split-K reduce and the next block's RMSNorm as two launches."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from amq_amd import arch
 from amq_amd.llama import QuantLlama
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+if "FUSE_DOWN_NORM" in os.environ:
+    QuantLlama.FUSE_DOWN_NORM = os.environ["FUSE_DOWN_NORM"] != "0"
 dev = torch.device("cuda:0")
 cfg = arch.MODEL_CONFIGS["Llama-2-7b-hf"]
 a, usage = arch.synthesize_arch(cfg, 3.0, seed=0, pinned=arch.PINNED_7B)
@@ -20,4 +23,4 @@ for _ in range(10):
     e0.record(); m.prefill(ids); e1.record(); e1.synchronize()
     ts.append(e0.elapsed_time(e1))
 ts.sort()
-print(f"{rows}-row prompt pass: median {ts[len(ts)//2]:.3f} ms  min {ts[0]:.3f} ms")
+print(f"{rows}-row prompt pass (FUSE_DOWN_NORM={int(QuantLlama.FUSE_DOWN_NORM)}): median {ts[len(ts)//2]:.3f} ms  min {ts[0]:.3f} ms")
