@@ -294,6 +294,370 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Decode step of a GROUPED-QUERY model over a long cache: one workgroup per (kv head, chunk of 64 NT keys) serves all G = n_heads / n_kv_heads
+// query heads of the group -- the group's rotated queries are the (up to 16) rows of ONE MFMA row block, so the chunk's K / V rows are taken in
+// once and scored against every head by the matrix cores.  attn_decode_split_kernel (amq_decode.hip) gives every QUERY head its own workgroups of
+// 16-lane dot products: the heads of a group each take in the same chunk (Llama-3.1-8B, 32 / 8 heads, 8192 cached keys: 1024 workgroups, 23.6 us
+// for 33.6 MB of K + V; a first grouped form of THAT kernel -- rows loaded once, scored against the G queries by the same VALU code, bit-identical
+// -- moved the work, not the time: 22.9 us, and 18.2 against 10.4 at 2048 keys, profiles/r06_attn_gqa.txt: the launch is bound by its vector
+// arithmetic, not by its bytes).
+//   * the chunk's NT tiles of 64 keys x (K | V) are requested at once by LDS-DMA (source-side swizzles of the prompt kernel above), rows at or past
+//     the new token's position clamped to the last cached row; the raw q / k / v of the step and the position's cos / sin pairs are requested
+//     behind them, ONE vmcnt(0) covers everything;
+//   * every lane rotates its query fragments in registers (HF's fp16 expression, the decode kernels'), the first 64 threads the new key -- appended
+//     to the cache by the workgroup whose chunk ends at the new token, which also writes it (and the new value) over the LDS rows at or past the
+//     position, so that no row the MFMAs read was never written;
+//   * wave w takes tile w: S^T = K . Q^T, key mask, per-row maximum and exp2, O^T = V^T . P^T (the prompt kernel's operand layouts); the waves'
+//     (m, l, O) are merged in wave order through LDS;
+//   * one active chunk: normalised output.  Several: (O, m, l) per query head into the split kernel's workspace; attn_gqa_combine_kernel, the next
+//     launch, adds them in chunk order.
+// Numerics: the prompt kernel's -- fp32 scores, exp2 domain, un-normalised probabilities rounded to fp16 before P.V -- within the tests' bound of
+// the eager fp32 formula and of the per-head kernels (tests/test_gpu_decode.py::test_attn_decode_gqa_*); deterministic (fixed merge orders).
+struct AttnGqaArgs {
+    const void* q; const void* k; const void* v; void* kc; void* vc; void* out;
+    const void* state;          // cur mode: the step-state block (cos/sin row, position at byte 256, error word at 260); else a device int32 position or null
+    const void* rope_table;     // [max_seq][64] (cos, sin) pairs, or null (cur mode / computed from rope_theta)
+    float* ws;
+    int pos, n_heads, n_kv_heads, max_seq, n_splits, cur_mode;
+    float rope_theta;
+};
+constexpr int AG_WS_STRIDE = 132;       // floats per (query head, chunk) in the workspace: O[128], m, l, pad (amq_decode.hip: ATT_WS_STRIDE)
+constexpr int AG_OM_STRIDE = 132;       // floats per (wave, query row) of the cross-wave merge area
+constexpr int AG_STAGE = 512;           // bytes in front of the tiles: rotated new key [128], new value [128]
+
+template <int NT>
+__global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnGqaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int r = lane & 15, o = lane >> 4;
+    const int kvh = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
+    const int G = a.n_heads / a.n_kv_heads, h0 = kvh * G;
+    int pos;
+    if (a.cur_mode) pos = *(const int*)((const char*)a.state + 256);
+    else if (a.state) pos = *(const int*)a.state;
+    else pos = a.pos;
+    if (pos < 0 || pos >= a.max_seq) {              // a position outside the cache: nothing is appended or written (attn_decode_kernel's guard)
+        if (a.cur_mode && tid == 0 && z == 0 && kvh == 0) *(int*)((char*)const_cast<void*>(a.state) + 260) = 1;
+        return;
+    }
+    constexpr int CHUNK = 64 * NT;
+    const int T = pos + 1;
+    const int n_act = (T + CHUNK - 1) / CHUNK;      // chunks that hold keys: workgroups z >= n_act have nothing to do
+    if (z >= n_act) return;
+    const int t0 = z * CHUNK;
+    const int t1 = t0 + CHUNK < T ? t0 + CHUNK : T; // this workgroup's keys: t0 .. t1 - 1
+    const int Tl = t1 - t0;
+    const bool has_new = t1 == T;                   // the chunk that ends at the new token
+    const unsigned last_old = pos > 0 ? pos - 1 : 0;    // rows >= pos are never read from the cache
+    _Float16* const kc = (_Float16*)a.kc + ((size_t)b * a.n_kv_heads + kvh) * (size_t)a.max_seq * AP_D;
+    _Float16* const vc = (_Float16*)a.vc + ((size_t)b * a.n_kv_heads + kvh) * (size_t)a.max_seq * AP_D;
+
+    // ---- every tile of the chunk by LDS-DMA (the prompt kernel's staging: 16 pieces of 1 KiB per tile and operand, swizzles on the source side)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + AG_STAGE;
+    const unsigned rit = 4 * wave + (lane >> 4), pp = lane & 15;
+    const unsigned kswz = (pp ^ (rit & 15)) << 4, vswz = ((((pp >> 1) ^ (rit & 7)) << 1) | (pp & 1)) << 4;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        const unsigned dst = lds0 + ti * (2 * AP_TILE) + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned key = (unsigned)(t0 + 64 * ti) + rit + 16 * j;
+            key = key < last_old ? key : last_old;
+            ap_glds16(kc, __umul24(key, 256u) + kswz, dst + j * 4096);
+            ap_glds16(vc, __umul24(key, 256u) + vswz, dst + AP_TILE + j * 4096);
+        }
+    }
+    // ---- behind them: this lane's raw query fragments (row r = query head h0 + r; rows past the group repeat its last head: computed, never stored),
+    // the cos / sin pairs they rotate with, and -- the first 64 threads -- the new key / value
+    const int rq = r < G ? r : G - 1;
+    const _Float16* const qb = (const _Float16*)a.q + ((size_t)b * a.n_heads + h0 + rq) * AP_D + 8 * o;
+    h8 qf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qf[t] = *(const h8*)(qb + 32 * t);
+    const h2* const cs_src = a.cur_mode ? (const h2*)a.state : (a.rope_table ? (const h2*)a.rope_table + (size_t)pos * 64 : nullptr);
+    h8 cs[2][2];                                    // [t][half]: (cos, sin) of pairs 32 t + 8 o .. + 3 and .. + 4 .. + 7
+    _Float16 k0 = 0, k1 = 0, v0 = 0, v1 = 0;
+    h2 csk = {(_Float16)1.f, (_Float16)0.f};
+    if (cs_src) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            cs[t][0] = *(const h8*)(cs_src + 32 * t + 8 * o);
+            cs[t][1] = *(const h8*)(cs_src + 32 * t + 8 * o + 4);
+        }
+        if (tid < 64) csk = cs_src[tid];
+    } else {                                        // no table, no step state: the pairs from rope_theta (attn_decode_kernel's rope_cs)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = 32 * t + 8 * o + e;
+                float sn, c_;
+                sincosf((float)pos * (1.0f / powf(a.rope_theta, (float)(2 * i) / (float)AP_D)), &sn, &c_);
+                cs[t][e >> 2][2 * (e & 3)] = (_Float16)c_;
+                cs[t][e >> 2][2 * (e & 3) + 1] = (_Float16)sn;
+            }
+        if (tid < 64) {
+            float sn, c_;
+            sincosf((float)pos * (1.0f / powf(a.rope_theta, (float)(2 * tid) / (float)AP_D)), &sn, &c_);
+            csk = (h2){(_Float16)c_, (_Float16)sn};
+        }
+    }
+    if (tid < 64) {
+        const _Float16* const kn = (const _Float16*)a.k + ((size_t)b * a.n_kv_heads + kvh) * AP_D;
+        const _Float16* const vn = (const _Float16*)a.v + ((size_t)b * a.n_kv_heads + kvh) * AP_D;
+        k0 = kn[tid]; k1 = kn[tid + 64];
+        v0 = vn[tid]; v1 = vn[tid + 64];
+    }
+    AMQ_WAIT_VM("attn.gqa.landed", 0, "");          // this wave's transfers and loads
+    // rotation: q' = q * cos + rotate_half(q) * sin in fp16 (HF apply_rotary_pos_emb; the decode kernels' expression): pair (d, d + 64) = fragments t, t + 2
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const h8 lo = qf[t], hi = qf[t + 2];
+        h8 nlo, nhi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const _Float16 c16 = cs[t][e >> 2][2 * (e & 3)], s16 = cs[t][e >> 2][2 * (e & 3) + 1];
+            nlo[e] = lo[e] * c16 + (-hi[e]) * s16;
+            nhi[e] = hi[e] * c16 + lo[e] * s16;
+        }
+        qf[t] = nlo; qf[t + 2] = nhi;
+    }
+    _Float16* const ks = (_Float16*)smem;           // [128] rotated new key | [128] new value
+    _Float16* const vs = ks + AP_D;
+    if (tid < 64) {
+        const _Float16 r0 = k0 * csk.x + (-k1) * csk.y, r1 = k1 * csk.x + k0 * csk.y;
+        ks[tid] = r0; ks[tid + 64] = r1;
+        vs[tid] = v0; vs[tid + 64] = v1;
+        if (has_new) {                              // the one workgroup of this kv head that appends
+            kc[(size_t)pos * AP_D + tid] = r0;
+            kc[(size_t)pos * AP_D + tid + 64] = r1;
+            vc[(size_t)pos * AP_D + tid] = v0;
+            vc[(size_t)pos * AP_D + tid + 64] = v1;
+        }
+    }
+    __syncthreads();                                // every wave's tiles have landed; ks / vs are visible
+    unsigned char* const tiles = smem + AG_STAGE;
+    if (has_new) {
+        // rows at or past the position (the new token's own row, and the clamped repeats behind it in its tile) take the new key / value: 16 chunks of
+        // 16 bytes per row and operand, placed where the staging's swizzles would have put them
+        const int lr0 = pos - t0;                   // first such row, chunk-local
+        const int lr1 = ((lr0 >> 6) + 1) << 6;      // end of its tile (later tiles of the chunk hold no keys: not computed)
+        for (int idx = tid; idx < (lr1 - lr0) * 16; idx += 256) {
+            const int lr = lr0 + (idx >> 4), c = idx & 15;
+            unsigned char* const tb = tiles + (lr >> 6) * (2 * AP_TILE);
+            const int row = lr & 63;
+            *(h8*)(tb + row * 256 + ((c ^ (row & 15)) << 4)) = *(const h8*)(ks + 8 * c);
+            *(h8*)(tb + AP_TILE + row * 256 + (((((c >> 1) ^ (row & 7)) << 1) | (c & 1)) << 4)) = *(const h8*)(vs + 8 * c);
+        }
+        __syncthreads();
+    }
+
+    // ---- wave w: tile w (the prompt kernel's tile body, every row at the same position)
+    const float sl2 = 0.08838834764831845f * 1.4426950408889634f;           // 1 / sqrt(128) * log2(e)
+    f4 oacc[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) oacc[d] = (f4){0.f, 0.f, 0.f, 0.f};
+    float m_w = -INFINITY, l_w = 0.f;
+    if (64 * wave < Tl) {
+        const unsigned char* const kb_ = tiles + wave * (2 * AP_TILE);
+        const unsigned char* const vb_ = kb_ + AP_TILE;
+        const int k0_ = t0 + 64 * wave;
+        f4 st[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            st[kb] = (f4){0.f, 0.f, 0.f, 0.f};
+            const int row = 16 * kb + r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const h8 kf = *(const h8*)(kb_ + row * 256 + (((4 * t + o) ^ r) << 4));
+                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t], st[kb], 0, 0, 0);
+            }
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                st[kb][i] = (k0_ + 16 * kb + 4 * o + i) < t1 ? st[kb][i] : -INFINITY;
+                mt = fmaxf(mt, st[kb][i]);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));         // the tile's first key is always inside the chunk: finite
+        m_w = mt;
+        h8 pb[2];
+        float ls = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p = __builtin_amdgcn_exp2f(st[kb][i] * sl2 - mt * sl2);
+                ls += p;
+                pb[kb >> 1][4 * (kb & 1) + i] = (_Float16)p;
+            }
+        l_w = ls;
+        const int tq = r >> 2, tp = r & 3;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+#pragma unroll
+            for (int ks_ = 0; ks_ < 2; ++ks_) {
+                const int row0 = 32 * ks_ + 4 * o + tq;
+                const int seg = 2 * d + (tp >> 1);
+                const int off0 = row0 * 256 + ((((seg >> 1) ^ (row0 & 7)) << 5) | ((seg & 1) << 4)) + ((tp & 1) << 3);
+                const int row1 = row0 + 16;
+                const int off1 = row1 * 256 + ((((seg >> 1) ^ (row1 & 7)) << 5) | ((seg & 1) << 4)) + ((tp & 1) << 3);
+                h8 vf;
+                const ap_v4h t0_ = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ap_v4h*)(vb_ + off0));
+                const ap_v4h t1_ = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ap_v4h*)(vb_ + off1));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vf[i] = (_Float16)t0_[i];
+                    vf[4 + i] = (_Float16)t1_[i];
+                }
+                oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[ks_], oacc[d], 0, 0, 0);
+            }
+        }
+        l_w += __shfl_xor(l_w, 16);
+        l_w += __shfl_xor(l_w, 32);
+    }
+    __syncthreads();                                // the tiles have been read: their LDS becomes the merge area
+    // ---- merge the waves' (m, l, O) in wave order: lane holds O^T[d = 16 db + 4 o + i][query r] -> Om[wave][r][d], ml[wave][r]
+    float* const Om = (float*)tiles;                // [4][16][AG_OM_STRIDE]
+    float* const mlw = Om + 4 * 16 * AG_OM_STRIDE;  // [4][16][2]
+#pragma unroll
+    for (int d = 0; d < 8; ++d) *(f4*)(Om + ((size_t)wave * 16 + r) * AG_OM_STRIDE + 16 * d + 4 * o) = oacc[d];
+    if (o == 0) { mlw[(wave * 16 + r) * 2] = m_w; mlw[(wave * 16 + r) * 2 + 1] = l_w; }
+    __syncthreads();
+    const bool single = n_act == 1;                 // wave-uniform
+    for (int idx = tid; idx < G * AP_D; idx += 256) {
+        const int qh = idx >> 7, d = idx & 127;
+        float M = mlw[qh * 2];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) M = fmaxf(M, mlw[(w * 16 + qh) * 2]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __builtin_amdgcn_exp2f(mlw[(w * 16 + qh) * 2] * sl2 - M * sl2);       // a wave without a tile: exp2(-inf) = 0
+            L += mlw[(w * 16 + qh) * 2 + 1] * f;
+            O += Om[((size_t)w * 16 + qh) * AG_OM_STRIDE + d] * f;
+        }
+        if (single) {
+            ((_Float16*)a.out)[((size_t)b * a.n_heads + h0 + qh) * AP_D + d] = (_Float16)(O / L);
+        } else {
+            float* const wz = a.ws + (((size_t)b * a.n_heads + h0 + qh) * (size_t)a.n_splits + z) * AG_WS_STRIDE;
+            wz[d] = O;                              // (read by attn_gqa_combine_kernel, the next launch)
+            if (d == 0) {
+                wz[AP_D] = M * 0.08838834764831845f;    // natural-exponent domain, as the split kernel's
+                wz[AP_D + 1] = L;
+            }
+        }
+    }
+}
+
+// The combine of a grouped-query decode step as a launch of its own: one 128-thread workgroup per (sequence, QUERY head) adds the chunks' (O, m, l)
+// in chunk order -- out = sum_c O_c e^(m_c - M) / sum_c l_c e^(m_c - M), attn_decode_split_kernel's expressions.  (As the last arriver's job inside
+// attn_decode_gqa_kernel it was ONE workgroup per kv head reading G x n_act x 528 bytes through dependent round trips: 25 of the launch's 40 us at
+// 8192 keys of a 32 / 8-head model, growing with G x n_act -- profiles/r06_attn_gqa.txt.  The kernel boundary is the hand-over: no tickets, no
+// agent-scope publish.)  One active chunk: attn_decode_gqa_kernel has written the output itself, nothing to do.
+__global__ __launch_bounds__(128) void attn_gqa_combine_kernel(const float* ws, void* out, const void* state, int pos_host, int cur_mode,
+                                                               int n_heads, int max_seq, int n_splits, int chunk) {
+    __shared__ float ml[2 * 1024];
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const float* const wsh = ws + ((size_t)b * n_heads + h) * (size_t)n_splits * AG_WS_STRIDE;
+    // Everything the first 32 chunks hold is requested before the position (hence the number of active chunks) is known: the workspace has n_splits
+    // slots per head whatever the position, a slot past the active chunks holds an older step's values and is not used.  One round trip for the
+    // position, the (m, l) pairs and 32 O rows instead of four dependent ones (5.9 -> ~3.5 us per launch at 32 chunks).
+    constexpr int SPEC = 32;
+    float ov[SPEC];
+#pragma unroll
+    for (int j = 0; j < SPEC; ++j) ov[j] = wsh[(size_t)(j < n_splits ? j : n_splits - 1) * AG_WS_STRIDE + d];
+    float m_d = 0.f, l_d = 0.f;
+    if (d < n_splits) { m_d = wsh[(size_t)d * AG_WS_STRIDE + AP_D]; l_d = wsh[(size_t)d * AG_WS_STRIDE + AP_D + 1]; }
+    int pos;
+    if (cur_mode) pos = *(const int*)((const char*)state + 256);
+    else if (state) pos = *(const int*)state;
+    else pos = pos_host;
+    if (pos < 0 || pos >= max_seq) return;
+    const int n_act = (pos + chunk) / chunk;        // ceil((pos + 1) / chunk)
+    if (n_act <= 1) return;
+    if (d < n_splits) { ml[2 * d] = m_d; ml[2 * d + 1] = l_d; }
+    for (int c = d + 128; c < n_act; c += 128) {
+        ml[2 * c] = wsh[(size_t)c * AG_WS_STRIDE + AP_D];
+        ml[2 * c + 1] = wsh[(size_t)c * AG_WS_STRIDE + AP_D + 1];
+    }
+    __syncthreads();
+    float M = -INFINITY;
+    for (int c = 0; c < n_act; ++c) M = fmaxf(M, ml[2 * c]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int j = 0; j < SPEC; ++j) {
+        if (j < n_act) {                            // chunk order
+            const float f = __expf(ml[2 * j] - M);
+            L += ml[2 * j + 1] * f;
+            O += ov[j] * f;
+        }
+    }
+    for (int c0 = SPEC; c0 < n_act; c0 += 16) {
+        float o16[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {              // sixteen chunks' O rows per round trip
+            const int cc = c0 + j < n_act ? c0 + j : n_act - 1;
+            o16[j] = wsh[(size_t)cc * AG_WS_STRIDE + d];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (c0 + j < n_act) {
+                const float f = __expf(ml[2 * (c0 + j)] - M);
+                L += ml[2 * (c0 + j) + 1] * f;
+                O += o16[j] * f;
+            }
+        }
+    }
+    ((_Float16*)out)[((size_t)b * n_heads + h) * AP_D + d] = (_Float16)(O / L);
+}
+
+// tiles of 64 keys per workgroup the grouped-query decode kernel needs for a cache of max_seq rows cut n_splits ways (1, 2 or 4), 0: chunks of more
+// than 256 keys -- the per-head split kernel serves the call
+int attn_decode_gqa_tiles(int max_seq, int n_splits) {
+    const int per = (max_seq + n_splits - 1) / n_splits;
+    return per <= 64 ? 1 : per <= 128 ? 2 : per <= 256 ? 4 : 0;
+}
+size_t attn_decode_gqa_lds_bytes(int nt) {
+    const size_t tiles = (size_t)nt * 2 * AP_TILE, merge = (size_t)(4 * 16 * AG_OM_STRIDE + 4 * 16 * 2) * sizeof(float);
+    return AG_STAGE + (tiles > merge ? tiles : merge);
+}
+bool attn_decode_takes_gqa(int n_heads, int n_kv_heads, int max_seq, int n_splits) {
+    const int G = n_kv_heads > 0 ? n_heads / n_kv_heads : 0;
+    return AMQ_ATT_GQA && G >= 2 && G <= 16 && n_splits > 1 && attn_decode_gqa_tiles(max_seq, n_splits) != 0;
+}
+
+template <int NT>
+static hipError_t launch_attn_decode_gqa_nt(const AttnGqaArgs& g, int batch, hipStream_t st) {
+    const size_t lds = attn_decode_gqa_lds_bytes(NT);
+    static unsigned long long attr_done = 0;
+    if (hipError_t e = ensure_dyn_lds(attr_done, (const void*)attn_decode_gqa_kernel<NT>, (int)lds)) return e;
+    hipLaunchKernelGGL(attn_decode_gqa_kernel<NT>, dim3(g.n_kv_heads, batch, g.n_splits), dim3(256), lds, st, g);
+    if (hipError_t e = hipGetLastError()) return e;
+    hipLaunchKernelGGL(attn_gqa_combine_kernel, dim3(g.n_heads, batch), dim3(128), 0, st, (const float*)g.ws, g.out, g.state, g.pos, g.cur_mode,
+                       g.n_heads, g.max_seq, g.n_splits, 64 * NT);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_decode_gqa(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, hipStream_t st) {
+    (void)tickets;                                         // (the grouped form hands over at a kernel boundary)
+    StreamDevice sd_(st);
+    const bool cur = a.rope_cur != nullptr;
+    AttnGqaArgs g{a.q, a.k, a.v, a.kcache, a.vcache, a.out, cur ? a.rope_cur : (const void*)a.pos_dev, cur ? nullptr : a.rope_table,
+                  (float*)ws, a.pos, a.n_heads, a.n_kv_heads, a.max_seq, n_splits, (int)cur, a.rope_theta};
+    switch (attn_decode_gqa_tiles(a.max_seq, n_splits)) {
+        case 1: return launch_attn_decode_gqa_nt<1>(g, batch, st);
+        case 2: return launch_attn_decode_gqa_nt<2>(g, batch, st);
+        case 4: return launch_attn_decode_gqa_nt<4>(g, batch, st);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
     StreamDevice sd_(st);                                  // attributes / CU counts of the stream's device
     const int lds = 2 * 2 * AP_TILE;                    // 64 KiB

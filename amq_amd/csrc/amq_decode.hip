@@ -1061,6 +1061,7 @@ static hipError_t launch_attn_decode_split_ring(const AttnArgs& a, int batch, in
 }
 
 hipError_t launch_attn_decode_split(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, hipStream_t st) {
+    if (attn_decode_takes_gqa(a.n_heads, a.n_kv_heads, a.max_seq, n_splits)) return launch_attn_decode_gqa(a, batch, n_splits, ws, tickets, st);
     StreamDevice sd_(st);                                  // kernel attributes are per device: the stream's, not the current one
     const size_t lds = 6 * ATT_D + (size_t)att_chunk_max(a.max_seq, n_splits) * 4;
     // row loads in flight per thread (the kernel's RING): while the launch is at most one workgroup per CU all of K at once and V behind it as the scores

@@ -947,12 +947,23 @@ ATTN_CUS = 256             # workgroups per round of the chip (MI355X: 256 CUs)
 ATTN_PREFETCH_KEYS = 384   # keys of a chunk the split kernel requests ahead into registers (amq_decode.hip); longer chunks take its remainder loop
 
 
-def attn_decode_splits(max_seq, n_heads=32, batch=1):
+ATTN_GQA_TILES = 0         # tiles of 64 keys per workgroup of the grouped-query kernel (0: by cache length, attn_decode_splits; 1 / 2 / 4: A/B tools)
+
+
+def attn_decode_splits(max_seq, n_heads=32, batch=1, n_kv_heads=None):
     """workgroups per head the auto policy gives a cache of ``max_seq`` rows (1: the single-workgroup kernel): about ATTN_CHUNK keys each, and --
     where the heads divide the CU count -- a whole number of rounds of the chip (7B at 2048 keys: 8 x 32 = 256 workgroups of 264 keys run the launch
-    in 11.9 us, 6 x 32 of 352 keys in 11.8; at 4000 keys 16 x 32 in 18.1 against 11 x 32 in 19.6: profiles/r05_attn_decode_long.txt)"""
+    in 11.9 us, 6 x 32 of 352 keys in 11.8; at 4000 keys 16 x 32 in 18.1 against 11 x 32 in 19.6: profiles/r05_attn_decode_long.txt).
+    Grouped-query models (``n_kv_heads`` given, 2 .. 16 query heads per kv head): workgroups per KV head of the grouped kernel (amq_attn_prefill.hip:
+    attn_decode_gqa_kernel), chunks of 64 / 128 / 256 keys -- the longest that still gives the chip a round of workgroups."""
     if max_seq <= ATTN_SPLIT_FROM:
         return 1
+    g = n_heads // n_kv_heads if n_kv_heads else 1
+    if 2 <= g <= 16:
+        # chunks of 256 keys (128 up to 2048 cached keys): 1024 / 2048 / 4096 / 8192 keys of a 32 / 8-head model 8.6 | 8.9, 10.2 | 10.5, - | 11.3,
+        # 20.1 | 15.8 us at 128 | 256 keys per workgroup; chunks of 64 lose everywhere (13.8 at 2048) -- profiles/r06_attn_gqa.txt
+        tiles = ATTN_GQA_TILES or (2 if max_seq <= 2048 else 4)
+        return max(2, -(-max_seq // (64 * tiles)))
     s = max(1, round(max_seq / ATTN_CHUNK))
     wg = max(1, n_heads * batch)
     if ATTN_CUS % wg == 0:
@@ -974,7 +985,7 @@ def attn_decode(q, k, v, kcache, vcache, out, pos, n_heads, n_kv_heads, rope_the
     B = kcache.shape[0]
     max_seq = kcache.shape[2]
     if n_splits == 0:
-        n_splits = attn_decode_splits(max_seq, n_heads, B)
+        n_splits = attn_decode_splits(max_seq, n_heads, B, n_kv_heads)
     _need(q, torch.float16, "q", B * n_heads * 128)
     _need(k, torch.float16, "k", B * n_kv_heads * 128)
     _need(v, torch.float16, "v", B * n_kv_heads * 128)

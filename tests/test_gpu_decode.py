@@ -178,9 +178,10 @@ def test_attn_decode_split_context(pos, max_seq, nh, nkv, batch, n_splits):
     got, kc2, vc2 = run(n_splits, False)
     assert torch.isfinite(got.float()).all()
     assert torch.equal(kc2[:, :, :pos + 1], kc1[:, :, :pos + 1]) and torch.equal(vc2[:, :, :pos + 1], vc1[:, :, :pos + 1])   # appended once, same row
-    ns = n_splits or ops.attn_decode_splits(max_seq, nh, batch)
+    ns = n_splits or ops.attn_decode_splits(max_seq, nh, batch, nkv)
     chunk = max(256, (((pos + 1 + ns - 1) // ns) + 31) // 32 * 32)
-    if pos + 1 <= chunk:
+    grouped = 2 <= nh // nkv <= 16 and -(-max_seq // ns) <= 256        # served by attn_decode_gqa_kernel (matrix cores, the prompt kernel's numerics)
+    if pos + 1 <= chunk and not grouped:
         assert torch.equal(got, one)                       # one active chunk: the single-workgroup kernel's bits
     else:
         assert (got.float() - one.float()).abs().max() <= 2e-3 * one.float().abs().max() + 1e-3
@@ -198,6 +199,88 @@ def test_attn_decode_split_context(pos, max_seq, nh, nkv, batch, n_splits):
     K = kc2[:, :, :pos + 1].repeat_interleave(nh // nkv, 1).float()                 # [B, nh, T, 128]
     V = vc2[:, :, :pos + 1].repeat_interleave(nh // nkv, 1).float()
     qr = torch.stack([_rope_ref(q[b].view(nh, 128), pos) for b in range(batch)]).float()   # [B, nh, 128]
+    w = torch.einsum("bhd,bhtd->bht", qr, K) * (128 ** -0.5)
+    ref = torch.einsum("bht,bhtd->bhd", torch.softmax(w, -1), V).reshape(batch, -1)
+    assert (got.float() - ref).abs().max() <= 4e-3 * ref.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("pos,max_seq,nh,nkv,batch,n_splits", [
+    (1500, 2048, 8, 2, 2, 0),         # G = 4 (Llama-3.x / Mistral), two sequences
+    (3000, 4096, 28, 4, 1, 0),        # G = 7 (Qwen2.5-7B)
+    (4000, 4096, 64, 8, 3, 0),        # G = 8 (70B / Qwen2.5-72B), three sequences
+    (2500, 4096, 10, 2, 1, 0),        # G = 5 (Qwen2.5-14B / 32B)
+    (700, 4096, 6, 3, 1, 16),         # G = 2, chunks of 256: three active of sixteen
+    (100, 2048, 8, 2, 1, 8),          # one active chunk: written normalised by its workgroup, no ticket
+    (0, 2048, 8, 2, 1, 0),            # the first token of a sequence: nothing cached, every LDS row comes from the new key / value
+    (63, 2048, 4, 1, 1, 32), (64, 2048, 4, 1, 1, 32), (65, 2048, 4, 1, 1, 32),        # one tile per workgroup: the new token last in its tile / first of the next
+    (255, 1024, 8, 4, 1, 8), (256, 1024, 8, 4, 1, 8),                                 # two tiles per workgroup
+    (1023, 1024, 32, 2, 1, 0),        # G = 16: a full MFMA row block; the last row of the cache
+    (8000, 8192, 32, 8, 1, 0),        # 32 chunks of four tiles: the combine in four batches of O rows
+    (30000, 32768, 8, 2, 1, 0)])      # 118 active chunks
+def test_attn_decode_gqa_kernel(pos, max_seq, nh, nkv, batch, n_splits):
+    """grouped-query heads over a long cache: ONE workgroup per (kv head, chunk) scores the chunk against all the group's query heads on the matrix cores
+    (attn_decode_gqa_kernel) -- against the per-query-head split kernel (the same call with every query head given its own copy of the kv head's
+    cache rows: n_kv_heads = n_heads) and the eager fp32 formula; cache append once, tickets left zero, deterministic, both position sources."""
+    from amq_amd import ops
+    dev = _dev()
+    G = nh // nkv
+    g = torch.Generator().manual_seed(11 * pos + nh)
+    kc = torch.zeros(batch, nkv, max_seq, 128, dtype=torch.float16, device=dev)
+    vc = torch.zeros_like(kc)
+    kc[:, :, :pos] = torch.randn(batch, nkv, pos, 128, generator=g).half().to(dev)
+    vc[:, :, :pos] = torch.randn(batch, nkv, pos, 128, generator=g).half().to(dev)
+    kc[:, :, pos:] = float("nan"); vc[:, :, pos:] = float("nan")                # rows that must never contribute (the new token's row is written by the call)
+    q = torch.randn(batch, nh * 128, generator=g).half().to(dev)
+    k = torch.randn(batch, nkv * 128, generator=g).half().to(dev)
+    v = torch.randn(batch, nkv * 128, generator=g).half().to(dev)
+    tab = ops.rope_table(max_seq, 10000.0, dev)
+    posd = torch.full((1,), pos, dtype=torch.int32, device=dev)
+    ns = n_splits or ops.attn_decode_splits(max_seq, nh, batch, nkv)
+    assert ns > 1 and -(-max_seq // ns) <= 256                                  # the grouped kernel's launches
+
+    def run(cur_mode, table=tab):
+        kc_, vc_ = kc.clone(), vc.clone()
+        out = torch.zeros(batch, nh * 128, dtype=torch.float16, device=dev)
+        if cur_mode:
+            cur, pos_state, err = ops.new_step_state(dev)
+            cur.copy_(tab.view(max_seq, 128)[pos]); pos_state.fill_(pos)
+            ops.attn_decode(q, k, v, kc_, vc_, out, pos_state, nh, nkv, cur=cur, n_splits=ns)
+            assert int(err.item()) == 0
+        else:
+            ops.attn_decode(q, k, v, kc_, vc_, out, posd, nh, nkv, table=table, n_splits=ns)
+        return out, kc_, vc_
+
+    got, kc_g, vc_g = run(False)
+    assert torch.isfinite(got.float()).all()
+    # the appended row: HF's rotation of the new key, the raw value; nothing else written
+    for b_ in range(batch):
+        assert torch.equal(kc_g[b_, :, pos], _rope_ref(k[b_].view(nkv, 128), pos)) and torch.equal(vc_g[b_, :, pos], v[b_].view(nkv, 128))
+    assert torch.equal(kc_g[:, :, :pos], kc[:, :, :pos]) and torch.equal(vc_g[:, :, :pos], vc[:, :, :pos])
+    assert torch.isnan(kc_g[:, :, pos + 1:]).all()
+    assert all(int(t.abs().sum().item()) == 0 for t in ops._ATTN_TICKETS._cur.values())
+    # the per-query-head kernels over per-head copies of the cache and of the new key / value (n_kv_heads = n_heads: never the grouped form)
+    kc_h, vc_h = kc.repeat_interleave(G, 1).contiguous(), vc.repeat_interleave(G, 1).contiguous()
+    k_h = k.view(batch, nkv, 128).repeat_interleave(G, 1).reshape(batch, -1).contiguous()
+    v_h = v.view(batch, nkv, 128).repeat_interleave(G, 1).reshape(batch, -1).contiguous()
+    out_h = torch.zeros_like(got)
+    ops.attn_decode(q, k_h, v_h, kc_h, vc_h, out_h, posd, nh, nh, table=tab, n_splits=max(2, -(-max_seq // 272)))
+    assert (got.float() - out_h.float()).abs().max() <= 2e-3 * out_h.float().abs().max() + 1e-3
+    again, _, _ = run(False)
+    assert torch.equal(again, got)                         # fixed merge orders: deterministic
+    junk = torch.empty(320 << 20, dtype=torch.uint8, device=dev)
+    junk.fill_(1)                                          # ... also with the cache rows and the workspace cold in HBM
+    cold, _, _ = run(False)
+    assert torch.equal(cold, got)
+    del junk
+    cur_out, kc_c, _ = run(True)
+    assert torch.equal(cur_out, got) and torch.equal(kc_c[:, :, pos], kc_g[:, :, pos])    # step-state position / rotation source: same bits
+    if pos < 4096:
+        th_out, kc_t, _ = run(False, table=None)           # cos / sin computed in the kernel from rope_theta: the table's values
+        assert torch.equal(th_out, got) and torch.equal(kc_t[:, :, pos], kc_g[:, :, pos])
+    # eager fp32 formula over the cache after the append
+    K = kc_g[:, :, :pos + 1].repeat_interleave(G, 1).float()
+    V = vc_g[:, :, :pos + 1].repeat_interleave(G, 1).float()
+    qr = torch.stack([_rope_ref(q[b_].view(nh, 128), pos) for b_ in range(batch)]).float()
     w = torch.einsum("bhd,bhtd->bht", qr, K) * (128 ** -0.5)
     ref = torch.einsum("bht,bhtd->bhd", torch.softmax(w, -1), V).reshape(batch, -1)
     assert (got.float() - ref).abs().max() <= 4e-3 * ref.abs().max() + 1e-3

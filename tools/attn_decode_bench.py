@@ -12,8 +12,10 @@ splits = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0".
 nh = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 nkv = int(sys.argv[4]) if len(sys.argv) > 4 else nh
 L = int(sys.argv[5]) if len(sys.argv) > 5 else 32
+if os.environ.get("GQA_TILES"):
+    ops.ATTN_GQA_TILES = int(os.environ["GQA_TILES"])      # A/B: tiles of 64 keys per workgroup of the grouped-query kernel
 dev = torch.device("cuda:0")
-max_seq = T + 80
+max_seq = int(os.environ.get("MAX_SEQ", T + 80))      # (MAX_SEQ: the cache's size, e.g. a power of two just above T)
 g = torch.Generator(device=dev).manual_seed(0)
 kc = [torch.randn(1, nkv, max_seq, 128, device=dev, generator=g).half() for _ in range(L)]
 vc = [torch.randn(1, nkv, max_seq, 128, device=dev, generator=g).half() for _ in range(L)]
@@ -48,5 +50,5 @@ for ns in splits:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps / L
     byts = 2 * nkv * (T + 1) * 256
-    eff = ns if ns else ops.attn_decode_splits(max_seq)
+    eff = ns if ns else ops.attn_decode_splits(max_seq, nh, 1, nkv)
     print(f"T {T} heads {nh}/{nkv} n_splits {eff:3d}: {us:7.2f} us per launch   {byts / us / 1e3:7.1f} GB/s of K+V ({byts / 1e6:.1f} MB)", flush=True)
