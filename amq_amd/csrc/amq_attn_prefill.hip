@@ -321,12 +321,13 @@ struct AttnGqaArgs {
     float* ws;
     int pos, n_heads, n_kv_heads, max_seq, n_splits, cur_mode;
     float rope_theta;
+    int iters;                  // stages of AG_STAGE_KEYS keys per workgroup (chunk = AG_STAGE_KEYS * iters)
 };
 constexpr int AG_WS_STRIDE = 132;       // floats per (query head, chunk) in the workspace: O[128], m, l, pad (amq_decode.hip: ATT_WS_STRIDE)
 constexpr int AG_OM_STRIDE = 132;       // floats per (wave, query row) of the cross-wave merge area
-constexpr int AG_STAGE = 512;           // bytes in front of the tiles: rotated new key [128], new value [128]
+constexpr int AG_STAGE = 512;           // bytes in front of the stage buffers: rotated new key [128], new value [128]
+constexpr int AG_STAGE_KEYS = 128;      // keys per stage: two tiles of 64
 
-template <int NT>
 __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnGqaArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, tid = threadIdx.x;
@@ -342,34 +343,38 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnGqaArgs a) {
         if (a.cur_mode && tid == 0 && z == 0 && kvh == 0) *(int*)((char*)const_cast<void*>(a.state) + 260) = 1;
         return;
     }
-    constexpr int CHUNK = 64 * NT;
+    const int chunk = AG_STAGE_KEYS * a.iters;
     const int T = pos + 1;
-    const int n_act = (T + CHUNK - 1) / CHUNK;      // chunks that hold keys: workgroups z >= n_act have nothing to do
+    const int n_act = (T + chunk - 1) / chunk;      // chunks that hold keys: workgroups z >= n_act have nothing to do
     if (z >= n_act) return;
-    const int t0 = z * CHUNK;
-    const int t1 = t0 + CHUNK < T ? t0 + CHUNK : T; // this workgroup's keys: t0 .. t1 - 1
-    const int Tl = t1 - t0;
+    const int t0 = z * chunk;
+    const int t1 = t0 + chunk < T ? t0 + chunk : T; // this workgroup's keys: t0 .. t1 - 1
+    const int n_it = (t1 - t0 + AG_STAGE_KEYS - 1) / AG_STAGE_KEYS;     // stages of 128 keys that hold any
     const bool has_new = t1 == T;                   // the chunk that ends at the new token
     const unsigned last_old = pos > 0 ? pos - 1 : 0;    // rows >= pos are never read from the cache
     _Float16* const kc = (_Float16*)a.kc + ((size_t)b * a.n_kv_heads + kvh) * (size_t)a.max_seq * AP_D;
     _Float16* const vc = (_Float16*)a.vc + ((size_t)b * a.n_kv_heads + kvh) * (size_t)a.max_seq * AP_D;
 
-    // ---- every tile of the chunk by LDS-DMA (the prompt kernel's staging: 16 pieces of 1 KiB per tile and operand, swizzles on the source side)
+    // ---- a stage = two tiles of 64 keys x (K | V) by LDS-DMA into one of two stage buffers (the prompt kernel's staging: 16 pieces of 1 KiB per tile
+    // and operand, swizzles on the source side); rows at or past the new token's position clamped to the last cached row
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + AG_STAGE;
     const unsigned rit = 4 * wave + (lane >> 4), pp = lane & 15;
     const unsigned kswz = (pp ^ (rit & 15)) << 4, vswz = ((((pp >> 1) ^ (rit & 7)) << 1) | (pp & 1)) << 4;
+    auto load_stage = [&](int it) {
+        const unsigned dst0 = lds0 + (it & 1) * (4 * AP_TILE) + wave * 1024;
 #pragma unroll
-    for (int ti = 0; ti < NT; ++ti) {
-        const unsigned dst = lds0 + ti * (2 * AP_TILE) + wave * 1024;
+        for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned key = (unsigned)(t0 + 64 * ti) + rit + 16 * j;
-            key = key < last_old ? key : last_old;
-            ap_glds16(kc, __umul24(key, 256u) + kswz, dst + j * 4096);
-            ap_glds16(vc, __umul24(key, 256u) + vswz, dst + AP_TILE + j * 4096);
+            for (int j = 0; j < 4; ++j) {
+                unsigned key = (unsigned)(t0 + AG_STAGE_KEYS * it + 64 * ti) + rit + 16 * j;
+                key = key < last_old ? key : last_old;
+                ap_glds16(kc, __umul24(key, 256u) + kswz, dst0 + ti * (2 * AP_TILE) + j * 4096);
+                ap_glds16(vc, __umul24(key, 256u) + vswz, dst0 + ti * (2 * AP_TILE) + AP_TILE + j * 4096);
+            }
         }
-    }
-    // ---- behind them: this lane's raw query fragments (row r = query head h0 + r; rows past the group repeat its last head: computed, never stored),
+    };
+    load_stage(0);
+    // ---- behind it: this lane's raw query fragments (row r = query head h0 + r; rows past the group repeat its last head: computed, never stored),
     // the cos / sin pairs they rotate with, and -- the first 64 threads -- the new key / value
     const int rq = r < G ? r : G - 1;
     const _Float16* const qb = (const _Float16*)a.q + ((size_t)b * a.n_heads + h0 + rq) * AP_D + 8 * o;
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnGqaArgs a) {
         k0 = kn[tid]; k1 = kn[tid + 64];
         v0 = vn[tid]; v1 = vn[tid + 64];
     }
-    AMQ_WAIT_VM("attn.gqa.landed", 0, "");          // this wave's transfers and loads
+    AMQ_WAIT_VM("attn.gqa.landed", 0, "");          // this wave's share of stage 0 and its loads
     // rotation: q' = q * cos + rotate_half(q) * sin in fp16 (HF apply_rotary_pos_emb; the decode kernels' expression): pair (d, d + 64) = fragments t, t + 2
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -437,72 +442,84 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnGqaArgs a) {
             vc[(size_t)pos * AP_D + tid + 64] = v1;
         }
     }
-    __syncthreads();                                // every wave's tiles have landed; ks / vs are visible
+    __syncthreads();                                // every wave's share of stage 0 has landed; ks / vs are visible
     unsigned char* const tiles = smem + AG_STAGE;
-    if (has_new) {
-        // rows at or past the position (the new token's own row, and the clamped repeats behind it in its tile) take the new key / value: 16 chunks of
-        // 16 bytes per row and operand, placed where the staging's swizzles would have put them
-        const int lr0 = pos - t0;                   // first such row, chunk-local
-        const int lr1 = ((lr0 >> 6) + 1) << 6;      // end of its tile (later tiles of the chunk hold no keys: not computed)
-        for (int idx = tid; idx < (lr1 - lr0) * 16; idx += 256) {
-            const int lr = lr0 + (idx >> 4), c = idx & 15;
-            unsigned char* const tb = tiles + (lr >> 6) * (2 * AP_TILE);
-            const int row = lr & 63;
-            *(h8*)(tb + row * 256 + ((c ^ (row & 15)) << 4)) = *(const h8*)(ks + 8 * c);
-            *(h8*)(tb + AP_TILE + row * 256 + (((((c >> 1) ^ (row & 7)) << 1) | (c & 1)) << 4)) = *(const h8*)(vs + 8 * c);
-        }
-        __syncthreads();
-    }
 
-    // ---- wave w: tile w (the prompt kernel's tile body, every row at the same position)
+    // ---- the stages: wave w takes keys 32 (w & 1) .. + 31 of tile w >> 1 (the prompt kernel's tile body cut to one 32-key step, every row at the same
+    // position), its running (m, l, O) carried across the stages; stage it + 1 is in flight under stage it's MFMAs
     const float sl2 = 0.08838834764831845f * 1.4426950408889634f;           // 1 / sqrt(128) * log2(e)
+    const int tile = wave >> 1, half = wave & 1;
     f4 oacc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) oacc[d] = (f4){0.f, 0.f, 0.f, 0.f};
-    float m_w = -INFINITY, l_w = 0.f;
-    if (64 * wave < Tl) {
-        const unsigned char* const kb_ = tiles + wave * (2 * AP_TILE);
-        const unsigned char* const vb_ = kb_ + AP_TILE;
-        const int k0_ = t0 + 64 * wave;
-        f4 st[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            st[kb] = (f4){0.f, 0.f, 0.f, 0.f};
-            const int row = 16 * kb + r;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const h8 kf = *(const h8*)(kb_ + row * 256 + (((4 * t + o) ^ r) << 4));
-                st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t], st[kb], 0, 0, 0);
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int it = 0; it < n_it; ++it) {
+        if (it + 1 < n_it) load_stage(it + 1);      // (its buffer was last read in stage it - 1, behind that stage's barrier)
+        unsigned char* const sb = tiles + (it & 1) * (4 * AP_TILE);
+        if (has_new && it == n_it - 1) {
+            // rows at or past the position (the new token's own row and the clamped repeats behind it in its tile) take the new key / value: 16 chunks
+            // of 16 bytes per row and operand, placed where the staging's swizzles would have put them -- no row the MFMAs read was never written
+            const int lr0 = pos - (t0 + AG_STAGE_KEYS * it);    // first such row, stage-local
+            const int lr1 = ((lr0 >> 6) + 1) << 6;              // end of its tile (a later tile of the stage holds no keys: not computed)
+            for (int idx = tid; idx < (lr1 - lr0) * 16; idx += 256) {
+                const int lr = lr0 + (idx >> 4), c = idx & 15;
+                unsigned char* const tb = sb + (lr >> 6) * (2 * AP_TILE);
+                const int row = lr & 63;
+                *(h8*)(tb + row * 256 + ((c ^ (row & 15)) << 4)) = *(const h8*)(ks + 8 * c);
+                *(h8*)(tb + AP_TILE + row * 256 + (((((c >> 1) ^ (row & 7)) << 1) | (c & 1)) << 4)) = *(const h8*)(vs + 8 * c);
             }
+            __syncthreads();
         }
-        float mt = -INFINITY;
+        const int k0_ = t0 + AG_STAGE_KEYS * it + 64 * tile + 32 * half;      // this wave's first key of the stage
+        if (k0_ < t1) {
+            const unsigned char* const kb_ = sb + tile * (2 * AP_TILE);
+            const unsigned char* const vb_ = kb_ + AP_TILE;
+            f4 st[2];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+            for (int kl = 0; kl < 2; ++kl) {
+                st[kl] = (f4){0.f, 0.f, 0.f, 0.f};
+                const int row = 32 * half + 16 * kl + r;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                st[kb][i] = (k0_ + 16 * kb + 4 * o + i) < t1 ? st[kb][i] : -INFINITY;
-                mt = fmaxf(mt, st[kb][i]);
+                for (int t = 0; t < 4; ++t) {
+                    const h8 kf = *(const h8*)(kb_ + row * 256 + (((4 * t + o) ^ r) << 4));
+                    st[kl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t], st[kl], 0, 0, 0);
+                }
             }
-        mt = fmaxf(mt, __shfl_xor(mt, 16));
-        mt = fmaxf(mt, __shfl_xor(mt, 32));         // the tile's first key is always inside the chunk: finite
-        m_w = mt;
-        h8 pb[2];
-        float ls = 0.f;
+            float mt = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+            for (int kl = 0; kl < 2; ++kl)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float p = __builtin_amdgcn_exp2f(st[kb][i] * sl2 - mt * sl2);
-                ls += p;
-                pb[kb >> 1][4 * (kb & 1) + i] = (_Float16)p;
+                for (int i = 0; i < 4; ++i) {
+                    st[kl][i] = (k0_ + 16 * kl + 4 * o + i) < t1 ? st[kl][i] : -INFINITY;
+                    mt = fmaxf(mt, st[kl][i]);
+                }
+            mt = fmaxf(mt, __shfl_xor(mt, 16));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));     // the wave's first key is inside the chunk: finite
+            const float m_new = fmaxf(m_run, mt);
+            const bool grew = __any(m_new != m_run);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);      // exp2(-inf) = 0 on the wave's first stage
+            m_run = m_new;
+            h8 pb;
+            float ls = 0.f;
+#pragma unroll
+            for (int kl = 0; kl < 2; ++kl)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(st[kl][i] * sl2 - m_new * sl2);
+                    ls += p;
+                    pb[4 * kl + i] = (_Float16)p;
+                }
+            l_run = l_run * alpha + ls;
+            if (grew) {
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) oacc[d][i] *= alpha;
             }
-        l_w = ls;
-        const int tq = r >> 2, tp = r & 3;
+            const int tq = r >> 2, tp = r & 3;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-#pragma unroll
-            for (int ks_ = 0; ks_ < 2; ++ks_) {
-                const int row0 = 32 * ks_ + 4 * o + tq;
+            for (int d = 0; d < 8; ++d) {
+                const int row0 = 32 * half + 4 * o + tq;
                 const int seg = 2 * d + (tp >> 1);
                 const int off0 = row0 * 256 + ((((seg >> 1) ^ (row0 & 7)) << 5) | ((seg & 1) << 4)) + ((tp & 1) << 3);
                 const int row1 = row0 + 16;
@@ -515,19 +532,20 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnGqaArgs a) {
                     vf[i] = (_Float16)t0_[i];
                     vf[4 + i] = (_Float16)t1_[i];
                 }
-                oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[ks_], oacc[d], 0, 0, 0);
+                oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb, oacc[d], 0, 0, 0);
             }
         }
-        l_w += __shfl_xor(l_w, 16);
-        l_w += __shfl_xor(l_w, 32);
+        AMQ_WAIT_VM("attn.gqa.stage", 0, "");       // this wave's share of the next stage
+        __syncthreads();                            // ... every wave's; and this stage's buffer has been read
     }
-    __syncthreads();                                // the tiles have been read: their LDS becomes the merge area
-    // ---- merge the waves' (m, l, O) in wave order: lane holds O^T[d = 16 db + 4 o + i][query r] -> Om[wave][r][d], ml[wave][r]
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    // ---- merge the waves' (m, l, O) in wave order (the stage buffers are free: the loop ends on a barrier): lane holds O^T[d = 16 db + 4 o + i][query r]
     float* const Om = (float*)tiles;                // [4][16][AG_OM_STRIDE]
     float* const mlw = Om + 4 * 16 * AG_OM_STRIDE;  // [4][16][2]
 #pragma unroll
     for (int d = 0; d < 8; ++d) *(f4*)(Om + ((size_t)wave * 16 + r) * AG_OM_STRIDE + 16 * d + 4 * o) = oacc[d];
-    if (o == 0) { mlw[(wave * 16 + r) * 2] = m_w; mlw[(wave * 16 + r) * 2 + 1] = l_w; }
+    if (o == 0) { mlw[(wave * 16 + r) * 2] = m_run; mlw[(wave * 16 + r) * 2 + 1] = l_run; }
     __syncthreads();
     const bool single = n_act == 1;                 // wave-uniform
     for (int idx = tid; idx < G * AP_D; idx += 256) {
@@ -538,7 +556,7 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(AttnGqaArgs a) {
         float L = 0.f, O = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float f = __builtin_amdgcn_exp2f(mlw[(w * 16 + qh) * 2] * sl2 - M * sl2);       // a wave without a tile: exp2(-inf) = 0
+            const float f = __builtin_amdgcn_exp2f(mlw[(w * 16 + qh) * 2] * sl2 - M * sl2);       // a wave that never had keys: exp2(-inf) = 0
             L += mlw[(w * 16 + qh) * 2 + 1] * f;
             O += Om[((size_t)w * 16 + qh) * AG_OM_STRIDE + d] * f;
         }
@@ -617,31 +635,15 @@ __global__ __launch_bounds__(128) void attn_gqa_combine_kernel(const float* ws, 
     ((_Float16*)out)[((size_t)b * n_heads + h) * AP_D + d] = (_Float16)(O / L);
 }
 
-// tiles of 64 keys per workgroup the grouped-query decode kernel needs for a cache of max_seq rows cut n_splits ways (1, 2 or 4), 0: chunks of more
-// than 256 keys -- the per-head split kernel serves the call
-int attn_decode_gqa_tiles(int max_seq, int n_splits) {
+// stages of 128 keys per workgroup for a cache of max_seq rows cut n_splits ways
+int attn_decode_gqa_iters(int max_seq, int n_splits) {
     const int per = (max_seq + n_splits - 1) / n_splits;
-    return per <= 64 ? 1 : per <= 128 ? 2 : per <= 256 ? 4 : 0;
-}
-size_t attn_decode_gqa_lds_bytes(int nt) {
-    const size_t tiles = (size_t)nt * 2 * AP_TILE, merge = (size_t)(4 * 16 * AG_OM_STRIDE + 4 * 16 * 2) * sizeof(float);
-    return AG_STAGE + (tiles > merge ? tiles : merge);
+    return (per + AG_STAGE_KEYS - 1) / AG_STAGE_KEYS;
 }
 bool attn_decode_takes_gqa(int n_heads, int n_kv_heads, int max_seq, int n_splits) {
     const int G = n_kv_heads > 0 ? n_heads / n_kv_heads : 0;
-    return AMQ_ATT_GQA && G >= 2 && G <= 16 && n_splits > 1 && attn_decode_gqa_tiles(max_seq, n_splits) != 0;
-}
-
-template <int NT>
-static hipError_t launch_attn_decode_gqa_nt(const AttnGqaArgs& g, int batch, hipStream_t st) {
-    const size_t lds = attn_decode_gqa_lds_bytes(NT);
-    static unsigned long long attr_done = 0;
-    if (hipError_t e = ensure_dyn_lds(attr_done, (const void*)attn_decode_gqa_kernel<NT>, (int)lds)) return e;
-    hipLaunchKernelGGL(attn_decode_gqa_kernel<NT>, dim3(g.n_kv_heads, batch, g.n_splits), dim3(256), lds, st, g);
-    if (hipError_t e = hipGetLastError()) return e;
-    hipLaunchKernelGGL(attn_gqa_combine_kernel, dim3(g.n_heads, batch), dim3(128), 0, st, (const float*)g.ws, g.out, g.state, g.pos, g.cur_mode,
-                       g.n_heads, g.max_seq, g.n_splits, 64 * NT);
-    return hipGetLastError();
+    (void)max_seq;
+    return AMQ_ATT_GQA && G >= 2 && G <= 16 && n_splits > 1;
 }
 
 hipError_t launch_attn_decode_gqa(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, hipStream_t st) {
@@ -649,13 +651,16 @@ hipError_t launch_attn_decode_gqa(const AttnArgs& a, int batch, int n_splits, vo
     StreamDevice sd_(st);
     const bool cur = a.rope_cur != nullptr;
     AttnGqaArgs g{a.q, a.k, a.v, a.kcache, a.vcache, a.out, cur ? a.rope_cur : (const void*)a.pos_dev, cur ? nullptr : a.rope_table,
-                  (float*)ws, a.pos, a.n_heads, a.n_kv_heads, a.max_seq, n_splits, (int)cur, a.rope_theta};
-    switch (attn_decode_gqa_tiles(a.max_seq, n_splits)) {
-        case 1: return launch_attn_decode_gqa_nt<1>(g, batch, st);
-        case 2: return launch_attn_decode_gqa_nt<2>(g, batch, st);
-        case 4: return launch_attn_decode_gqa_nt<4>(g, batch, st);
-    }
-    return hipErrorInvalidValue;
+                  (float*)ws, a.pos, a.n_heads, a.n_kv_heads, a.max_seq, n_splits, (int)cur, a.rope_theta, attn_decode_gqa_iters(a.max_seq, n_splits)};
+    const size_t lds = AG_STAGE + (size_t)2 * 4 * AP_TILE;         // two stage buffers of two tiles x (K | V); the cross-wave merge reuses them
+    static_assert((size_t)(4 * 16 * AG_OM_STRIDE + 4 * 16 * 2) * sizeof(float) <= (size_t)2 * 4 * AP_TILE, "merge area inside the stage buffers");
+    static unsigned long long attr_done = 0;
+    if (hipError_t e = ensure_dyn_lds(attr_done, (const void*)attn_decode_gqa_kernel, (int)lds)) return e;
+    hipLaunchKernelGGL(attn_decode_gqa_kernel, dim3(g.n_kv_heads, batch, g.n_splits), dim3(256), lds, st, g);
+    if (hipError_t e = hipGetLastError()) return e;
+    hipLaunchKernelGGL(attn_gqa_combine_kernel, dim3(g.n_heads, batch), dim3(128), 0, st, (const float*)g.ws, g.out, g.state, g.pos, g.cur_mode,
+                       g.n_heads, g.max_seq, g.n_splits, AG_STAGE_KEYS * g.iters);
+    return hipGetLastError();
 }
 
 hipError_t launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {

@@ -159,14 +159,14 @@ constexpr int ATT_MIN_CHUNK = AMQ_ATT_MIN_CHUNK;      // fewest keys a workgroup
 // the same step with the context split over n_splits workgroups per head: ws = fp32 [batch][n_heads][n_splits][132],
 // tickets = int32 [batch][n_heads], zero before (and after) every launch
 hipError_t launch_attn_decode_split(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, hipStream_t st);
-// grouped-query models over a long cache (2 <= n_heads / n_kv_heads <= 16, chunks of at most 256 keys): one workgroup per (kv head, chunk) scores the
+// grouped-query models over a long cache (2 <= n_heads / n_kv_heads <= 16): one workgroup per (kv head, chunk) scores the
 // chunk against all the group's heads on the matrix cores (amq_attn_prefill.hip: attn_decode_gqa_kernel); same workspace and tickets.
 // AMQ_ATT_GQA=0: every query head its own workgroups, as for multi-head models (A/B builds)
 #ifndef AMQ_ATT_GQA
 #define AMQ_ATT_GQA 1
 #endif
 bool attn_decode_takes_gqa(int n_heads, int n_kv_heads, int max_seq, int n_splits);
-int attn_decode_gqa_tiles(int max_seq, int n_splits);
+int attn_decode_gqa_iters(int max_seq, int n_splits);      // stages of 128 keys per workgroup
 hipError_t launch_attn_decode_gqa(const AttnArgs& a, int batch, int n_splits, void* ws, void* tickets, hipStream_t st);
 hipError_t launch_rmsnorm(const void* x, const void* gamma, void* y, int M, int K, float eps, hipStream_t st);
 hipError_t launch_rmsnorm_xfrag(const void* x, const void* gamma, void* xf, int M, int K, float eps, hipStream_t st);

@@ -947,7 +947,7 @@ ATTN_CUS = 256             # workgroups per round of the chip (MI355X: 256 CUs)
 ATTN_PREFETCH_KEYS = 384   # keys of a chunk the split kernel requests ahead into registers (amq_decode.hip); longer chunks take its remainder loop
 
 
-ATTN_GQA_TILES = 0         # tiles of 64 keys per workgroup of the grouped-query kernel (0: by cache length, attn_decode_splits; 1 / 2 / 4: A/B tools)
+ATTN_GQA_KEYS = 0          # keys per workgroup of the grouped-query kernel (0: by cache length, attn_decode_splits; a multiple of 128: A/B tools)
 
 
 def attn_decode_splits(max_seq, n_heads=32, batch=1, n_kv_heads=None):
@@ -960,10 +960,11 @@ def attn_decode_splits(max_seq, n_heads=32, batch=1, n_kv_heads=None):
         return 1
     g = n_heads // n_kv_heads if n_kv_heads else 1
     if 2 <= g <= 16:
-        # chunks of 256 keys (128 up to 2048 cached keys): 1024 / 2048 / 4096 / 8192 keys of a 32 / 8-head model 8.6 | 8.9, 10.2 | 10.5, - | 11.3,
-        # 20.1 | 15.8 us at 128 | 256 keys per workgroup; chunks of 64 lose everywhere (13.8 at 2048) -- profiles/r06_attn_gqa.txt
-        tiles = ATTN_GQA_TILES or (2 if max_seq <= 2048 else 4)
-        return max(2, -(-max_seq // (64 * tiles)))
+        # a round of the chip (workgroups = kv heads x sequences x splits), chunks of whole 128-key stages: 128 keys up to 2048 cached keys, at least 256
+        # beyond (more, smaller chunks cost more in partial results than they gain: profiles/r06_attn_gqa.txt); ATTN_GQA_KEYS: A/B tools
+        per = ATTN_GQA_KEYS or max(128 if max_seq <= 2048 else 256, -(-max_seq // max(1, ATTN_CUS // (n_kv_heads * batch))))
+        per = -(-per // 128) * 128
+        return max(2, -(-max_seq // per))
     s = max(1, round(max_seq / ATTN_CHUNK))
     wg = max(1, n_heads * batch)
     if ATTN_CUS % wg == 0:

@@ -174,7 +174,13 @@ def beyond_the_metric(dev):
             tps = _decode_rate(dev, m, PROMPT, 8, 64)
             roof = gemv_roofline(m, reps=10)
             step_bytes = m.total_bytes_per_token(PROMPT + 40)
-            return {"tokens_per_s": round(tps, 1), "roofline_frac": round(roof["gbps"] / HBM_PEAK_GBPS, 3), "us_per_launch": round(roof["us_per_launch"], 2),
+            long_ctx = None
+            if m.nh != m.nkv:       # grouped-query heads: the decode attention over a long cache (attn_decode_gqa_kernel: one workgroup per kv head and chunk)
+                del m
+                torch.cuda.empty_cache()
+                m, _, _ = build_model(dev, seed=0, max_seq=8192, model=model, pinned=())
+                long_ctx = round(_decode_rate(dev, m, 8000, 8, 48), 1)
+            return {"tokens_per_s": round(tps, 1), "tokens_per_s_at_8000_cached_keys": long_ctx, "roofline_frac": round(roof["gbps"] / HBM_PEAK_GBPS, 3), "us_per_launch": round(roof["us_per_launch"], 2),
                     "linear_gb_per_token": round(m.linear_bytes_per_token() / 1e9, 3), "lm_head_gb_per_token": round(m.lm_head.numel() * 2 / 1e9, 3),
                     "whole_step_gbps": round(step_bytes * tps / 1e9, 1), "whole_step_frac": round(step_bytes * tps / 1e9 / HBM_PEAK_GBPS, 3),
                     "bits_usage": round(usage, 3), "finite_logits": bool(torch.isfinite(m.logits.float()).all().item()),

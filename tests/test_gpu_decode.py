@@ -180,7 +180,7 @@ def test_attn_decode_split_context(pos, max_seq, nh, nkv, batch, n_splits):
     assert torch.equal(kc2[:, :, :pos + 1], kc1[:, :, :pos + 1]) and torch.equal(vc2[:, :, :pos + 1], vc1[:, :, :pos + 1])   # appended once, same row
     ns = n_splits or ops.attn_decode_splits(max_seq, nh, batch, nkv)
     chunk = max(256, (((pos + 1 + ns - 1) // ns) + 31) // 32 * 32)
-    grouped = 2 <= nh // nkv <= 16 and -(-max_seq // ns) <= 256        # served by attn_decode_gqa_kernel (matrix cores, the prompt kernel's numerics)
+    grouped = 2 <= nh // nkv <= 16                                     # served by attn_decode_gqa_kernel (matrix cores, the prompt kernel's numerics)
     if pos + 1 <= chunk and not grouped:
         assert torch.equal(got, one)                       # one active chunk: the single-workgroup kernel's bits
     else:
@@ -215,8 +215,11 @@ def test_attn_decode_split_context(pos, max_seq, nh, nkv, batch, n_splits):
     (63, 2048, 4, 1, 1, 32), (64, 2048, 4, 1, 1, 32), (65, 2048, 4, 1, 1, 32),        # one tile per workgroup: the new token last in its tile / first of the next
     (255, 1024, 8, 4, 1, 8), (256, 1024, 8, 4, 1, 8),                                 # two tiles per workgroup
     (1023, 1024, 32, 2, 1, 0),        # G = 16: a full MFMA row block; the last row of the cache
-    (8000, 8192, 32, 8, 1, 0),        # 32 chunks of four tiles: the combine in four batches of O rows
-    (30000, 32768, 8, 2, 1, 0)])      # 118 active chunks
+    (8000, 8192, 32, 8, 1, 0),        # 32 chunks of two stages
+    (3000, 4096, 4, 1, 1, 4),         # chunks of 1024 keys: eight stages per workgroup, the running (m, l, O) across them
+    (2999, 4096, 12, 4, 2, 3),        # chunks of 1408 keys (eleven stages), the last one ends mid-stage; two sequences
+    (30000, 32768, 8, 2, 1, 0),       # 118 active chunks of 256 keys
+    (30000, 32768, 8, 2, 1, 8)])      # eight chunks of 32 stages
 def test_attn_decode_gqa_kernel(pos, max_seq, nh, nkv, batch, n_splits):
     """grouped-query heads over a long cache: ONE workgroup per (kv head, chunk) scores the chunk against all the group's query heads on the matrix cores
     (attn_decode_gqa_kernel) -- against the per-query-head split kernel (the same call with every query head given its own copy of the kv head's
@@ -236,7 +239,7 @@ def test_attn_decode_gqa_kernel(pos, max_seq, nh, nkv, batch, n_splits):
     tab = ops.rope_table(max_seq, 10000.0, dev)
     posd = torch.full((1,), pos, dtype=torch.int32, device=dev)
     ns = n_splits or ops.attn_decode_splits(max_seq, nh, batch, nkv)
-    assert ns > 1 and -(-max_seq // ns) <= 256                                  # the grouped kernel's launches
+    assert ns > 1
 
     def run(cur_mode, table=tab):
         kc_, vc_ = kc.clone(), vc.clone()

@@ -118,7 +118,9 @@ def _corpus():
     cases.append(("gemv bf16 8 rows", lambda: ops.linear_bf16(xb8, qb, mb, 4, 1024, 2048)))
 
     # ---- decode attention, split over the context (ring of row loads, ticket + last-arriver combine) and the single-workgroup kernel
-    for max_seq, pos, B, hq, hkv in ((600, 599, 1, 32, 32), (2048, 2047, 1, 32, 32), (4000, 3999, 1, 32, 8), (1024, 700, 4, 32, 32), (512, 300, 2, 32, 32)):
+    # (grouped-query heads: the staged MFMA kernel -- LDS-DMA stage buffers, one drain per stage -- and its combine launch)
+    for max_seq, pos, B, hq, hkv in ((600, 599, 1, 32, 32), (2048, 2047, 1, 32, 32), (4000, 3999, 1, 32, 8), (1024, 700, 4, 32, 32), (512, 300, 2, 32, 32),
+                                     (8192, 8000, 1, 28, 4), (2048, 1500, 3, 8, 2)):
         q, kk, vv = rnd(B, hq * 128), rnd(B, hkv * 128), rnd(B, hkv * 128)
         kc, vc = rnd(B, hkv, max_seq, 128), rnd(B, hkv, max_seq, 128)
         table = ops.rope_table(max_seq, 10000.0, dev)

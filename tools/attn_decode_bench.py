@@ -12,8 +12,8 @@ splits = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0".
 nh = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 nkv = int(sys.argv[4]) if len(sys.argv) > 4 else nh
 L = int(sys.argv[5]) if len(sys.argv) > 5 else 32
-if os.environ.get("GQA_TILES"):
-    ops.ATTN_GQA_TILES = int(os.environ["GQA_TILES"])      # A/B: tiles of 64 keys per workgroup of the grouped-query kernel
+if os.environ.get("GQA_KEYS"):
+    ops.ATTN_GQA_KEYS = int(os.environ["GQA_KEYS"])        # A/B: keys per workgroup of the grouped-query kernel (a multiple of 128)
 dev = torch.device("cuda:0")
 max_seq = int(os.environ.get("MAX_SEQ", T + 80))      # (MAX_SEQ: the cache's size, e.g. a power of two just above T)
 g = torch.Generator(device=dev).manual_seed(0)
