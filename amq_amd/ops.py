@@ -962,7 +962,10 @@ def attn_decode_splits(max_seq, n_heads=32, batch=1, n_kv_heads=None):
     if 2 <= g <= 16:
         # a round of the chip (workgroups = kv heads x sequences x splits), chunks of whole 128-key stages: 128 keys up to 2048 cached keys, at least 256
         # beyond (more, smaller chunks cost more in partial results than they gain: profiles/r06_attn_gqa.txt); ATTN_GQA_KEYS: A/B tools
-        per = ATTN_GQA_KEYS or max(128 if max_seq <= 2048 else 256, -(-max_seq // max(1, ATTN_CUS // (n_kv_heads * batch))))
+        want = max(1, ATTN_CUS // (n_kv_heads * batch))
+        if want > 32 and 32 * n_kv_heads * batch >= ATTN_CUS // 2:
+            want = 32           # the combine launch takes 32 chunks in one round trip: 28 / 4 heads at 16384 keys 20.2 us with 64 chunks, 17.4 with 32
+        per = ATTN_GQA_KEYS or max(128 if max_seq <= 2048 else 256, -(-max_seq // want))
         per = -(-per // 128) * 128
         return max(2, -(-max_seq // per))
     s = max(1, round(max_seq / ATTN_CHUNK))
