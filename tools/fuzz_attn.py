@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random sweep of the decode attention entry points against the eager fp32 formula (GPU box; test infrastructure, not product): random (query heads,
-kv heads, cache size, position, sequences, splits) through ops.attn_decode -- the single-workgroup kernel, the per-head split kernel and the
+kv heads, cache size, position, sequences, splits) through ops.attn_decode (and, for half as many cases, ops.attn_prefill: the prompt kernel) -- the single-workgroup kernel, the per-head split kernel and the
 grouped-query kernel (stage / tile boundaries, the first token, the last row of the cache, one .. many active chunks) -- at the tests' bound; the appended
 row must be HF's rotation of the new key, nothing else in the caches may change, the tickets must be left zero, a second run must give the same bits.
 usage: fuzz_attn.py [cases=200] [seed=0]   -- prints every failing case and exits non-zero if there was one."""
@@ -88,5 +88,60 @@ for c in range(cases):
         print("FAIL", what, "--", repr(e)[:200], flush=True)
     if c % 25 == 24:
         print(f"... {c + 1} cases, {fails} failures", flush=True)
-print(f"{cases} cases, {fails} failures")
+print(f"decode: {cases} cases, {fails} failures", flush=True)
+dec_fails = fails
+
+# ---- the prompt kernel (amq_attn_prefill_f16): random (rows, heads, kv heads, sequences, cached prefix) in both K / V layouts and with the result in
+# fragment order, against the eager causal formula
+pcases = cases // 2
+for c in range(pcases):
+    G = rng.choice([1, 1, 2, 4, 5, 7, 8])
+    nkv = rng.choice([1, 2, 3, 4, 8])
+    nh = G * nkv
+    S = rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 100, 127, 128, 129, 200, 256, 300, 511, 700, 1024])
+    batch = rng.choice([1, 1, 2, 3]) if S * nh <= 4096 * 8 else 1
+    pos0 = rng.choice([0, 0, 1, 40, 63, 64, 65, 300, 1000]) if rng.random() < 0.6 else 0
+    xfrag = batch == 1 and rng.random() < 0.3
+    what = f"prefill S {S} nh {nh} nkv {nkv} batch {batch} pos0 {pos0} xfrag {xfrag}"
+    try:
+        g = torch.Generator().manual_seed(5000 + c)
+        H, KV = nh * 128, nkv * 128
+        T = pos0 + S
+        q = torch.randn(batch * S, H, generator=g).half().to(dev)
+        use_cache = pos0 > 0 or rng.random() < 0.5
+        if use_cache:
+            max_seq = T + rng.choice([0, 1, 9, 100])
+            kc = torch.full((batch, nkv, max_seq, 128), float("nan"), dtype=torch.float16, device=dev)
+            vc = torch.full_like(kc, float("nan"))
+            kc[:, :, :T] = torch.randn(batch, nkv, T, 128, generator=g).half().to(dev)
+            vc[:, :, :T] = torch.randn(batch, nkv, T, 128, generator=g).half().to(dev)
+            kk, vv = kc, vc
+            kf, vf = kc[:, :, :T].float(), vc[:, :, :T].float()
+        else:
+            kk = torch.randn(batch * S, KV, generator=g).half().to(dev)
+            vv = torch.randn(batch * S, KV, generator=g).half().to(dev)
+            kf = kk.view(batch, S, nkv, 128).transpose(1, 2).float()
+            vf = vv.view(batch, S, nkv, 128).transpose(1, 2).float()
+        if xfrag:
+            xf = ops.attn_prefill(q, kk, vv, None, S, nh, nkv, batch=1, pos0=pos0, kv_cache=use_cache, out_xfrag=True)
+            out = ops.attn_prefill(q, kk, vv, torch.empty_like(q), S, nh, nkv, batch=1, pos0=pos0, kv_cache=use_cache)
+            assert torch.equal(xf, ops.xfrag(out, S, H)), "fragment-ordered result differs from the row-major one"
+        else:
+            out = ops.attn_prefill(q, kk, vv, torch.empty_like(q), S, nh, nkv, batch=batch, pos0=pos0, kv_cache=use_cache)
+        qf = q.view(batch, S, nh, 128).transpose(1, 2).float()
+        kf = kf.repeat_interleave(G, dim=1); vf = vf.repeat_interleave(G, dim=1)
+        sc = qf @ kf.transpose(-1, -2) / (128 ** 0.5)
+        mask = torch.arange(T, device=dev)[None, :] > (pos0 + torch.arange(S, device=dev))[:, None]
+        ref = (torch.softmax(sc.masked_fill(mask[None, None], float("-inf")), dim=-1) @ vf).transpose(1, 2).reshape(batch * S, H)
+        assert torch.isfinite(out.float()).all(), "non-finite output"
+        err_ = (out.float() - ref).abs().max().item()
+        bar = 4e-3 * ref.abs().max().item() + 1e-3
+        assert err_ <= bar, f"error {err_:.3e} over the bar {bar:.3e}"
+        again = ops.attn_prefill(q, kk, vv, torch.empty_like(q), S, nh, nkv, batch=batch, pos0=pos0, kv_cache=use_cache)
+        assert torch.equal(again, out), "not deterministic"
+    except Exception as e:                                  # noqa: BLE001
+        fails += 1
+        print("FAIL", what, "--", repr(e)[:200], flush=True)
+print(f"prefill: {pcases} cases, {fails - dec_fails} failures")
+print(f"{cases + pcases} cases, {fails} failures")
 sys.exit(1 if fails else 0)
