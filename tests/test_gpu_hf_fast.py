@@ -310,3 +310,37 @@ def test_model_families_through_the_swap_and_the_runner(family):
         assert r.inv_freq is not None and not torch.allclose(r.inv_freq.cpu(), 1.0 / (500000.0 ** (torch.arange(0, 128, 2).float() / 128)))
     if family == "qwen2":
         assert r.has_bias and (r.nh, r.nkv, r.H) == (7, 1, 896)
+
+
+@pytest.mark.parametrize("family", ["mistral", "qwen2", "llama"])
+def test_grouped_query_families_decode_over_a_long_cache(family):
+    """a cache of 1024 rows puts the decode attention of the grouped-query families (4 / 7 / 2 query heads per kv head) on the grouped kernel
+    (attn_decode_gqa_kernel: one workgroup per kv head and chunk, matrix cores): a 600-token prompt, then decode steps fed HF's own greedy tokens --
+    every step's logits against HF's past_key_values loop over the same modules"""
+    from amq_amd import ops
+    from amq_amd.llama import QuantLlama
+    model, _ = _prepared(family)
+    model.config.max_position_embeddings = 2048                    # (the tiny configs say 256; the default rotary embedding does not depend on it)
+    ids = torch.randint(1, 1000, (1, 600), generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.inference_mode():
+        o = model(ids, use_cache=True)
+        past, tok = o.past_key_values, o.logits[:, -1].max(1)[1].unsqueeze(1)
+        first_lg = o.logits[0, -1].float()
+        toks, slow_lg = [int(tok)], []
+        for _ in range(5):
+            o = model(tok, past_key_values=past, use_cache=True)
+            past = o.past_key_values
+            slow_lg.append(o.logits[0, -1].float())
+            tok = o.logits[:, -1].max(1)[1].unsqueeze(1)
+            toks.append(int(tok))
+    r = QuantLlama.from_hf(model, max_seq=1024)
+    assert r.nh // r.nkv in (2, 4, 7) and ops.attn_decode_splits(1024, r.nh, 1, r.nkv) > 1
+    scale = first_lg.abs().max()
+    with torch.inference_mode():
+        r.prefill(ids[0])
+        assert (r.logits.view(-1).float() - first_lg).abs().max() <= 6e-3 * scale
+        for i in range(5):
+            r.set_token(torch.as_tensor([toks[i]], device=DEV))
+            r.decode_step()
+            assert (r.logits.view(-1).float() - slow_lg[i]).abs().max() <= 6e-3 * scale, i
+    assert r.host_pos == 605
