@@ -658,6 +658,9 @@ hipError_t launch_attn_decode_gqa(const AttnArgs& a, int batch, int n_splits, vo
     if (hipError_t e = ensure_dyn_lds(attr_done, (const void*)attn_decode_gqa_kernel, (int)lds)) return e;
     hipLaunchKernelGGL(attn_decode_gqa_kernel, dim3(g.n_kv_heads, batch, g.n_splits), dim3(256), lds, st, g);
     if (hipError_t e = hipGetLastError()) return e;
+#ifdef AMQ_GQA_ABL_NO_COMBINE          /* timing-only ablation: what the combine launch adds to the step (results wrong beyond one chunk) */
+    return hipSuccess;
+#endif
     hipLaunchKernelGGL(attn_gqa_combine_kernel, dim3(g.n_heads, batch), dim3(128), 0, st, (const float*)g.ws, g.out, g.state, g.pos, g.cur_mode,
                        g.n_heads, g.max_seq, g.n_splits, AG_STAGE_KEYS * g.iters);
     return hipGetLastError();
